@@ -1,0 +1,123 @@
+/*
+ * mpcgpu.h -- C-ABI of libmpcgpu.so: the MI355X-native batched NMPC solver.
+ *
+ * This is the drop-in boundary for the reference's solver plugin.  The reference loads a generated
+ * OpEn/PyO3 module and calls (paths relative to /root/reference/):
+ *
+ *     built_solver = __import__(config.optimizer_name)          src/mpc_traj_tracker/trajectory_generator.py:70
+ *     self.solver  = built_solver.solver()                      trajectory_generator.py:71
+ *     solution     = self.solver.run(parameters, initial_guess) trajectory_generator.py:318
+ *     solution.solution / .cost / .exit_status / .solve_time_ms trajectory_generator.py:320-323
+ *     (stub signature incl. initial_lagrange_multipliers, initial_penalty: trajectory_generator.py:25-27)
+ *
+ * and the problem that solver was generated from is defined at
+ *     src/mpc_traj_tracker/mpc/mpc_generator.py:160-297   (cost, constraints, solver settings)
+ *     src/pkg_motion_model/motion_model.py:142-164         (unicycle RK4)
+ *
+ * Entry points below replace exactly that: create (= "build" the solver for a config), solve a batch of
+ * independent parameter vectors `p` (same layout as mpc_generator.py:179-188), destroy.  Plain pointers
+ * and sizes only; the library never frees caller memory, never throws; return 0 = ok, < 0 = error
+ * (text via mpcgpu_last_error).  One handle per (device, stream); a handle is not thread-safe.
+ * There is NO CPU fallback: without a usable HIP device mpcgpu_create fails.
+ */
+#ifndef MPCGPU_H
+#define MPCGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPCGPU_ABI_VERSION 1
+
+/* replaces: the yaml config consumed by MpcModule.build (mpc_generator.py:151-158, config/mpc_default.yaml:7-55)
+ * plus the SolverConfiguration of mpc_generator.py:285-293 (opengen defaults quoted there). */
+typedef struct mpcgpu_config {
+    int32_t N;        /* N_hor (1..64) */
+    int32_t nu;       /* 2 */
+    int32_t ns;       /* 3 */
+    int32_t Nother;   /* max other robots        (<= 16) */
+    int32_t Nstcobs;  /* max static obstacles    (<= 16) */
+    int32_t nstcobs;  /* 12 = 4 edges x (b,a0,a1) */
+    int32_t Ndynobs;  /* max dynamic obstacles   (1..32) */
+    int32_t ndynobs;  /* 6 = (x,y,rx,ry,angle,alpha) */
+    double ts;
+    double lin_vel_min, lin_vel_max, ang_vel_max;
+    double lin_acc_min, lin_acc_max, ang_acc_max;
+    double vehicle_width, social_margin, fleet_weight; /* fleet_weight = 1000 (mpc_generator.py:216) */
+    double tol;            /* 1e-4  */
+    double delta_tol;      /* 1e-4  */
+    double init_tol;       /* 1e-4  */
+    double init_penalty;   /* 10    (mpc_generator.py:286) */
+    double penalty_update; /* 5     */
+    double tol_update;     /* 0.1   */
+    double suff_decrease;  /* 0.1   */
+    int32_t max_inner;     /* 500   */
+    int32_t max_outer;     /* 10    */
+    int32_t lbfgs_mem;     /* 10 (1..16) */
+    int32_t device;        /* HIP device ordinal (>= 0) */
+    double max_duration_us; /* 5e6 (mpc_generator.py:22); <= 0 disables the in-kernel clock test */
+} mpcgpu_config;
+
+/* exit_status codes; names as in config/mpc_default.yaml:54 */
+enum { MPCGPU_CONVERGED = 0, MPCGPU_NOT_CONVERGED_ITERATIONS = 1, MPCGPU_NOT_CONVERGED_OUT_OF_TIME = 2 };
+
+/* replaces: MpcModule.build + __import__(optimizer_name).solver()  (trajectory_generator.py:63-71) */
+int32_t mpcgpu_create(const mpcgpu_config* cfg, void** handle);
+void mpcgpu_destroy(void* handle);
+
+/* error text of the last failing call on this handle (handle == NULL: last mpcgpu_create failure) */
+const char* mpcgpu_last_error(void* handle);
+
+/* len(p) for this config: mpc_generator.py:179-188 */
+int32_t mpcgpu_num_params(void* handle);
+int32_t mpcgpu_abi_version(void);
+
+/*
+ * replaces: solver.run(p, initial_guess, initial_lagrange_multipliers, initial_penalty) for B problems
+ * (trajectory_generator.py:318).  HOST pointers.  u0 / y0 / c0 may be NULL (zeros / zeros / init_penalty:
+ * every reference call site passes initial_guess=None, src/interface_mpc.py:82).  Output pointers other
+ * than u, cost, status may be NULL.
+ *   p      [B x np]    u0 [B x 2N]   y0 [B x 2N]   c0 [B]
+ *   u      [B x 2N]    cost [B] (= f(u), penalty terms excluded)   status [B]
+ *   inner_it, outer_it [B]   fpr [B] (last inner ||gamma*fpr||)   f2norm [B]   y_out [B x 2N]
+ *   ms     [B]  device residency time of each solve (the solve_time_ms field of the plugin result)
+ * Synchronous: results are in place on return.
+ */
+int32_t mpcgpu_solve_batch(void* handle, int32_t B, const double* p, const double* u0, const double* y0,
+                           const double* c0, double* u, double* cost, int32_t* status, int32_t* inner_it,
+                           int32_t* outer_it, double* fpr, double* f2norm, double* y_out, double* ms);
+
+/* Same, DEVICE pointers (e.g. torch tensors' data_ptr()), enqueued on `stream` (hipStream_t; NULL = the
+ * handle's own stream).  Contains one small device->host read of the batch's active-obstacle counts, then
+ * the solve kernel launch; returns after enqueueing the solve kernel (call hipStreamSynchronize / torch sync
+ * before reading results). */
+int32_t mpcgpu_solve_batch_dev(void* handle, int32_t B, const double* p, const double* u0, const double* y0,
+                               const double* c0, double* u, double* cost, int32_t* status, int32_t* inner_it,
+                               int32_t* outer_it, double* fpr, double* f2norm, double* y_out, double* ms,
+                               void* stream);
+
+/*
+ * Test hook -- replaces the generated CasADi functions cost(u, xi, p) / grad_cost / mapping_f1 / mapping_f2
+ * that OpEn calls (built by mpc_generator.py:295-297): evaluates them once per problem on the GPU through
+ * the very same device code the solver kernel uses.  HOST pointers.
+ *   u [B x 2N]   xi [B x (1+2N)] = (c, y)   p [B x np]
+ *   psi [B]  f [B]  grad [B x 2N]  F1 [B x 2N]  F2 [B x Ndynobs]     (any output may be NULL)
+ */
+int32_t mpcgpu_cost_grad_batch(void* handle, int32_t B, const double* u, const double* xi, const double* p,
+                               double* psi, double* f, double* grad, double* F1, double* F2);
+
+/* Device time (ms, HIP events on the launch stream) of the last solve call: parameter-compaction kernel and
+ * solve kernel.  Valid after the stream has been synchronised. */
+int32_t mpcgpu_last_timing(void* handle, double* prep_ms, double* solve_ms);
+
+/* Batch-wide maxima of active entries seen by the last solve / cost_grad call: static obstacles, fleet
+ * entries, dynamic-obstacle entries (sizes the LDS carve), and the LDS bytes per wavefront used. */
+int32_t mpcgpu_last_shape(void* handle, int32_t* max_static, int32_t* max_fleet, int32_t* max_dyn,
+                          int32_t* lds_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPCGPU_H */

@@ -1,0 +1,784 @@
+// mpc_kernels.hpp -- device code of the batched NMPC solver for gfx950 (MI355X, wave64).
+//
+// One problem instance per 64-lane wavefront (one wavefront per workgroup):
+//   * "vector lanes"  k < N hold step k of every horizon vector: (v_k, w_k) of u, grad, FPR, L-BFGS work
+//     vectors, multipliers ... -- 2 doubles per lane, so n = 2N-dim vector algebra is one instruction and an
+//     inner product is one wave reduction;
+//   * "item lanes"    (k, sub) = (lane % N, lane / N), lane < N*LPS, split the (step x object) stage-cost
+//     terms of step k (reference-path segments, static polygons, dynamic ellipses, fleet discs);
+//   * the compacted problem tables and the L-BFGS memory live in LDS; HBM is touched once per solve.
+//
+// What is restated (paths relative to /root/reference/):
+//   cost / constraints : src/mpc_traj_tracker/mpc/mpc_generator.py:25-54,85-130,160-272
+//   unicycle RK4       : src/pkg_motion_model/motion_model.py:142-164 (closed form: Simpson on the heading)
+//   solver             : the OpEn algorithm the reference generates at mpc_generator.py:269-297
+//                        (PANOC + L-BFGS + ALM/PM; published algorithm)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mpcgpu {
+
+constexpr int WAVE = 64;
+constexpr int HDR = 64;        // header doubles per problem in the workspace
+constexpr int SEGW = 6;        // doubles per reference segment  (s1x, s1y, dx, dy, 1/(|d|^2+1e-16), pad)
+constexpr int STCW = 12;       // doubles per static obstacle    (b[4], a0[4], a1[4])
+constexpr int DYNW = 9;        // doubles per (dyn entry, step)  (cx, cy, cosA, sinA, ihx, ihy, isx, isy, wgt)
+constexpr int PARTW = 5;       // doubles per item-lane partial  (gx, gy, best, bgx, bgy)
+constexpr int MAX_MEM = 16;
+
+// header slots
+enum { H_KS = 18, H_KF = 19, H_KD = 20, H_CTH0 = 21, H_STH0 = 22, H_ENTRY = 24 /* .. +Ndynobs */ };
+
+struct KParams {
+    int N, LPS, Nother, Nstcobs, Ndynobs, np, mem;
+    int max_inner, max_outer;
+    double ts, inv_ts;
+    double vmin, vmax, wmax, amin, amax, aamax;
+    double W2, social, fleetw;
+    double tol, delta_tol, init_tol, init_penalty, penalty_update, tol_update, suff_decrease;
+    long long max_ticks;  // wall_clock64 ticks (100 MHz); <= 0 disables
+    // parameter-vector offsets (mpc_generator.py:179-188)
+    int r0, c0, os0, od0, qs0, qd0;
+    // workspace (global) layout per problem, doubles
+    int ws_stride, ws_vref, ws_seg, ws_stc, ws_fm, ws_fxy, ws_dm, ws_dyn;
+    // LDS layout (doubles), strides use the batch maxima mKs/mKf/mKd
+    int mKs, mKf, mKd;
+    int l_seg, l_stc, l_fm, l_fxy, l_dm, l_dyn, l_pos, l_H, l_W, l_part, l_S, l_Y, l_rho, l_alpha, l_total;
+};
+
+struct BatchPtrs {
+    const double* p; const double* u0; const double* y0; const double* c0;
+    double* u; double* cost; int32_t* status; int32_t* inner_it; int32_t* outer_it;
+    double* fpr; double* f2norm; double* y_out; double* ms;
+    double* ws; int* counts;
+};
+
+// ------------------------------------------------------------------------------------------------
+// wave helpers (all 64 lanes participate; results of sums are bit-identical in every lane)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) x += __shfl_xor(x, d);
+    return x;
+}
+__device__ __forceinline__ double uniform(double x) {  // tell the compiler x is wave-uniform
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_u(double x) { return uniform(wave_sum(x)); }
+// inclusive prefix sum over lanes 0..n-1 (lanes >= n must carry 0)
+__device__ __forceinline__ double scan_prefix(double x, int lane, int n) {
+    for (int d = 1; d < n; d <<= 1) {
+        const double t = __shfl_up(x, d);
+        if (lane >= d) x += t;
+    }
+    return x;
+}
+// inclusive suffix sum over lanes 0..n-1 (lanes >= n must carry 0)
+__device__ __forceinline__ double scan_suffix(double x, int lane, int n) {
+    for (int d = 1; d < n; d <<= 1) {
+        const double t = __shfl_down(x, d);
+        if (lane + d < WAVE) x += t;
+    }
+    return x;
+}
+__device__ __forceinline__ double shift_up1(double x, int lane, double first) {  // lane k gets lane k-1
+    const double t = __shfl_up(x, 1);
+    return lane == 0 ? first : t;
+}
+__device__ __forceinline__ double shift_down1(double x, int lane) {  // lane k gets lane k+1 (lane 63: 0)
+    const double t = __shfl_down(x, 1);
+    return lane == WAVE - 1 ? 0.0 : t;
+}
+__device__ __forceinline__ double clampd(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
+
+// ------------------------------------------------------------------------------------------------
+// parameter compaction: p (mpc_generator.py:179-188 layout, mostly zero padding) -> per-problem tables
+//   * all-zero static obstacles contribute exactly 0 (prod of max(0,0)^2)           -> dropped
+//   * all-zero other-robot rows are identical discs at the origin                   -> one entry x multiplicity
+//   * all-zero dynamic-obstacle rows are identical (rx=ry=0, alpha=0) ellipses at 0 -> one entry x multiplicity
+//   (zero padding keeps its reference semantics: a robot near the origin still feels it.)
+// one 64-thread block per problem.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE) void prep_kernel(KParams kp, BatchPtrs io, int B) {
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    const int lane = threadIdx.x;
+    const int N = kp.N;
+    const double* __restrict__ p = io.p + (size_t)b * kp.np;
+    double* __restrict__ ws = io.ws + (size_t)b * kp.ws_stride;
+
+    if (lane < 18) ws[lane] = p[lane];
+    if (lane == 0) {
+        double s, c;
+        sincos(p[2], &s, &c);
+        ws[H_CTH0] = c;
+        ws[H_STH0] = s;
+    }
+    // reference segments i = 0..N-1: (ref_i, ref_{i+1}), ref_N := ref_{N-1}  (mpc_generator.py:194-195)
+    for (int i = lane; i < N; i += WAVE) {
+        const int i2 = (i + 1 < N) ? i + 1 : N - 1;
+        const double s1x = p[kp.r0 + 3 * i], s1y = p[kp.r0 + 3 * i + 1];
+        const double dx = p[kp.r0 + 3 * i2] - s1x, dy = p[kp.r0 + 3 * i2 + 1] - s1y;
+        double* sg = ws + kp.ws_seg + SEGW * i;
+        sg[0] = s1x; sg[1] = s1y; sg[2] = dx; sg[3] = dy;
+        sg[4] = 1.0 / (dx * dx + dy * dy + 1e-16);
+        sg[5] = 0.0;
+        ws[kp.ws_vref + i] = p[kp.r0 + 3 * N + i];
+    }
+    // ---- static obstacles: lane o checks obstacle o
+    int Ks;
+    {
+        bool nz = false;
+        if (lane < kp.Nstcobs)
+            for (int e = 0; e < STCW; ++e) nz |= (p[kp.os0 + STCW * lane + e] != 0.0);
+        const unsigned long long m = __ballot(nz);
+        Ks = __popcll(m);
+        if (nz) {
+            const int idx = __popcll(m & ((1ull << lane) - 1ull));
+            for (int e = 0; e < STCW; ++e) ws[kp.ws_stc + STCW * idx + e] = p[kp.os0 + STCW * lane + e];
+        }
+    }
+    // ---- other robots: lane j checks robot j (x,y only; theta never enters the cost)
+    int Kf;
+    {
+        bool nz = false;
+        if (lane < kp.Nother)
+            for (int k = 0; k < N; ++k) {
+                const int o = kp.c0 + lane * 3 * N + 3 * k;
+                nz |= (p[o] != 0.0) | (p[o + 1] != 0.0);
+            }
+        const unsigned long long m = __ballot(nz);
+        const int na = __popcll(m);
+        const int npad = kp.Nother - na;
+        Kf = na + (npad > 0 ? 1 : 0);
+        if (nz) {
+            const int idx = __popcll(m & ((1ull << lane) - 1ull));
+            ws[kp.ws_fm + idx] = 1.0;
+            for (int k = 0; k < N; ++k) {
+                const int o = kp.c0 + lane * 3 * N + 3 * k;
+                ws[kp.ws_fxy + (idx * N + k) * 2] = p[o];
+                ws[kp.ws_fxy + (idx * N + k) * 2 + 1] = p[o + 1];
+            }
+        }
+        if (npad > 0) {
+            if (lane == 0) ws[kp.ws_fm + na] = (double)npad;
+            for (int k = lane; k < N; k += WAVE) {
+                ws[kp.ws_fxy + (na * N + k) * 2] = 0.0;
+                ws[kp.ws_fxy + (na * N + k) * 2 + 1] = 0.0;
+            }
+        }
+    }
+    // ---- dynamic obstacles: lane i checks row i
+    int Kd;
+    __shared__ int s_entry[WAVE];  // original row -> entry (or -1 for padded rows)
+    {
+        bool nz = false;
+        if (lane < kp.Ndynobs)
+            for (int t = 0; t < 6 * N; ++t) nz |= (p[kp.od0 + lane * 6 * N + t] != 0.0);
+        const unsigned long long m = __ballot(nz);
+        const int na = __popcll(m);
+        const int npad = kp.Ndynobs - na;
+        Kd = na + (npad > 0 ? 1 : 0);
+        const int idx = nz ? __popcll(m & ((1ull << lane) - 1ull)) : na;  // padded rows share entry `na`
+        if (lane < kp.Ndynobs) {
+            ws[H_ENTRY + lane] = (double)idx;
+            s_entry[lane] = nz ? idx : -1;
+            if (nz) ws[kp.ws_dm + idx] = 1.0;
+        }
+        if (npad > 0 && lane == 0) ws[kp.ws_dm + na] = (double)npad;
+        __syncthreads();
+        // (row, step) items: sincos of the ellipse angle and the inverse squared semi-axes, once per solve
+        for (int t = lane; t < kp.Ndynobs * N; t += WAVE) {
+            const int i = t / N, k = t - i * N;
+            const int e = s_entry[i];
+            if (e < 0) continue;
+            const double* q = p + kp.od0 + i * 6 * N + 6 * k;
+            double* d = ws + kp.ws_dyn + (e * N + k) * DYNW;
+            double sa, ca;
+            sincos(q[4], &sa, &ca);
+            const double rx = q[2], ry = q[3];
+            d[0] = q[0]; d[1] = q[1]; d[2] = ca; d[3] = sa;
+            d[4] = 1.0 / ((rx + 1e-6) * (rx + 1e-6));
+            d[5] = 1.0 / ((ry + 1e-6) * (ry + 1e-6));
+            d[6] = 1.0 / ((rx + kp.social + 1e-6) * (rx + kp.social + 1e-6));
+            d[7] = 1.0 / ((ry + kp.social + 1e-6) * (ry + kp.social + 1e-6));
+            d[8] = p[kp.qd0 + k] * q[5];  // q_dyn[k] * alpha
+        }
+        if (npad > 0) {
+            for (int k = lane; k < N; k += WAVE) {
+                double* d = ws + kp.ws_dyn + (na * N + k) * DYNW;
+                d[0] = 0.0; d[1] = 0.0; d[2] = 1.0; d[3] = 0.0;
+                d[4] = 1.0 / ((0.0 + 1e-6) * (0.0 + 1e-6));
+                d[5] = d[4];
+                d[6] = 1.0 / ((kp.social + 1e-6) * (kp.social + 1e-6));
+                d[7] = d[6];
+                d[8] = 0.0;  // alpha = 0: the soft term of a padded row is exactly 0
+            }
+        }
+    }
+    if (lane == 0) {
+        ws[H_KS] = (double)Ks; ws[H_KF] = (double)Kf; ws[H_KD] = (double)Kd;
+        atomicMax(io.counts + 0, Ks);
+        atomicMax(io.counts + 1, Kf);
+        atomicMax(io.counts + 2, Kd);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-wave problem context
+// ------------------------------------------------------------------------------------------------
+struct Ctx {
+    // uniform problem scalars
+    double x0, y0, th0, cth0, sth0, xg, yg, thg, v_init, w_init;
+    double qvel, rv, rw, qN, qthN, qrpd, acc_pen, wacc_pen;
+    int Ks, Kf, Kd;
+    // lane roles
+    int lane, ik, isub;
+    bool vl, il;
+    double vref;  // vector lane k: speed reference of step k
+    // LDS tables
+    double *seg, *stc, *fm, *fxy, *dm, *dyn, *pos, *H, *W, *part;
+};
+
+struct EvalOut {
+    double psi, f, nrm2F2;  // uniform
+    double gv, gw;          // vector lanes: d psi / d (v_k, w_k)
+    double F1a, F1b;        // vector lanes: acceleration mapping F1[k], F1[N+k]
+    double F2e;             // lane i < Kd: F2 value of dynamic entry i
+};
+
+__device__ __forceinline__ void load_problem(const KParams& kp, const double* __restrict__ ws, double* lds,
+                                             Ctx& cx) {
+    const int lane = threadIdx.x;
+    const int N = kp.N;
+    cx.lane = lane;
+    cx.vl = lane < N;
+    cx.il = lane < N * kp.LPS;
+    cx.ik = lane % N;
+    cx.isub = lane / N;
+    cx.x0 = ws[0]; cx.y0 = ws[1]; cx.th0 = ws[2]; cx.xg = ws[3]; cx.yg = ws[4]; cx.thg = ws[5];
+    cx.v_init = ws[6]; cx.w_init = ws[7];
+    cx.qvel = ws[9]; cx.rv = ws[11]; cx.rw = ws[12]; cx.qN = ws[13]; cx.qthN = ws[14]; cx.qrpd = ws[15];
+    cx.acc_pen = ws[16]; cx.wacc_pen = ws[17];
+    cx.Ks = (int)ws[H_KS]; cx.Kf = (int)ws[H_KF]; cx.Kd = (int)ws[H_KD];
+    cx.cth0 = ws[H_CTH0]; cx.sth0 = ws[H_STH0];
+    cx.vref = cx.vl ? ws[kp.ws_vref + lane] : 0.0;
+    cx.seg = lds + kp.l_seg; cx.stc = lds + kp.l_stc; cx.fm = lds + kp.l_fm; cx.fxy = lds + kp.l_fxy;
+    cx.dm = lds + kp.l_dm; cx.dyn = lds + kp.l_dyn; cx.pos = lds + kp.l_pos; cx.H = lds + kp.l_H;
+    cx.W = lds + kp.l_W; cx.part = lds + kp.l_part;
+    // coalesced table copies HBM -> LDS (only the active entries of this problem)
+    for (int i = lane; i < N * SEGW; i += WAVE) cx.seg[i] = ws[kp.ws_seg + i];
+    for (int i = lane; i < cx.Ks * STCW; i += WAVE) cx.stc[i] = ws[kp.ws_stc + i];
+    for (int i = lane; i < cx.Kf; i += WAVE) cx.fm[i] = ws[kp.ws_fm + i];
+    for (int i = lane; i < cx.Kf * N * 2; i += WAVE) cx.fxy[i] = ws[kp.ws_fxy + i];
+    for (int i = lane; i < cx.Kd; i += WAVE) cx.dm[i] = ws[kp.ws_dm + i];
+    for (int i = lane; i < cx.Kd * N * DYNW; i += WAVE) cx.dyn[i] = ws[kp.ws_dyn + i];
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// psi(u; c, y), f(u), F1, F2 and (optionally) grad psi at the point held by the vector lanes.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, double v, double w, double c,
+                                           double ya, double yb, bool want_grad, EvalOut& out) {
+    const int N = kp.N, LPS = kp.LPS, lane = cx.lane;
+    const double ts = kp.ts;
+    const double inf = __builtin_huge_val();
+    if (!cx.vl) { v = 0.0; w = 0.0; }
+
+    // ---- rollout: headings are a prefix sum of ts*w, positions a prefix sum of Simpson increments
+    const double tw = ts * w;
+    const double th1 = cx.th0 + scan_prefix(tw, lane, N);  // theta_{k+1}
+    const double thm = th1 - 0.5 * tw;                      // theta_k + ts*w_k/2
+    double sm, cm, s2, c2;
+    sincos(thm, &sm, &cm);
+    sincos(th1, &s2, &c2);
+    const double c0 = shift_up1(c2, lane, cx.cth0), s0 = shift_up1(s2, lane, cx.sth0);
+    const double sixth = 1.0 / 6.0;
+    const double Cx = (c0 + 4.0 * cm + c2) * sixth, Sy = (s0 + 4.0 * sm + s2) * sixth;
+    const double dCw = -ts * (2.0 * sm + s2) * sixth, dSw = ts * (2.0 * cm + c2) * sixth;
+    const double X = cx.x0 + scan_prefix(cx.vl ? ts * v * Cx : 0.0, lane, N);
+    const double Y = cx.y0 + scan_prefix(cx.vl ? ts * v * Sy : 0.0, lane, N);
+    if (cx.vl) { cx.pos[2 * lane] = X; cx.pos[2 * lane + 1] = Y; }
+    __syncthreads();
+
+    // ---- item phase A: stage terms of step ik handled by this lane
+    double cost_l = 0.0, S_l = 0.0, gx = 0.0, gy = 0.0, dsx = 0.0, dsy = 0.0;
+    double best = inf, bgx = 0.0, bgy = 0.0;
+    double px = 0.0, py = 0.0;
+    if (cx.il) {
+        const int k = cx.ik;
+        px = cx.pos[2 * k]; py = cx.pos[2 * k + 1];
+        // reference-path deviation: min over segments i >= k (mpc_generator.py:207,116-130,28-36)
+        for (int i = k + cx.isub; i < N; i += LPS) {
+            const double* sg = cx.seg + SEGW * i;
+            const double s1x = sg[0], s1y = sg[1], dx = sg[2], dy = sg[3], inv = sg[4];
+            const double th = ((px - s1x) * dx + (py - s1y) * dy) * inv;
+            const double t = clampd(th, 0.0, 1.0);
+            const double wx = s1x + t * dx - px, wy = s1y + t * dy - py;
+            const double d2 = wx * wx + wy * wy;
+            if (d2 < best) {
+                best = d2;
+                const double wd = (th >= 0.0 && th <= 1.0) ? (wx * dx + wy * dy) * inv : 0.0;
+                bgx = 2.0 * (wd * dx - wx);
+                bgy = 2.0 * (wd * dy - wy);
+            }
+        }
+        // fleet discs (mpc_generator.py:211-216,105-108)
+        for (int j = cx.isub; j < cx.Kf; j += LPS) {
+            const double mult = cx.fm[j];
+            const double ex = px - cx.fxy[(j * N + k) * 2], ey = py - cx.fxy[(j * N + k) * 2 + 1];
+            const double hh = kp.W2 - (ex * ex + ey * ey);
+            if (hh > 0.0) {
+                const double wj = kp.fleetw * mult;
+                cost_l += wj * hh;
+                gx -= 2.0 * wj * ex;
+                gy -= 2.0 * wj * ey;
+            }
+        }
+        // static polygons, 4 half-planes each (mpc_generator.py:219-225,46-54)
+        for (int o = cx.isub; o < cx.Ks; o += LPS) {
+            const double* s = cx.stc + STCW * o;
+            const double m0 = fmax(0.0, s[0] - s[4] * px - s[8] * py);
+            const double m1 = fmax(0.0, s[1] - s[5] * px - s[9] * py);
+            const double m2 = fmax(0.0, s[2] - s[6] * px - s[10] * py);
+            const double m3 = fmax(0.0, s[3] - s[7] * px - s[11] * py);
+            const double q0 = m0 * m0, q1 = m1 * m1, q2 = m2 * m2, q3 = m3 * m3;
+            const double p01 = q0 * q1, p23 = q2 * q3;
+            const double prod = p01 * p23;
+            if (prod > 0.0) {
+                S_l += prod;
+                const double r0 = 2.0 * m0 * q1 * p23, r1 = 2.0 * m1 * q0 * p23;
+                const double r2 = 2.0 * m2 * q3 * p01, r3 = 2.0 * m3 * q2 * p01;
+                dsx -= r0 * s[4] + r1 * s[5] + r2 * s[6] + r3 * s[7];
+                dsy -= r0 * s[8] + r1 * s[9] + r2 * s[10] + r3 * s[11];
+            }
+        }
+        // dynamic ellipses: hard indicator -> H, soft cost with social margin (mpc_generator.py:229-241,38-44,85-95)
+        for (int i = cx.isub; i < cx.Kd; i += LPS) {
+            const double* e = cx.dyn + (i * N + k) * DYNW;
+            const double ex = px - e[0], ey = py - e[1], ca = e[2], sa = e[3];
+            const double a = ex * ca + ey * sa, bb = ex * sa - ey * ca;
+            const double a2 = a * a, b2 = bb * bb;
+            const double Ih = 1.0 - a2 * e[4] - b2 * e[5];
+            cx.H[i * N + k] = Ih > 0.0 ? Ih : 0.0;
+            const double Is = 1.0 - a2 * e[6] - b2 * e[7];
+            if (Is > 0.0) {
+                const double wgt = e[8] * cx.dm[i];
+                cost_l += wgt * Is * Is;
+                const double wI = 2.0 * wgt * Is;
+                gx += wI * (-2.0 * a * ca * e[6] - 2.0 * bb * sa * e[7]);
+                gy += wI * (-2.0 * a * sa * e[6] + 2.0 * bb * ca * e[7]);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- constraint sums: S (static, broadcast into every F2 component), D_i (row sums of H)
+    const double S = wave_sum_u(S_l);
+    double F2e = 0.0, mult_i = 0.0;
+    if (lane < cx.Kd) {
+        double D = 0.0;
+        for (int k = 0; k < N; ++k) D += cx.H[lane * N + k];
+        mult_i = cx.dm[lane];
+        F2e = S + D;
+    }
+    const double nrm2F2 = wave_sum_u(mult_i * F2e * F2e);
+    out.F2e = F2e;
+    out.nrm2F2 = nrm2F2;
+
+    // ---- item phase B (only when some penalty constraint is violated): weighted hard-constraint gradients
+    if (want_grad && nrm2F2 > 0.0) {
+        const double sumF2 = wave_sum_u(mult_i * F2e);
+        if (lane < cx.Kd) cx.W[lane] = c * mult_i * F2e;
+        __syncthreads();
+        if (cx.il) {
+            const int k = cx.ik;
+            for (int i = cx.isub; i < cx.Kd; i += LPS) {
+                const double* e = cx.dyn + (i * N + k) * DYNW;
+                const double ex = px - e[0], ey = py - e[1], ca = e[2], sa = e[3];
+                const double a = ex * ca + ey * sa, bb = ex * sa - ey * ca;
+                const double Ih = 1.0 - a * a * e[4] - bb * bb * e[5];
+                if (Ih > 0.0) {
+                    const double wi = cx.W[i];
+                    gx += wi * (-2.0 * a * ca * e[4] - 2.0 * bb * sa * e[5]);
+                    gy += wi * (-2.0 * a * sa * e[4] + 2.0 * bb * ca * e[5]);
+                }
+            }
+            gx += c * sumF2 * dsx;
+            gy += c * sumF2 * dsy;
+        }
+    }
+
+    // ---- combine the LPS item lanes of each step on its vector lane
+    if (cx.il) {
+        double* pp = cx.part + (cx.isub * N + cx.ik) * PARTW;
+        pp[0] = gx; pp[1] = gy; pp[2] = best; pp[3] = bgx; pp[4] = bgy;
+    }
+    __syncthreads();
+    double Gx = 0.0, Gy = 0.0, vcost = 0.0;
+    if (cx.vl) {
+        double bb = inf, wbx = 0.0, wby = 0.0;
+        for (int s = 0; s < LPS; ++s) {
+            const double* pp = cx.part + (s * N + lane) * PARTW;
+            Gx += pp[0]; Gy += pp[1];
+            if (pp[2] < bb) { bb = pp[2]; wbx = pp[3]; wby = pp[4]; }
+        }
+        // LPS lanes interleave segments; the reference's left fold keeps the lowest index on ties, which is
+        // what "<" over sub = 0.. gives for equal values only up to interleaving -- ties have equal gradients
+        // for end-to-end segments (shared vertex), see DESIGN.md.
+        Gx += cx.qrpd * wbx; Gy += cx.qrpd * wby;
+        vcost = cx.qrpd * bb;
+    }
+
+    // ---- per-step terms on the vector lanes (mpc_generator.py:208-209,246,254-267)
+    const double vprev = shift_up1(v, lane, cx.v_init), wprev = shift_up1(w, lane, cx.w_init);
+    const double a = cx.vl ? (v - vprev) * kp.inv_ts : 0.0;
+    const double bacc = cx.vl ? (w - wprev) * kp.inv_ts : 0.0;
+    out.F1a = a; out.F1b = bacc;
+    const double icm = 1.0 / fmax(c, 1.0);
+    const double za = a + ya * icm, zb = bacc + yb * icm;
+    const double ea = za > kp.amax ? za - kp.amax : (za < kp.amin ? za - kp.amin : 0.0);
+    const double eb = zb > kp.aamax ? zb - kp.aamax : (zb < -kp.aamax ? zb + kp.aamax : 0.0);
+    double gthN = 0.0;
+    if (cx.vl) {
+        const double dv = v - cx.vref;
+        vcost += cx.qvel * dv * dv + cx.rv * v * v + cx.rw * w * w + cx.acc_pen * a * a + cx.wacc_pen * bacc * bacc;
+        if (lane == N - 1) {
+            const double ex = X - cx.xg, ey = Y - cx.yg, et = th1 - cx.thg;
+            vcost += cx.qN * (ex * ex + ey * ey) + cx.qthN * et * et;
+            Gx += 2.0 * cx.qN * ex; Gy += 2.0 * cx.qN * ey;
+            gthN = 2.0 * cx.qthN * et;
+        }
+    }
+    const double f = wave_sum_u(cost_l + vcost);
+    const double dist2 = wave_sum_u(cx.vl ? ea * ea + eb * eb : 0.0);
+    out.f = f;
+    out.psi = f + 0.5 * c * dist2 + 0.5 * c * nrm2F2;
+
+    if (want_grad) {
+        gthN = __shfl(gthN, N - 1);
+        const double da = cx.vl ? (2.0 * cx.acc_pen * a + c * ea) * kp.inv_ts : 0.0;
+        const double db = cx.vl ? (2.0 * cx.wacc_pen * bacc + c * eb) * kp.inv_ts : 0.0;
+        const double da_n = shift_down1(da, lane), db_n = shift_down1(db, lane);
+        double gv = 2.0 * cx.qvel * (v - cx.vref) + 2.0 * cx.rv * v + da - da_n;
+        double gw = 2.0 * cx.rw * w + db - db_n;
+        // adjoint of the rollout: suffix sums instead of a serial backward sweep
+        const double Ax = scan_suffix(Gx, lane, N), Ay = scan_suffix(Gy, lane, N);
+        const double T = cx.vl ? ts * v * (-Sy * Ax + Cx * Ay) : 0.0;
+        const double Bx = scan_suffix(T, lane, N) - T;
+        gv += ts * (Cx * Ax + Sy * Ay);
+        gw += ts * v * (dCw * Ax + dSw * Ay) + ts * (Bx + gthN);
+        out.gv = cx.vl ? gv : 0.0;
+        out.gw = cx.vl ? gw : 0.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// test-hook kernel: one evaluation per problem through eval_point
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE) void cost_grad_kernel(KParams kp, BatchPtrs io, const double* __restrict__ u,
+                                                         const double* __restrict__ xi, double* psi, double* f,
+                                                         double* grad, double* F1, double* F2, int B) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    const int lane = threadIdx.x, N = kp.N;
+    const double* ws = io.ws + (size_t)b * kp.ws_stride;
+    Ctx cx;
+    load_problem(kp, ws, lds, cx);
+    const double* ub = u + (size_t)b * 2 * N;
+    const double* xb = xi + (size_t)b * (1 + 2 * N);
+    const double v = cx.vl ? ub[2 * lane] : 0.0, w = cx.vl ? ub[2 * lane + 1] : 0.0;
+    const double c = xb[0];
+    const double ya = cx.vl ? xb[1 + lane] : 0.0, yb = cx.vl ? xb[1 + N + lane] : 0.0;
+    EvalOut o;
+    eval_point(kp, cx, v, w, c, ya, yb, true, o);
+    if (lane == 0) {
+        if (psi) psi[b] = o.psi;
+        if (f) f[b] = o.f;
+    }
+    if (cx.vl) {
+        if (grad) { grad[(size_t)b * 2 * N + 2 * lane] = o.gv; grad[(size_t)b * 2 * N + 2 * lane + 1] = o.gw; }
+        if (F1) { F1[(size_t)b * 2 * N + lane] = o.F1a; F1[(size_t)b * 2 * N + N + lane] = o.F1b; }
+    }
+    if (F2 && lane < kp.Ndynobs) {
+        const int e = (int)ws[H_ENTRY + lane];
+        F2[(size_t)b * kp.Ndynobs + lane] = __shfl(o.F2e, e);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// solver kernel: ALM/PM outer loop around PANOC, one problem per wavefront.
+// The iteration is organised as a small state machine around ONE call site of eval_point.
+// ------------------------------------------------------------------------------------------------
+enum { ST_INIT0 = 0, ST_INIT1, ST_LIP, ST_NOLS, ST_LS, ST_OUTER };
+
+__device__ __forceinline__ double dot2(double a0, double a1, double b0, double b1) {
+    return wave_sum_u(a0 * b0 + a1 * b1);
+}
+
+__global__ __launch_bounds__(WAVE) void solve_kernel(KParams kp, BatchPtrs io, int B) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    const long long t_start = wall_clock64();
+    const int lane = threadIdx.x, N = kp.N, mem = kp.mem;
+    const double* ws = io.ws + (size_t)b * kp.ws_stride;
+    Ctx cx;
+    load_problem(kp, ws, lds, cx);
+    double* LS = lds + kp.l_S;      // [mem][N][2]
+    double* LY = lds + kp.l_Y;      // [mem][N][2]
+    double* LRHO = lds + kp.l_rho;  // [mem]
+    double* LALPHA = lds + kp.l_alpha;
+    const bool vl = cx.vl;
+
+    // PANOC constants [OpEn]
+    const double GAMMA_L_COEFF = 0.95, DELTA_LIP = 1e-12, EPS_LIP = 1e-6, LIP_UPD_EPS = 1e-6;
+    const double MAX_LIP = 1e9, MIN_L = 1e-10, SMALL_EPS = 2.220446049250313e-16, DBLMIN = 2.2250738585072014e-308;
+    const int MAX_LIP_IT = 10, MAX_LS_IT = 10;
+
+    // decision vector and multipliers (vector lanes; zeros elsewhere)
+    double u0v = 0.0, u0w = 0.0, ya = 0.0, yb = 0.0;
+    if (vl) {
+        if (io.u0) { u0v = io.u0[(size_t)b * 2 * N + 2 * lane]; u0w = io.u0[(size_t)b * 2 * N + 2 * lane + 1]; }
+        if (io.y0) { ya = io.y0[(size_t)b * 2 * N + lane]; yb = io.y0[(size_t)b * 2 * N + N + lane]; }
+    }
+    double uv = u0v, uw = u0w;
+    double c = kp.init_penalty;
+    if (io.c0) { const double c0 = io.c0[b]; if (c0 > 0.0) c = c0; }
+    c = uniform(c);
+    ya = clampd(ya, -1e12, 1e12); yb = clampd(yb, -1e12, 1e12);  // y <- Proj_Y(y), Y = [-1e12, 1e12]^n1
+    double ypa = ya, ypb = yb;  // y_plus
+
+    // PANOC cache
+    double gv = 0, gw = 0, gpv = 0, gpw = 0, hv = 0, hw = 0 /*u_half*/, sv = 0, sw = 0 /*gradient step*/;
+    double rv_ = 0, rw_ = 0 /*gamma*fpr*/, dv = 0, dw = 0 /*direction*/, pv = 0, pw = 0 /*u_plus*/;
+    double osv = 0, osw = 0, ogv = 0, ogw = 0;  // L-BFGS old state / old g
+    double g0v = 0, g0w = 0;                    // gradient at u kept during the Lipschitz estimate
+    double gamma = 0, Lip = 0, sigma = 0, cost = 0, nfpr = 0, tau = 1, rhs = 0, nh = 1;
+    double akkt_tol = kp.init_tol;
+    int iter = 0, num_iter = 0, lip_it = 0, nls = 0;
+    bool cont_iters = true, cont_time = true;
+    int lb_active = 0, lb_head = 0;
+    bool lb_first = true;
+    double lb_gamma = 1.0;
+    // ALM cache
+    int alm_iteration = 0, num_outer = 1, inner_total = 0, status = 0;
+    double dy_norm = 0, dy_norm_plus = 0, f2_norm = 0, f2_norm_plus = 0, last_fpr = 0, f_final = 0;
+
+    int state = ST_INIT0;
+    double ev = uv, ew = uw;  // evaluation point
+    bool want_grad = true;
+    EvalOut o;
+
+    for (;;) {
+        eval_point(kp, cx, ev, ew, c, ya, yb, want_grad, o);
+        bool step_begin = false;
+
+        if (state == ST_INIT0) {
+            // cost + gradient at u; perturbation for the local Lipschitz estimate: h_i = max(delta, eps*u_i)
+            cost = o.psi; gv = o.gv; gw = o.gw; g0v = gv; g0w = gw;
+            const double h0 = vl ? ((EPS_LIP * uv > DELTA_LIP) ? EPS_LIP * uv : DELTA_LIP) : 0.0;
+            const double h1 = vl ? ((EPS_LIP * uw > DELTA_LIP) ? EPS_LIP * uw : DELTA_LIP) : 0.0;
+            nh = sqrt(dot2(h0, h1, h0, h1));
+            ev = uv + h0; ew = uw + h1; want_grad = true; state = ST_INIT1;
+            continue;
+        } else if (state == ST_INIT1) {
+            const double d0 = o.gv - g0v, d1 = o.gw - g0w;
+            Lip = sqrt(dot2(d0, d1, d0, d1)) / nh;
+            gamma = GAMMA_L_COEFF / fmax(Lip, MIN_L);
+            sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * gamma);
+            sv = uv - gamma * gv; sw = uw - gamma * gw;
+            hv = vl ? clampd(sv, kp.vmin, kp.vmax) : 0.0; hw = vl ? clampd(sw, -kp.wmax, kp.wmax) : 0.0;
+            step_begin = true;
+        } else if (state == ST_LIP) {
+            const double cost_half = o.psi;
+            const double ip = dot2(gv, gw, rv_, rw_);
+            const double rhs_lip = cost + LIP_UPD_EPS * fabs(cost) - ip + (GAMMA_L_COEFF / (2.0 * gamma)) * nfpr * nfpr;
+            if (cost_half > rhs_lip && lip_it < MAX_LIP_IT && Lip < MAX_LIP) {
+                lb_active = 0; lb_first = true;  // invalidate the L-BFGS buffer
+                Lip *= 2.0; gamma *= 0.5;
+                sv = uv - gamma * gv; sw = uw - gamma * gw;
+                hv = vl ? clampd(sv, kp.vmin, kp.vmax) : 0.0; hw = vl ? clampd(sw, -kp.wmax, kp.wmax) : 0.0;
+                rv_ = uv - hv; rw_ = uw - hw;
+                nfpr = sqrt(dot2(rv_, rw_, rv_, rw_));
+                ++lip_it;
+                ev = hv; ew = hw; want_grad = false;
+                continue;
+            }
+            sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * gamma);
+            // ---- L-BFGS buffer update with (state = u, g = gamma*fpr)   [crate lbfgs: C-BFGS acceptance]
+            if (lb_first) {
+                lb_first = false;
+                osv = uv; osw = uw; ogv = rv_; ogw = rw_;
+            } else {
+                const double s0 = uv - osv, s1 = uw - osw, y0_ = rv_ - ogv, y1_ = rw_ - ogw;
+                const double ys = dot2(s0, s1, y0_, y1_), ss = dot2(s0, s1, s0, s1);
+                if (!(ss <= DBLMIN || ys <= 1e-10) && (ys / ss > 1e-8 * nfpr)) {
+                    osv = uv; osw = uw; ogv = rv_; ogw = rw_;
+                    lb_head = (lb_head + mem - 1) % mem;
+                    if (vl) {
+                        LS[(lb_head * N + lane) * 2] = s0; LS[(lb_head * N + lane) * 2 + 1] = s1;
+                        LY[(lb_head * N + lane) * 2] = y0_; LY[(lb_head * N + lane) * 2 + 1] = y1_;
+                    }
+                    if (lane == 0) LRHO[lb_head] = 1.0 / ys;
+                    lb_gamma = ys / dot2(y0_, y1_, y0_, y1_);
+                    lb_active = (lb_active + 1 < mem) ? lb_active + 1 : mem;
+                    __syncthreads();
+                }
+            }
+            if (iter == 0) {
+                // first iteration: no line search, u <- u_half
+                uv = hv; uw = hw;
+                ev = uv; ew = uw; want_grad = true; state = ST_NOLS;
+                continue;
+            }
+            // ---- direction d = H * (gamma*fpr): two-loop recursion, newest pair first
+            double q0 = rv_, q1 = rw_;
+            for (int j = 0; j < lb_active; ++j) {
+                const int sl = (lb_head + j) % mem;
+                const double sj0 = vl ? LS[(sl * N + lane) * 2] : 0.0, sj1 = vl ? LS[(sl * N + lane) * 2 + 1] : 0.0;
+                const double al = LRHO[sl] * dot2(sj0, sj1, q0, q1);
+                if (lane == 0) LALPHA[j] = al;
+                if (vl) { q0 -= al * LY[(sl * N + lane) * 2]; q1 -= al * LY[(sl * N + lane) * 2 + 1]; }
+            }
+            __syncthreads();
+            if (lb_active > 0) { q0 *= lb_gamma; q1 *= lb_gamma; }
+            for (int j = lb_active - 1; j >= 0; --j) {
+                const int sl = (lb_head + j) % mem;
+                const double yj0 = vl ? LY[(sl * N + lane) * 2] : 0.0, yj1 = vl ? LY[(sl * N + lane) * 2 + 1] : 0.0;
+                const double be = LRHO[sl] * dot2(yj0, yj1, q0, q1);
+                const double co = LALPHA[j] - be;
+                if (vl) { q0 += co * LS[(sl * N + lane) * 2]; q1 += co * LS[(sl * N + lane) * 2 + 1]; }
+            }
+            dv = q0; dw = q1;
+            // ---- line search on the forward-backward envelope
+            {
+                const double gg = dot2(gv, gw, gv, gw);
+                const double e0 = sv - hv, e1 = sw - hw;
+                const double d2 = dot2(e0, e1, e0, e1);
+                const double fbe = cost - 0.5 * gamma * gg + 0.5 * d2 / gamma;
+                rhs = fbe - sigma * nfpr * nfpr;
+            }
+            tau = 1.0; nls = 0;
+            pv = uv - (1.0 - tau) * rv_ - tau * dv; pw = uw - (1.0 - tau) * rw_ - tau * dw;
+            ev = pv; ew = pw; want_grad = true; state = ST_LS;
+            continue;
+        } else if (state == ST_NOLS) {
+            cost = o.psi; gv = o.gv; gw = o.gw;
+            sv = uv - gamma * gv; sw = uw - gamma * gw;
+            hv = vl ? clampd(sv, kp.vmin, kp.vmax) : 0.0; hw = vl ? clampd(sw, -kp.wmax, kp.wmax) : 0.0;
+            ++iter;
+            step_begin = true;
+        } else if (state == ST_LS) {
+            cost = o.psi; gv = o.gv; gw = o.gw;
+            sv = pv - gamma * gv; sw = pw - gamma * gw;
+            hv = vl ? clampd(sv, kp.vmin, kp.vmax) : 0.0; hw = vl ? clampd(sw, -kp.wmax, kp.wmax) : 0.0;
+            const double gg = dot2(gv, gw, gv, gw);
+            const double e0 = sv - hv, e1 = sw - hw;
+            const double d2 = dot2(e0, e1, e0, e1);
+            const double lhs = cost - 0.5 * gamma * gg + 0.5 * d2 / gamma;
+            if (lhs > rhs && nls < MAX_LS_IT) {
+                tau *= 0.5; ++nls;
+                pv = uv - (1.0 - tau) * rv_ - tau * dv; pw = uw - (1.0 - tau) * rw_ - tau * dw;
+                ev = pv; ew = pw; want_grad = true;
+                continue;
+            }
+            uv = pv; uw = pw;  // after MAX_LS_IT halvings the last trial point is kept
+            ++iter;
+            step_begin = true;
+        } else {  // ST_OUTER: evaluated at the inner solution (c, y still those of the inner problem)
+            inner_total += num_iter;
+            last_fpr = nfpr;
+            f_final = o.f;
+            // y+ <- y + c (F1(u) - Proj_C(F1(u) + y/c))
+            double dy2l = 0.0;
+            if (vl) {
+                const double za = o.F1a + ya / c, zb = o.F1b + yb / c;
+                ypa = ya + c * (o.F1a - clampd(za, kp.amin, kp.amax));
+                ypb = yb + c * (o.F1b - clampd(zb, -kp.aamax, kp.aamax));
+                dy2l = (ypa - ya) * (ypa - ya) + (ypb - yb) * (ypb - yb);
+            }
+            dy_norm_plus = sqrt(wave_sum_u(dy2l));
+            f2_norm_plus = sqrt(o.nrm2F2);
+            const bool crit1 = alm_iteration > 0 && dy_norm_plus <= c * kp.delta_tol + SMALL_EPS;
+            const bool crit2 = f2_norm_plus <= kp.delta_tol + SMALL_EPS;
+            const bool crit3 = akkt_tol <= kp.tol + SMALL_EPS;
+            // converged: status = status of the last inner problem; the outer-iteration cap overrides it
+            if ((crit1 && crit2 && crit3) || num_outer == kp.max_outer) {
+                if (num_outer == kp.max_outer) status = 1;
+                break;
+            }
+            if (kp.max_ticks > 0 && wall_clock64() - t_start > kp.max_ticks) { status = 2; break; }
+            const bool stall = alm_iteration == 0 || (dy_norm_plus <= kp.suff_decrease * dy_norm + SMALL_EPS &&
+                                                      f2_norm_plus <= kp.suff_decrease * f2_norm + SMALL_EPS);
+            if (!stall) c *= kp.penalty_update;
+            akkt_tol = fmax(akkt_tol * kp.tol_update, kp.tol);
+            ++alm_iteration; ++num_outer;
+            dy_norm = dy_norm_plus; f2_norm = f2_norm_plus;
+            ya = fmin(fmax(ypa, -1e12), 1e12); yb = fmin(fmax(ypb, -1e12), 1e12);  // y <- Proj_Y(y+)
+            // reset the PANOC cache for the next inner problem
+            lb_active = 0; lb_first = true; tau = 1.0; Lip = 0; sigma = 0; gamma = 0; iter = 0;
+            gpv = 0; gpw = 0;
+            num_iter = 0; cont_iters = true; cont_time = true;
+            ev = uv; ew = uw; want_grad = true; state = ST_INIT0;
+            continue;
+        }
+
+        if (step_begin) {
+            bool inner_done = false;
+            if (state != ST_INIT1) {  // a full step has completed: the solver loop's bookkeeping
+                if (cont_iters && cont_time) {
+                    ++num_iter;
+                    cont_iters = num_iter < kp.max_inner;
+                    if (kp.max_ticks > 0) cont_time = (wall_clock64() - t_start) <= kp.max_ticks;
+                } else {
+                    inner_done = true;
+                }
+            }
+            if (!inner_done) {
+                if (iter >= 1) { gpv = gv; gpw = gw; }
+                rv_ = uv - hv; rw_ = uw - hw;
+                nfpr = sqrt(dot2(rv_, rw_, rv_, rw_));
+                bool ex = nfpr < kp.tol;
+                if (ex) {  // AKKT residual || gfpr/gamma + grad - grad_prev || < eps_nu
+                    const double a0 = rv_ / gamma + gv - gpv, a1 = rw_ / gamma + gw - gpw;
+                    ex = sqrt(dot2(a0, a1, a0, a1)) < akkt_tol;
+                }
+                if (ex) {
+                    inner_done = true;
+                } else {
+                    lip_it = 0;
+                    ev = hv; ew = hw; want_grad = false; state = ST_LIP;
+                    continue;
+                }
+            }
+            // inner problem finished: the feasible half step is the result
+            status = !cont_iters ? 1 : (!cont_time ? 2 : 0);
+            uv = hv; uw = hw;
+            ev = uv; ew = uw; want_grad = false; state = ST_OUTER;
+        }
+    }
+
+    // ---- write results (coalesced per problem)
+    if (vl) {
+        io.u[(size_t)b * 2 * N + 2 * lane] = uv;
+        io.u[(size_t)b * 2 * N + 2 * lane + 1] = uw;
+        if (io.y_out) { io.y_out[(size_t)b * 2 * N + lane] = ypa; io.y_out[(size_t)b * 2 * N + N + lane] = ypb; }
+    }
+    if (lane == 0) {
+        io.cost[b] = f_final;
+        io.status[b] = status;
+        if (io.inner_it) io.inner_it[b] = inner_total;
+        if (io.outer_it) io.outer_it[b] = num_outer;
+        if (io.fpr) io.fpr[b] = last_fpr;
+        if (io.f2norm) io.f2norm[b] = f2_norm_plus;
+        if (io.ms) io.ms[b] = (double)(wall_clock64() - t_start) * 1e-5;  // 100 MHz ticks -> ms
+    }
+}
+
+}  // namespace mpcgpu

@@ -1,0 +1,360 @@
+// mpcgpu.hip -- C-ABI (include/mpcgpu.h) over the gfx950 kernels in mpc_kernels.hpp.
+//
+// Host side only: argument validation, device buffers, workspace + LDS layout, launches, timing events.
+// No CPU fallback: every entry point needs a HIP device.
+#include "../../include/mpcgpu.h"
+#include "mpc_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+using namespace mpcgpu;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void* ptr = nullptr;
+    size_t cap = 0;
+};
+
+struct Handle {
+    mpcgpu_config cfg{};
+    KParams kp{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // prep start/end, solve start/end
+    bool timing_valid = false;
+    std::string err;
+    // grow-only device buffers
+    DevBuf ws, counts, p, u0, y0, c0, u, cost, status, inner, outer, fpr, f2, y, ms, xi, psi, f, grad, F1, F2;
+    int* h_counts = nullptr;  // pinned
+    int last_shape[4] = {0, 0, 0, 0};
+};
+
+int fail(Handle* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_OK(h, call)                                                                                 \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess) return fail(h, -10, "%s failed: %s", #call, hipGetErrorString(e_));       \
+    } while (0)
+
+int ensure(Handle* h, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return 0;
+    if (b.ptr) HIP_OK(h, hipFree(b.ptr));
+    b.ptr = nullptr; b.cap = 0;
+    HIP_OK(h, hipMalloc(&b.ptr, bytes));
+    b.cap = bytes;
+    return 0;
+}
+
+inline int even(int x) { return (x + 1) & ~1; }
+
+void fill_static_params(Handle* h) {
+    const mpcgpu_config& c = h->cfg;
+    KParams& k = h->kp;
+    const int N = c.N;
+    k.N = N;
+    k.LPS = WAVE / N;
+    if (k.LPS > 4) k.LPS = 4;
+    if (k.LPS < 1) k.LPS = 1;
+    k.Nother = c.Nother; k.Nstcobs = c.Nstcobs; k.Ndynobs = c.Ndynobs; k.mem = c.lbfgs_mem;
+    k.max_inner = c.max_inner; k.max_outer = c.max_outer;
+    k.ts = c.ts; k.inv_ts = 1.0 / c.ts;
+    k.vmin = c.lin_vel_min; k.vmax = c.lin_vel_max; k.wmax = c.ang_vel_max;
+    k.amin = c.lin_acc_min; k.amax = c.lin_acc_max; k.aamax = c.ang_acc_max;
+    k.W2 = c.vehicle_width * c.vehicle_width; k.social = c.social_margin; k.fleetw = c.fleet_weight;
+    k.tol = c.tol; k.delta_tol = c.delta_tol; k.init_tol = c.init_tol; k.init_penalty = c.init_penalty;
+    k.penalty_update = c.penalty_update; k.tol_update = c.tol_update; k.suff_decrease = c.suff_decrease;
+    k.max_ticks = c.max_duration_us > 0.0 ? (long long)(c.max_duration_us * 100.0) : 0;
+    // parameter layout: mpc_generator.py:179-188
+    k.r0 = 18;
+    k.c0 = k.r0 + 4 * N;
+    k.os0 = k.c0 + 3 * N * c.Nother;
+    k.od0 = k.os0 + c.Nstcobs * c.nstcobs;
+    k.qs0 = k.od0 + c.Ndynobs * c.ndynobs * N;
+    k.qd0 = k.qs0 + N;
+    k.np = k.qd0 + N;
+    // workspace layout (worst-case strides)
+    int o = HDR;
+    k.ws_vref = o; o += even(N);
+    k.ws_seg = o; o += N * SEGW;
+    k.ws_stc = o; o += c.Nstcobs * STCW;
+    k.ws_fm = o; o += even(c.Nother);
+    k.ws_fxy = o; o += c.Nother * N * 2;
+    k.ws_dm = o; o += even(c.Ndynobs);
+    k.ws_dyn = o; o += even(c.Ndynobs * N * DYNW);
+    k.ws_stride = (o + 15) & ~15;
+}
+
+// LDS carve for the batch maxima (doubles; every offset even => 16-byte aligned)
+void fill_lds_layout(KParams& k, int mKs, int mKf, int mKd) {
+    const int N = k.N;
+    k.mKs = mKs; k.mKf = mKf; k.mKd = mKd;
+    int o = 0;
+    k.l_seg = o; o += N * SEGW;
+    k.l_stc = o; o += mKs * STCW;
+    k.l_fm = o; o += even(mKf);
+    k.l_fxy = o; o += mKf * N * 2;
+    k.l_dm = o; o += even(mKd);
+    k.l_dyn = o; o += even(mKd * N * DYNW);
+    k.l_pos = o; o += N * 2;
+    k.l_H = o; o += even(mKd * N);
+    k.l_W = o; o += even(mKd);
+    k.l_part = o; o += even(k.LPS * N * PARTW);
+    k.l_S = o; o += k.mem * N * 2;
+    k.l_Y = o; o += k.mem * N * 2;
+    k.l_rho = o; o += even(k.mem);
+    k.l_alpha = o; o += even(k.mem);
+    k.l_total = o;
+}
+
+// compaction kernel + count read-back + LDS layout.  Leaves kp ready for a launch on `s`.
+int prepare(Handle* h, int B, const double* d_p, hipStream_t s, BatchPtrs& io) {
+    if (int r = ensure(h, h->ws, (size_t)B * h->kp.ws_stride * sizeof(double))) return r;
+    if (int r = ensure(h, h->counts, 4 * sizeof(int))) return r;
+    io.p = d_p;
+    io.ws = (double*)h->ws.ptr;
+    io.counts = (int*)h->counts.ptr;
+    HIP_OK(h, hipMemsetAsync(io.counts, 0, 4 * sizeof(int), s));
+    HIP_OK(h, hipEventRecord(h->ev[0], s));
+    hipLaunchKernelGGL(prep_kernel, dim3(B), dim3(WAVE), 0, s, h->kp, io, B);
+    HIP_OK(h, hipGetLastError());
+    HIP_OK(h, hipEventRecord(h->ev[1], s));
+    HIP_OK(h, hipMemcpyAsync(h->h_counts, io.counts, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_OK(h, hipStreamSynchronize(s));
+    const int mKs = h->h_counts[0], mKf = h->h_counts[1], mKd = h->h_counts[2];
+    fill_lds_layout(h->kp, mKs, mKf, mKd);
+    const int lds_bytes = h->kp.l_total * (int)sizeof(double);
+    h->last_shape[0] = mKs; h->last_shape[1] = mKf; h->last_shape[2] = mKd; h->last_shape[3] = lds_bytes;
+    if (lds_bytes > 160 * 1024) return fail(h, -5, "LDS carve of %d bytes exceeds 160 KiB", lds_bytes);
+    return 0;
+}
+
+int validate(const mpcgpu_config* c) {
+    if (!c) return fail(nullptr, -1, "config is NULL");
+    if (c->N < 2 || c->N > 64) return fail(nullptr, -1, "N_hor=%d unsupported (2..64)", c->N);
+    if (c->nu != 2 || c->ns != 3) return fail(nullptr, -1, "only the unicycle model (nu=2, ns=3) is supported, got nu=%d ns=%d", c->nu, c->ns);
+    if (c->nstcobs != 12) return fail(nullptr, -1, "nstcobs=%d unsupported (12 = 4 edges x (b,a0,a1))", c->nstcobs);
+    if (c->ndynobs != 6) return fail(nullptr, -1, "ndynobs=%d unsupported (6)", c->ndynobs);
+    if (c->Nother < 0 || c->Nother > 16) return fail(nullptr, -1, "Nother=%d unsupported (0..16)", c->Nother);
+    if (c->Nstcobs < 0 || c->Nstcobs > 16) return fail(nullptr, -1, "Nstcobs=%d unsupported (0..16)", c->Nstcobs);
+    if (c->Ndynobs < 1 || c->Ndynobs > 32) return fail(nullptr, -1, "Ndynobs=%d unsupported (1..32)", c->Ndynobs);
+    if (c->lbfgs_mem < 1 || c->lbfgs_mem > MAX_MEM) return fail(nullptr, -1, "lbfgs_mem=%d unsupported (1..%d)", c->lbfgs_mem, MAX_MEM);
+    if (!(c->ts > 0.0)) return fail(nullptr, -1, "ts must be positive");
+    if (c->max_inner < 1 || c->max_outer < 1) return fail(nullptr, -1, "max_inner / max_outer must be >= 1");
+    if (!(c->tol > 0.0) || !(c->init_tol > 0.0) || !(c->delta_tol > 0.0) || !(c->init_penalty > 0.0))
+        return fail(nullptr, -1, "tolerances and initial penalty must be positive");
+    if (c->device < 0) return fail(nullptr, -1, "device=%d: a HIP device ordinal is required (no CPU path)", c->device);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t mpcgpu_abi_version(void) { return MPCGPU_ABI_VERSION; }
+
+int32_t mpcgpu_create(const mpcgpu_config* cfg, void** handle) {
+    if (!handle) return fail(nullptr, -1, "handle out-pointer is NULL");
+    *handle = nullptr;
+    if (int r = validate(cfg)) return r;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, -2, "no HIP device available (%s); libmpcgpu has no CPU fallback",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (cfg->device >= ndev) return fail(nullptr, -2, "device %d requested but only %d present", cfg->device, ndev);
+    Handle* h = new (std::nothrow) Handle();
+    if (!h) return fail(nullptr, -3, "out of host memory");
+    h->cfg = *cfg;
+    h->device = cfg->device;
+    fill_static_params(h);
+#define CREATE_OK(call)                                                                                 \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess) {                                                                         \
+            fail(nullptr, -10, "%s failed: %s", #call, hipGetErrorString(e_));                          \
+            delete h;                                                                                   \
+            return -10;                                                                                 \
+        }                                                                                               \
+    } while (0)
+    CREATE_OK(hipSetDevice(h->device));
+    CREATE_OK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    for (auto& ev : h->ev) CREATE_OK(hipEventCreate(&ev));
+    CREATE_OK(hipHostMalloc((void**)&h->h_counts, 4 * sizeof(int), hipHostMallocDefault));
+#undef CREATE_OK
+    *handle = h;
+    return 0;
+}
+
+void mpcgpu_destroy(void* handle) {
+    Handle* h = (Handle*)handle;
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    DevBuf* bufs[] = {&h->ws, &h->counts, &h->p, &h->u0, &h->y0, &h->c0, &h->u, &h->cost, &h->status, &h->inner,
+                      &h->outer, &h->fpr, &h->f2, &h->y, &h->ms, &h->xi, &h->psi, &h->f, &h->grad, &h->F1, &h->F2};
+    for (DevBuf* b : bufs)
+        if (b->ptr) (void)hipFree(b->ptr);
+    if (h->h_counts) (void)hipHostFree(h->h_counts);
+    for (auto& ev : h->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+const char* mpcgpu_last_error(void* handle) {
+    Handle* h = (Handle*)handle;
+    return h ? h->err.c_str() : g_create_error.c_str();
+}
+
+int32_t mpcgpu_num_params(void* handle) {
+    Handle* h = (Handle*)handle;
+    return h ? h->kp.np : -1;
+}
+
+int32_t mpcgpu_solve_batch_dev(void* handle, int32_t B, const double* p, const double* u0, const double* y0,
+                               const double* c0, double* u, double* cost, int32_t* status, int32_t* inner_it,
+                               int32_t* outer_it, double* fpr, double* f2norm, double* y_out, double* ms,
+                               void* stream) {
+    Handle* h = (Handle*)handle;
+    if (!h) return -1;
+    if (B < 0) return fail(h, -1, "B=%d is negative", B);
+    if (B == 0) return 0;
+    if (!p || !u || !cost || !status) return fail(h, -1, "p, u, cost and status must not be NULL");
+    HIP_OK(h, hipSetDevice(h->device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    BatchPtrs io{};
+    if (int r = prepare(h, B, p, s, io)) return r;
+    io.u0 = u0; io.y0 = y0; io.c0 = c0; io.u = u; io.cost = cost; io.status = status; io.inner_it = inner_it;
+    io.outer_it = outer_it; io.fpr = fpr; io.f2norm = f2norm; io.y_out = y_out; io.ms = ms;
+    HIP_OK(h, hipEventRecord(h->ev[2], s));
+    hipLaunchKernelGGL(solve_kernel, dim3(B), dim3(WAVE), h->kp.l_total * sizeof(double), s, h->kp, io, B);
+    HIP_OK(h, hipGetLastError());
+    HIP_OK(h, hipEventRecord(h->ev[3], s));
+    h->timing_valid = true;
+    return 0;
+}
+
+int32_t mpcgpu_solve_batch(void* handle, int32_t B, const double* p, const double* u0, const double* y0,
+                           const double* c0, double* u, double* cost, int32_t* status, int32_t* inner_it,
+                           int32_t* outer_it, double* fpr, double* f2norm, double* y_out, double* ms) {
+    Handle* h = (Handle*)handle;
+    if (!h) return -1;
+    if (B < 0) return fail(h, -1, "B=%d is negative", B);
+    if (B == 0) return 0;
+    if (!p || !u || !cost || !status) return fail(h, -1, "p, u, cost and status must not be NULL");
+    HIP_OK(h, hipSetDevice(h->device));
+    const size_t n = 2 * (size_t)h->kp.N, np = (size_t)h->kp.np, Bz = (size_t)B;
+    hipStream_t s = h->stream;
+    if (int r = ensure(h, h->p, Bz * np * 8)) return r;
+    if (int r = ensure(h, h->u, Bz * n * 8)) return r;
+    if (int r = ensure(h, h->cost, Bz * 8)) return r;
+    if (int r = ensure(h, h->status, Bz * 4)) return r;
+    if (int r = ensure(h, h->inner, Bz * 4)) return r;
+    if (int r = ensure(h, h->outer, Bz * 4)) return r;
+    if (int r = ensure(h, h->fpr, Bz * 8)) return r;
+    if (int r = ensure(h, h->f2, Bz * 8)) return r;
+    if (int r = ensure(h, h->y, Bz * n * 8)) return r;
+    if (int r = ensure(h, h->ms, Bz * 8)) return r;
+    HIP_OK(h, hipMemcpyAsync(h->p.ptr, p, Bz * np * 8, hipMemcpyHostToDevice, s));
+    if (u0) { if (int r = ensure(h, h->u0, Bz * n * 8)) return r; HIP_OK(h, hipMemcpyAsync(h->u0.ptr, u0, Bz * n * 8, hipMemcpyHostToDevice, s)); }
+    if (y0) { if (int r = ensure(h, h->y0, Bz * n * 8)) return r; HIP_OK(h, hipMemcpyAsync(h->y0.ptr, y0, Bz * n * 8, hipMemcpyHostToDevice, s)); }
+    if (c0) { if (int r = ensure(h, h->c0, Bz * 8)) return r; HIP_OK(h, hipMemcpyAsync(h->c0.ptr, c0, Bz * 8, hipMemcpyHostToDevice, s)); }
+    int r = mpcgpu_solve_batch_dev(h, B, (const double*)h->p.ptr, u0 ? (const double*)h->u0.ptr : nullptr,
+                                   y0 ? (const double*)h->y0.ptr : nullptr, c0 ? (const double*)h->c0.ptr : nullptr,
+                                   (double*)h->u.ptr, (double*)h->cost.ptr, (int32_t*)h->status.ptr,
+                                   (int32_t*)h->inner.ptr, (int32_t*)h->outer.ptr, (double*)h->fpr.ptr,
+                                   (double*)h->f2.ptr, (double*)h->y.ptr, (double*)h->ms.ptr, s);
+    if (r) return r;
+    HIP_OK(h, hipMemcpyAsync(u, h->u.ptr, Bz * n * 8, hipMemcpyDeviceToHost, s));
+    HIP_OK(h, hipMemcpyAsync(cost, h->cost.ptr, Bz * 8, hipMemcpyDeviceToHost, s));
+    HIP_OK(h, hipMemcpyAsync(status, h->status.ptr, Bz * 4, hipMemcpyDeviceToHost, s));
+    if (inner_it) HIP_OK(h, hipMemcpyAsync(inner_it, h->inner.ptr, Bz * 4, hipMemcpyDeviceToHost, s));
+    if (outer_it) HIP_OK(h, hipMemcpyAsync(outer_it, h->outer.ptr, Bz * 4, hipMemcpyDeviceToHost, s));
+    if (fpr) HIP_OK(h, hipMemcpyAsync(fpr, h->fpr.ptr, Bz * 8, hipMemcpyDeviceToHost, s));
+    if (f2norm) HIP_OK(h, hipMemcpyAsync(f2norm, h->f2.ptr, Bz * 8, hipMemcpyDeviceToHost, s));
+    if (y_out) HIP_OK(h, hipMemcpyAsync(y_out, h->y.ptr, Bz * n * 8, hipMemcpyDeviceToHost, s));
+    if (ms) HIP_OK(h, hipMemcpyAsync(ms, h->ms.ptr, Bz * 8, hipMemcpyDeviceToHost, s));
+    HIP_OK(h, hipStreamSynchronize(s));
+    return 0;
+}
+
+int32_t mpcgpu_cost_grad_batch(void* handle, int32_t B, const double* u, const double* xi, const double* p,
+                               double* psi, double* f, double* grad, double* F1, double* F2) {
+    Handle* h = (Handle*)handle;
+    if (!h) return -1;
+    if (B < 0) return fail(h, -1, "B=%d is negative", B);
+    if (B == 0) return 0;
+    if (!u || !xi || !p) return fail(h, -1, "u, xi and p must not be NULL");
+    HIP_OK(h, hipSetDevice(h->device));
+    const size_t n = 2 * (size_t)h->kp.N, np = (size_t)h->kp.np, Bz = (size_t)B, nd = (size_t)h->kp.Ndynobs;
+    hipStream_t s = h->stream;
+    if (int r = ensure(h, h->p, Bz * np * 8)) return r;
+    if (int r = ensure(h, h->u, Bz * n * 8)) return r;
+    if (int r = ensure(h, h->xi, Bz * (n + 1) * 8)) return r;
+    if (int r = ensure(h, h->psi, Bz * 8)) return r;
+    if (int r = ensure(h, h->f, Bz * 8)) return r;
+    if (int r = ensure(h, h->grad, Bz * n * 8)) return r;
+    if (int r = ensure(h, h->F1, Bz * n * 8)) return r;
+    if (int r = ensure(h, h->F2, Bz * nd * 8)) return r;
+    HIP_OK(h, hipMemcpyAsync(h->p.ptr, p, Bz * np * 8, hipMemcpyHostToDevice, s));
+    HIP_OK(h, hipMemcpyAsync(h->u.ptr, u, Bz * n * 8, hipMemcpyHostToDevice, s));
+    HIP_OK(h, hipMemcpyAsync(h->xi.ptr, xi, Bz * (n + 1) * 8, hipMemcpyHostToDevice, s));
+    BatchPtrs io{};
+    if (int r = prepare(h, B, (const double*)h->p.ptr, s, io)) return r;
+    hipLaunchKernelGGL(cost_grad_kernel, dim3(B), dim3(WAVE), h->kp.l_total * sizeof(double), s, h->kp, io,
+                       (const double*)h->u.ptr, (const double*)h->xi.ptr, (double*)h->psi.ptr, (double*)h->f.ptr,
+                       (double*)h->grad.ptr, (double*)h->F1.ptr, (double*)h->F2.ptr, B);
+    HIP_OK(h, hipGetLastError());
+    if (psi) HIP_OK(h, hipMemcpyAsync(psi, h->psi.ptr, Bz * 8, hipMemcpyDeviceToHost, s));
+    if (f) HIP_OK(h, hipMemcpyAsync(f, h->f.ptr, Bz * 8, hipMemcpyDeviceToHost, s));
+    if (grad) HIP_OK(h, hipMemcpyAsync(grad, h->grad.ptr, Bz * n * 8, hipMemcpyDeviceToHost, s));
+    if (F1) HIP_OK(h, hipMemcpyAsync(F1, h->F1.ptr, Bz * n * 8, hipMemcpyDeviceToHost, s));
+    if (F2) HIP_OK(h, hipMemcpyAsync(F2, h->F2.ptr, Bz * nd * 8, hipMemcpyDeviceToHost, s));
+    HIP_OK(h, hipStreamSynchronize(s));
+    return 0;
+}
+
+int32_t mpcgpu_last_timing(void* handle, double* prep_ms, double* solve_ms) {
+    Handle* h = (Handle*)handle;
+    if (!h) return -1;
+    if (!h->timing_valid) return fail(h, -4, "no solve call has been timed yet");
+    HIP_OK(h, hipSetDevice(h->device));
+    HIP_OK(h, hipEventSynchronize(h->ev[3]));
+    float a = 0.f, b = 0.f;
+    HIP_OK(h, hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
+    HIP_OK(h, hipEventElapsedTime(&b, h->ev[2], h->ev[3]));
+    if (prep_ms) *prep_ms = a;
+    if (solve_ms) *solve_ms = b;
+    return 0;
+}
+
+int32_t mpcgpu_last_shape(void* handle, int32_t* max_static, int32_t* max_fleet, int32_t* max_dyn,
+                          int32_t* lds_bytes) {
+    Handle* h = (Handle*)handle;
+    if (!h) return -1;
+    if (max_static) *max_static = h->last_shape[0];
+    if (max_fleet) *max_fleet = h->last_shape[1];
+    if (max_dyn) *max_dyn = h->last_shape[2];
+    if (lds_bytes) *lds_bytes = h->last_shape[3];
+    return 0;
+}
+
+}  // extern "C"

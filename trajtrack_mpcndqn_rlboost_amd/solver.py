@@ -1,0 +1,240 @@
+"""ctypes binding of ``libmpcgpu.so`` (C-ABI: ``include/mpcgpu.h``).
+
+``BatchSolver.solve`` is the batched counterpart of the reference's ``solver.run(p, initial_guess)``
+(``src/mpc_traj_tracker/trajectory_generator.py:318``).  The library is loaded from this package directory
+(built in-tree by ``csrc/Makefile``); if it is missing, or no HIP device is usable, construction raises --
+there is deliberately no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from .config import MpcConfig
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_PKG, "libmpcgpu.so")
+
+STATUS_NAMES = ("Converged", "NotConvergedIterations", "NotConvergedOutOfTime")
+
+
+class MpcGpuError(RuntimeError):
+    """Any failure reported through the C-ABI (the reference's callers catch RuntimeError)."""
+
+
+class _CConfig(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32), ("nu", C.c_int32), ("ns", C.c_int32), ("Nother", C.c_int32), ("Nstcobs", C.c_int32),
+        ("nstcobs", C.c_int32), ("Ndynobs", C.c_int32), ("ndynobs", C.c_int32),
+        ("ts", C.c_double),
+        ("lin_vel_min", C.c_double), ("lin_vel_max", C.c_double), ("ang_vel_max", C.c_double),
+        ("lin_acc_min", C.c_double), ("lin_acc_max", C.c_double), ("ang_acc_max", C.c_double),
+        ("vehicle_width", C.c_double), ("social_margin", C.c_double), ("fleet_weight", C.c_double),
+        ("tol", C.c_double), ("delta_tol", C.c_double), ("init_tol", C.c_double), ("init_penalty", C.c_double),
+        ("penalty_update", C.c_double), ("tol_update", C.c_double), ("suff_decrease", C.c_double),
+        ("max_inner", C.c_int32), ("max_outer", C.c_int32), ("lbfgs_mem", C.c_int32), ("device", C.c_int32),
+        ("max_duration_us", C.c_double),
+    ]
+
+
+EXPORTS = ("mpcgpu_abi_version", "mpcgpu_create", "mpcgpu_destroy", "mpcgpu_last_error", "mpcgpu_num_params",
+           "mpcgpu_solve_batch", "mpcgpu_solve_batch_dev", "mpcgpu_cost_grad_batch", "mpcgpu_last_timing",
+           "mpcgpu_last_shape")
+
+
+def library_path() -> str:
+    return _LIB
+
+
+def build_library(force: bool = False) -> str:
+    """Compile libmpcgpu.so for gfx950 with hipcc (recipe: csrc/Makefile)."""
+    cmd = ["make", "-C", os.path.join(_PKG, "csrc"), "-s"]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd)
+    return _LIB
+
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB):
+        raise MpcGpuError(f"{_LIB} not found: build it with `make -C {os.path.join(_PKG, 'csrc')}` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = C.CDLL(_LIB)
+    dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_void_p
+    L.mpcgpu_abi_version.restype = C.c_int32
+    L.mpcgpu_create.argtypes = [C.POINTER(_CConfig), C.POINTER(vp)]
+    L.mpcgpu_create.restype = C.c_int32
+    L.mpcgpu_destroy.argtypes = [vp]
+    L.mpcgpu_destroy.restype = None
+    L.mpcgpu_last_error.argtypes = [vp]
+    L.mpcgpu_last_error.restype = C.c_char_p
+    L.mpcgpu_num_params.argtypes = [vp]
+    L.mpcgpu_num_params.restype = C.c_int32
+    L.mpcgpu_solve_batch.argtypes = [vp, C.c_int32, dp, dp, dp, dp, dp, dp, ip, ip, ip, dp, dp, dp, dp]
+    L.mpcgpu_solve_batch.restype = C.c_int32
+    L.mpcgpu_solve_batch_dev.argtypes = [vp, C.c_int32] + [vp] * 13 + [vp]
+    L.mpcgpu_solve_batch_dev.restype = C.c_int32
+    L.mpcgpu_cost_grad_batch.argtypes = [vp, C.c_int32, dp, dp, dp, dp, dp, dp, dp, dp]
+    L.mpcgpu_cost_grad_batch.restype = C.c_int32
+    L.mpcgpu_last_timing.argtypes = [vp, dp, dp]
+    L.mpcgpu_last_timing.restype = C.c_int32
+    L.mpcgpu_last_shape.argtypes = [vp, ip, ip, ip, ip]
+    L.mpcgpu_last_shape.restype = C.c_int32
+    _lib = L
+    return L
+
+
+@dataclass
+class BatchResult:
+    """Per-problem fields of the OpEn solution object (``solution, cost, exit_status, solve_time_ms`` are the
+    ones the reference reads at trajectory_generator.py:320-323)."""
+    solution: np.ndarray        # [B, 2N]
+    cost: np.ndarray            # [B]
+    status: np.ndarray          # [B] int32 codes, see STATUS_NAMES
+    num_inner_iterations: np.ndarray
+    num_outer_iterations: np.ndarray
+    last_problem_norm_fpr: np.ndarray
+    f2_norm: np.ndarray
+    lagrange_multipliers: np.ndarray  # [B, 2N]
+    solve_time_ms: np.ndarray
+
+    @property
+    def exit_status(self):
+        return [STATUS_NAMES[s] for s in self.status]
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class BatchSolver:
+    """One handle of libmpcgpu.so = one generated solver of the reference, for batches of problems."""
+
+    def __init__(self, config: Optional[MpcConfig] = None, device: int = 0):
+        self.config = config if config is not None else MpcConfig()
+        self._L = load_library()
+        self._h = C.c_void_p()
+        d = self.config.solver_dict(device)
+        self._cfg = _CConfig(**d)
+        rc = self._L.mpcgpu_create(C.byref(self._cfg), C.byref(self._h))
+        if rc != 0:
+            msg = self._L.mpcgpu_last_error(None).decode()
+            self._h = C.c_void_p()
+            raise MpcGpuError(f"mpcgpu_create failed ({rc}): {msg}")
+        self.device = device
+        self.N = int(self.config.N_hor)
+        self.n = 2 * self.N
+        self.np = int(self._L.mpcgpu_num_params(self._h))
+        assert self.np == self.config.num_params
+
+    # -- lifetime ---------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._L.mpcgpu_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise MpcGpuError(f"{what} failed ({rc}): {self._L.mpcgpu_last_error(self._h).decode()}")
+
+    # -- host-pointer API -------------------------------------------------------------------------
+    def solve(self, p, initial_guess=None, initial_lagrange_multipliers=None, initial_penalty=None) -> BatchResult:
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        if p.ndim == 1:
+            p = p[None]
+        if p.ndim != 2 or p.shape[1] != self.np:
+            raise MpcGpuError(f"3003 -> wrong number of parameters: got {p.shape}, expected [B, {self.np}]")
+        B = p.shape[0]
+
+        def opt(a, shape, what, code):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            if a.shape != shape:
+                raise MpcGpuError(f"{code} -> {what} has incompatible dimensions: got {a.shape}, expected {shape}")
+            return a
+        u0 = opt(initial_guess, (B, self.n), "initial guess", 1600)
+        y0 = opt(initial_lagrange_multipliers, (B, self.n), "Lagrange multipliers", 1700)
+        c0 = opt(initial_penalty, (B,), "initial penalty", 1800)
+        u = np.empty((B, self.n)); cost = np.empty(B); status = np.empty(B, np.int32)
+        inner = np.empty(B, np.int32); outer = np.empty(B, np.int32)
+        fpr = np.empty(B); f2 = np.empty(B); y = np.empty((B, self.n)); ms = np.empty(B)
+        rc = self._L.mpcgpu_solve_batch(self._h, B, _dp(p), _dp(u0), _dp(y0), _dp(c0), _dp(u), _dp(cost),
+                                        _ip(status), _ip(inner), _ip(outer), _dp(fpr), _dp(f2), _dp(y), _dp(ms))
+        self._check(rc, "mpcgpu_solve_batch")
+        return BatchResult(u, cost, status, inner, outer, fpr, f2, y, ms)
+
+    def cost_grad(self, u, p, c=None, y=None):
+        """Test hook: psi, f, grad psi, F1, F2 of every problem (GPU evaluation of the generated functions)."""
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        if p.ndim == 1:
+            p, u = p[None], u[None]
+        B = p.shape[0]
+        if p.shape != (B, self.np) or u.shape != (B, self.n):
+            raise MpcGpuError(f"bad shapes p{p.shape} u{u.shape}")
+        xi = np.zeros((B, 1 + self.n))
+        if c is not None:
+            xi[:, 0] = c
+        if y is not None:
+            xi[:, 1:] = y
+        psi = np.empty(B); f = np.empty(B); grad = np.empty((B, self.n)); F1 = np.empty((B, self.n))
+        F2 = np.empty((B, int(self.config.Ndynobs)))
+        rc = self._L.mpcgpu_cost_grad_batch(self._h, B, _dp(u), _dp(xi), _dp(p), _dp(psi), _dp(f), _dp(grad),
+                                            _dp(F1), _dp(F2))
+        self._check(rc, "mpcgpu_cost_grad_batch")
+        return dict(psi=psi, f=f, grad=grad, F1=F1, F2=F2)
+
+    # -- device-pointer API (torch tensors on this solver's device) ---------------------------------
+    def solve_device(self, p, out: dict, initial_guess=None, initial_lagrange_multipliers=None,
+                     initial_penalty=None, stream: int = 0):
+        """Enqueue a batch whose inputs/outputs are float64/int32 CUDA tensors (HBM-resident).
+
+        ``out`` must hold preallocated tensors ``u [B,2N] f64, cost [B] f64, status [B] i32`` and may hold
+        ``inner_it, outer_it (i32), fpr, f2norm, ms (f64 [B]), y (f64 [B,2N])``.  ``stream`` is a raw
+        hipStream_t (e.g. ``torch.cuda.current_stream().cuda_stream``); 0 = the handle's own stream.
+        Returns after the solve kernel has been enqueued.
+        """
+        B = int(p.shape[0])
+        if tuple(p.shape) != (B, self.np) or not p.is_contiguous():
+            raise MpcGpuError(f"p must be a contiguous [B, {self.np}] tensor, got {tuple(p.shape)}")
+
+        def ptr(t):
+            return None if t is None else C.c_void_p(t.data_ptr())
+        rc = self._L.mpcgpu_solve_batch_dev(
+            self._h, B, ptr(p), ptr(initial_guess), ptr(initial_lagrange_multipliers), ptr(initial_penalty),
+            ptr(out["u"]), ptr(out["cost"]), ptr(out["status"]), ptr(out.get("inner_it")),
+            ptr(out.get("outer_it")), ptr(out.get("fpr")), ptr(out.get("f2norm")), ptr(out.get("y")),
+            ptr(out.get("ms")), C.c_void_p(stream) if stream else None)
+        self._check(rc, "mpcgpu_solve_batch_dev")
+
+    def last_timing(self):
+        a, b = C.c_double(), C.c_double()
+        self._check(self._L.mpcgpu_last_timing(self._h, C.byref(a), C.byref(b)), "mpcgpu_last_timing")
+        return dict(prep_ms=a.value, solve_ms=b.value)
+
+    def last_shape(self):
+        v = [C.c_int32() for _ in range(4)]
+        self._check(self._L.mpcgpu_last_shape(self._h, *[C.byref(x) for x in v]), "mpcgpu_last_shape")
+        return dict(max_static=v[0].value, max_fleet=v[1].value, max_dyn=v[2].value, lds_bytes=v[3].value)
