@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: batched receding-horizon NMPC solves on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch: B independent cold-start solves (u0 = 0, what every
+reference call site does: src/interface_mpc.py:82 passes initial_guess=None) of the metric configuration
+named in BASELINE.json -- mpc_default.yaml, N_hor = 20, 8 dynamic obstacles, B = 8192 problems per GPU --
+with the parameter vectors already resident in HBM.  For N > 1 the driver launches one rank per GPU
+(torch.distributed.run); the batch shards across ranks with no data-path collective (weak scaling: every
+rank owns its own 8192 robots); RCCL is used only for the barrier and the max-over-ranks time.
+
+Rank 0 prints ONE JSON line (contract in the task description) with two extra objects:
+  roofline     -- dominant kernel (solve_kernel) against the HBM roofline, timed with HIP events on the
+                  launch stream; `valu_f64` gives the figure that actually bounds this kernel.
+  cpu_baseline -- the oracle (plain-C restatement, "port") on the host cores, on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VECTOR_PEAK_TF = 78.6   # MI355X vector FP64 (half the 157.3 TF FP32 vector rate)
+ALGO_BYTES_N20 = 21944       # 8*np + 8*2N + 8*2N + 40 per solve at N = 20
+
+
+def shard(total: int, rank: int, world: int):
+    """Contiguous chunk [lo, hi) of `total` items owned by `rank` (sizes differ by at most one)."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8192, help="problems per GPU per step")
+    ap.add_argument("--n-dyn", type=int, default=8)
+    ap.add_argument("--horizon", type=int, default=20)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 disables)")
+    args = ap.parse_args()
+
+    import torch
+    from trajtrack_mpcndqn_rlboost_amd import BatchSolver, MpcConfig, scenes
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    cfg = MpcConfig(N_hor=args.horizon)
+    N, B = cfg.N_hor, args.batch
+    solver = BatchSolver(cfg, device=local_rank)
+    # every rank owns its own B robots of the global scene set (weak scaling): global problem g = rank*B + i
+    sc = scenes.make_batch(cfg, B, n_dyn=args.n_dyn, seed=1234 + 7919 * rank)
+    p = torch.from_numpy(sc["p"]).to(dev)
+    out = dict(u=torch.empty(B, 2 * N, dtype=torch.float64, device=dev),
+               cost=torch.empty(B, dtype=torch.float64, device=dev),
+               status=torch.empty(B, dtype=torch.int32, device=dev),
+               inner_it=torch.empty(B, dtype=torch.int32, device=dev),
+               outer_it=torch.empty(B, dtype=torch.int32, device=dev),
+               f2norm=torch.empty(B, dtype=torch.float64, device=dev))
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        solver.solve_device(p, out, stream=stream)
+    barrier()
+    kernel_ms, prep_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        solver.solve_device(p, out, stream=stream)
+        t = solver.last_timing()          # HIP events recorded on `stream` around the two kernels
+        kernel_ms.append(t["solve_ms"]); prep_ms.append(t["prep_ms"])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        status = out["status"].cpu().numpy()
+        inner = out["inner_it"].cpu().numpy()
+        k_ms = float(np.mean(kernel_ms))
+        algo_bytes = (8 * cfg.num_params + 8 * 2 * N + 8 * 2 * N + 40) * B
+        achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+        line = {
+            "metric": "MPC solves/sec (batch, N=20 horizon, 8 dyn obs)",
+            "value": world * B * args.steps / elapsed,
+            "unit": "solves/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"mpc_default.yaml N_hor={N}, {args.n_dyn} dynamic obstacles (r=1.6 m discs), "
+                                   "5 static boxes, cold start u0=0, "
+                                   f"batch={B} robots per GPU (BASELINE.json metric configuration)",
+                       "batch_per_gpu": B, "N_hor": N, "n_dyn": args.n_dyn, "parallelism": f"shard{world}",
+                       "mean_inner_iterations": float(inner.mean()),
+                       "status_histogram": np.bincount(status, minlength=3).tolist()},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "solve_kernel", "kernel_ms": k_ms, "prep_kernel_ms": float(np.mean(prep_ms)),
+                         "algorithmic_bytes_per_solve": algo_bytes // B,
+                         "note": "LDS-resident solver: HBM is read once per solve; the kernel is VALU-f64/latency bound"},
+        }
+        if args.cpu_seconds > 0 and world == 1:
+            line["cpu_baseline"] = cpu_baseline(cfg, sc["p"], args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cfg, p_all, budget_s):
+    """The oracle (C restatement of the same algorithm, kind = "port") on all host cores, on the first S
+    problems of the very same workload; S is calibrated so the run takes about `budget_s` seconds."""
+    import oracle
+    ocfg = oracle.OracleConfig.from_dict(cfg.solver_dict())
+    cores = os.cpu_count() or 1
+    probe = min(len(p_all), max(cores, 32))
+    t = time.perf_counter()
+    oracle.solve_batch(ocfg, p_all[:probe], nthreads=cores)
+    dt = time.perf_counter() - t
+    S = int(min(len(p_all), max(probe, probe * 0.8 * budget_s / max(dt, 1e-3))))
+    S = max(cores, (S // cores) * cores)
+    S = min(S, len(p_all))
+    t = time.perf_counter()
+    _, _, res, used = oracle.solve_batch(ocfg, p_all[:S], nthreads=cores)
+    dt = time.perf_counter() - t
+    return {"value": S / dt, "unit": "solves/s", "cores": used, "kind": "port",
+            "sample": f"first {S} problems of the same batch, OpenMP over problems, {dt:.1f} s wall, "
+                      f"mean inner iterations {float(res['inner_iters'].mean()):.0f}"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,113 @@
+"""CPU: the oracle (oracle/mpc_oracle.c) against the golden vectors generated from the reference's own source
+(tests/golden/make_fixtures.py executes /root/reference/src/mpc_traj_tracker/mpc/mpc_generator.py)."""
+import numpy as np
+import pytest
+
+import oracle
+from conftest import load_golden, make_cfg, oracle_cfg
+
+RTOL = 1e-11  # float64 restatement vs torch-autograd execution of the reference code
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.max(np.abs(a - b)) / max(1.0, float(np.max(np.abs(b)))))
+
+
+@pytest.mark.parametrize("N", [20, 40])
+def test_cost_grad_matches_reference_fixtures(N):
+    cfg = oracle_cfg(make_cfg(N))
+    fx = load_golden(f"costgrad_N{N}.npz")
+    assert fx["p"].shape[1] == oracle.num_params(cfg)
+    n_active_f2 = 0
+    for i in range(len(fx["f"])):
+        r = oracle.cost_grad(cfg, fx["u"][i], fx["p"][i], float(fx["c"][i]), fx["y"][i])
+        r0 = oracle.cost_grad(cfg, fx["u"][i], fx["p"][i], 0.0, None)
+        assert _rel(r["f"], fx["f"][i]) < RTOL
+        assert _rel(r["psi"], fx["psi"][i]) < RTOL
+        assert _rel(r["grad"], fx["grad_psi"][i]) < RTOL
+        assert _rel(r0["grad"], fx["grad_f"][i]) < RTOL
+        assert _rel(r0["psi"], fx["f"][i]) < RTOL          # psi with c = 0 is f
+        assert _rel(r["F1"], fx["F1"][i]) < RTOL
+        assert _rel(r["F2"], fx["F2"][i]) < RTOL
+        n_active_f2 += fx["F2"][i].max() > 0
+    assert n_active_f2 >= len(fx["f"]) // 2  # the fixtures do exercise the penalty constraints
+
+
+def test_known_answers_from_survey():
+    """Hand-checked anchor: f(u=0) = 100*0.24^2*sum k^2 + 10*1.2^2*20 = 16819.2."""
+    fx = load_golden("costgrad_N20.npz")
+    assert abs(fx["f"][0] - 16819.2) < 1e-6
+    assert np.all(fx["F2"][0] == 0.0)
+    assert abs(fx["f"][1] - 13317.429691895022) < 1e-9
+    cfg = oracle_cfg(make_cfg(20))
+    r = oracle.cost_grad(cfg, fx["u"][0], fx["p"][0])
+    assert abs(r["f"] - 16819.2) < 1e-6
+
+
+def test_problem_meta_matches_config(meta):
+    for N in (20, 40):
+        m = meta[f"N{N}"]
+        cfg = make_cfg(N)
+        assert m["np"] == cfg.num_params == oracle.num_params(oracle_cfg(cfg))
+        assert m["n1"] == 2 * N and m["n2"] == cfg.Ndynobs
+        assert m["U_lo"] == [cfg.lin_vel_min, -cfg.ang_vel_max] * N
+        assert m["U_hi"] == [cfg.lin_vel_max, cfg.ang_vel_max] * N
+        assert m["C_lo"] == [cfg.lin_acc_min] * N + [-cfg.ang_acc_max] * N
+        assert m["C_hi"] == [cfg.lin_acc_max] * N + [cfg.ang_acc_max] * N
+        # solver settings the reference passes to the builder (mpc_generator.py:285-287)
+        assert m["solver_cfg"]["with_initial_penalty"] == cfg.solver_initial_penalty == 10
+        assert m["solver_cfg"]["with_max_duration_micros"] == cfg.solver_max_duration_micros == 5_000_000
+        for k, v in m["yaml"].items():
+            assert getattr(cfg, k) == v or k == "N_hor"
+
+
+def test_unicycle_rk4_matches_reference_numpy():
+    fx = load_golden("unicycle_rk4.npz")
+    for s, a, o in zip(fx["state"], fx["action"], fx["next_state"]):
+        assert np.max(np.abs(oracle.unicycle_rk4(s, a, float(fx["ts"])) - o)) < 1e-14
+
+
+def test_gradient_by_central_differences():
+    cfg = oracle_cfg(make_cfg(20))
+    fx = load_golden("costgrad_N20.npz")
+    rng = np.random.default_rng(3)
+    for i in (2, 3, 5):
+        u, p, c, y = fx["u"][i], fx["p"][i], float(fx["c"][i]), fx["y"][i]
+        g = oracle.cost_grad(cfg, u, p, c, y)["grad"]
+        d = rng.standard_normal(u.size)
+        h = 1e-6
+        fp = oracle.cost_grad(cfg, u + h * d, p, c, y)["psi"]
+        fm = oracle.cost_grad(cfg, u - h * d, p, c, y)["psi"]
+        assert abs((fp - fm) / (2 * h) - g @ d) <= 2e-5 * max(1.0, abs(g @ d))
+
+
+def test_solver_easy_problem_converges_and_is_feasible():
+    from trajtrack_mpcndqn_rlboost_amd import scenes
+    cfg = make_cfg(20)
+    ocfg = oracle_cfg(cfg)
+    sc = scenes.make_batch(cfg, 16, n_dyn=0, with_box=False, with_walls=False, seed=5)
+    u, y, res, _ = oracle.solve_batch(ocfg, sc["p"], nthreads=4)
+    uu = u.reshape(16, 20, 2)
+    assert np.all(uu[..., 0] >= cfg.lin_vel_min - 1e-12) and np.all(uu[..., 0] <= cfg.lin_vel_max + 1e-12)
+    assert np.all(np.abs(uu[..., 1]) <= cfg.ang_vel_max + 1e-12)
+    assert (res["status"] == 0).sum() >= 4
+    assert np.all(res["f2_norm"] == 0.0)
+    # the reported cost is f(u) (psi with c = 0)
+    for i in range(4):
+        assert abs(oracle.cost_grad(ocfg, u[i], sc["p"][i])["f"] - res["cost"][i]) < 1e-9 * max(1, res["cost"][i])
+    # warm start from the solution: converges immediately to (numerically) the same point
+    u2, _, res2, _ = oracle.solve_batch(ocfg, sc["p"], u0=u, nthreads=4)
+    conv = (res["status"] == 0) & (res2["status"] == 0)
+    assert np.max(np.abs(u2[conv] - u[conv])) < 1e-4
+    assert res2["inner_iters"][conv].mean() < res["inner_iters"][conv].mean()
+
+
+def test_iteration_caps_and_status_codes():
+    from trajtrack_mpcndqn_rlboost_amd import scenes
+    cfg = make_cfg(20, solver_max_inner_iterations=3, solver_max_outer_iterations=2)
+    sc = scenes.make_batch(cfg, 4, n_dyn=4, seed=6)
+    u, y, res, _ = oracle.solve_batch(oracle_cfg(cfg), sc["p"], nthreads=2)
+    assert np.all(res["status"] == 1)             # NotConvergedIterations
+    assert np.all(res["outer_iters"] == 2)
+    assert np.all(res["inner_iters"] <= 2 * 3)

@@ -47,6 +47,16 @@ struct KParams {
     int l_seg, l_stc, l_fm, l_fxy, l_dm, l_dyn, l_pos, l_H, l_W, l_part, l_S, l_Y, l_rho, l_alpha, l_total;
 };
 
+// lanes per step for the item phase
+__host__ __device__ constexpr int lps_of(int n) { return n <= 16 ? 4 : (n <= 21 ? 3 : (n <= 32 ? 2 : 1)); }
+// compile-time horizon NT (0 = runtime horizon from KParams; DPP row counts then cover the whole wave)
+template <int NT>
+struct Dim {
+    static constexpr int LPS = NT ? lps_of(NT) : 0;
+    static constexpr int ROWS_V = NT ? (NT + 15) / 16 : 4;             // rows holding vector lanes
+    static constexpr int ROWS_I = NT ? (NT * lps_of(NT) + 15) / 16 : 4;  // rows holding item lanes
+};
+
 struct BatchPtrs {
     const double* p; const double* u0; const double* y0; const double* c0;
     double* u; double* cost; int32_t* status; int32_t* inner_it; int32_t* outer_it;
@@ -55,42 +65,81 @@ struct BatchPtrs {
 };
 
 // ------------------------------------------------------------------------------------------------
-// wave helpers (all 64 lanes participate; results of sums are bit-identical in every lane)
+// wave primitives on DPP (data-parallel primitives: cross-lane operands inside VALU instructions, no LDS
+// round trip).  gfx950 is a GFX9-family wave64 target: row_shr / row_shl / row_bcast / wave_shr are legal.
+// A double moves as two 32-bit DPP movs.  Sums are bit-identical in every lane (they come out of SGPRs).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double x) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) x += __shfl_xor(x, d);
-    return x;
+enum : int {
+    DPP_ROW_SHL0 = 0x100, DPP_ROW_SHR0 = 0x110, DPP_WAVE_SHL1 = 0x130, DPP_WAVE_SHR1 = 0x138,
+    DPP_BCAST15 = 0x142, DPP_BCAST31 = 0x143
+};
+// lanes whose source is outside the row / wave, or that are masked off, receive 0
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double dpp0(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_d(double x, int l) {  // uniform broadcast of lane l
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+    return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double uniform(double x) {  // tell the compiler x is wave-uniform
     const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
     const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_sum_u(double x) { return uniform(wave_sum(x)); }
-// inclusive prefix sum over lanes 0..n-1 (lanes >= n must carry 0)
-__device__ __forceinline__ double scan_prefix(double x, int lane, int n) {
-    for (int d = 1; d < n; d <<= 1) {
-        const double t = __shfl_up(x, d);
-        if (lane >= d) x += t;
-    }
+// inclusive prefix sum inside every 16-lane row
+__device__ __forceinline__ double row_prefix(double x) {
+    x += dpp0<DPP_ROW_SHR0 + 1>(x);
+    x += dpp0<DPP_ROW_SHR0 + 2>(x);
+    x += dpp0<DPP_ROW_SHR0 + 4>(x);
+    x += dpp0<DPP_ROW_SHR0 + 8>(x);
     return x;
 }
-// inclusive suffix sum over lanes 0..n-1 (lanes >= n must carry 0)
-__device__ __forceinline__ double scan_suffix(double x, int lane, int n) {
-    for (int d = 1; d < n; d <<= 1) {
-        const double t = __shfl_down(x, d);
-        if (lane + d < WAVE) x += t;
-    }
+__device__ __forceinline__ double row_suffix(double x) {
+    x += dpp0<DPP_ROW_SHL0 + 1>(x);
+    x += dpp0<DPP_ROW_SHL0 + 2>(x);
+    x += dpp0<DPP_ROW_SHL0 + 4>(x);
+    x += dpp0<DPP_ROW_SHL0 + 8>(x);
+    return x;
+}
+// sum over the first ROWS*16 lanes (lanes that do not take part must carry 0); uniform result
+template <int ROWS>
+__device__ __forceinline__ double wave_sum_u(double x) {
+    x = row_prefix(x);  // lane 15 of each row = row total
+    double t = readlane_d(x, 15);
+    if (ROWS > 1) t += readlane_d(x, 31);
+    if (ROWS > 2) t += readlane_d(x, 47);
+    if (ROWS > 3) t += readlane_d(x, 63);
+    return uniform(t);
+}
+// inclusive prefix sum over lanes 0..16*ROWS-1 (lanes >= n must carry 0)
+template <int ROWS>
+__device__ __forceinline__ double scan_prefix(double x) {
+    x = row_prefix(x);
+    if (ROWS > 1) x += dpp0<DPP_BCAST15, 0xA>(x);  // last lane of rows 0/2 -> rows 1/3
+    if (ROWS > 2) x += dpp0<DPP_BCAST31, 0xC>(x);  // lane 31 -> rows 2,3
+    return x;
+}
+// inclusive suffix sum over lanes 0..16*ROWS-1 (lanes >= n must carry 0)
+template <int ROWS>
+__device__ __forceinline__ double scan_suffix(double x, int lane) {
+    x = row_suffix(x);  // first lane of each row = row total
+    // cascade from the top row down: each row adds the (already completed) first lane of the row above it
+    if (ROWS > 3) { const double t = readlane_d(x, 48); if (lane >= 32 && lane < 48) x += t; }
+    if (ROWS > 2) { const double t = readlane_d(x, 32); if (lane >= 16 && lane < 32) x += t; }
+    if (ROWS > 1) { const double t = readlane_d(x, 16); if (lane < 16) x += t; }
     return x;
 }
 __device__ __forceinline__ double shift_up1(double x, int lane, double first) {  // lane k gets lane k-1
-    const double t = __shfl_up(x, 1);
+    const double t = dpp0<DPP_WAVE_SHR1>(x);
     return lane == 0 ? first : t;
 }
-__device__ __forceinline__ double shift_down1(double x, int lane) {  // lane k gets lane k+1 (lane 63: 0)
-    const double t = __shfl_down(x, 1);
-    return lane == WAVE - 1 ? 0.0 : t;
+__device__ __forceinline__ double shift_down1(double x) {  // lane k gets lane k+1 (lane 63: 0)
+    return dpp0<DPP_WAVE_SHL1>(x);
 }
 __device__ __forceinline__ double clampd(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
 
@@ -250,13 +299,15 @@ struct EvalOut {
     double F2e;             // lane i < Kd: F2 value of dynamic entry i
 };
 
+template <int NT>
 __device__ __forceinline__ void load_problem(const KParams& kp, const double* __restrict__ ws, double* lds,
                                              Ctx& cx) {
     const int lane = threadIdx.x;
-    const int N = kp.N;
+    const int N = NT ? NT : kp.N;
+    const int LPS = NT ? Dim<NT>::LPS : kp.LPS;
     cx.lane = lane;
     cx.vl = lane < N;
-    cx.il = lane < N * kp.LPS;
+    cx.il = lane < N * LPS;
     cx.ik = lane % N;
     cx.isub = lane / N;
     cx.x0 = ws[0]; cx.y0 = ws[1]; cx.th0 = ws[2]; cx.xg = ws[3]; cx.yg = ws[4]; cx.thg = ws[5];
@@ -282,16 +333,18 @@ __device__ __forceinline__ void load_problem(const KParams& kp, const double* __
 // ------------------------------------------------------------------------------------------------
 // psi(u; c, y), f(u), F1, F2 and (optionally) grad psi at the point held by the vector lanes.
 // ------------------------------------------------------------------------------------------------
+template <int NT>
 __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, double v, double w, double c,
                                            double ya, double yb, bool want_grad, EvalOut& out) {
-    const int N = kp.N, LPS = kp.LPS, lane = cx.lane;
+    const int N = NT ? NT : kp.N, LPS = NT ? Dim<NT>::LPS : kp.LPS, lane = cx.lane;
+    constexpr int RV = Dim<NT>::ROWS_V, RI = Dim<NT>::ROWS_I;
     const double ts = kp.ts;
     const double inf = __builtin_huge_val();
     if (!cx.vl) { v = 0.0; w = 0.0; }
 
     // ---- rollout: headings are a prefix sum of ts*w, positions a prefix sum of Simpson increments
     const double tw = ts * w;
-    const double th1 = cx.th0 + scan_prefix(tw, lane, N);  // theta_{k+1}
+    const double th1 = cx.th0 + scan_prefix<RV>(tw);  // theta_{k+1}
     const double thm = th1 - 0.5 * tw;                      // theta_k + ts*w_k/2
     double sm, cm, s2, c2;
     sincos(thm, &sm, &cm);
@@ -300,8 +353,8 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     const double sixth = 1.0 / 6.0;
     const double Cx = (c0 + 4.0 * cm + c2) * sixth, Sy = (s0 + 4.0 * sm + s2) * sixth;
     const double dCw = -ts * (2.0 * sm + s2) * sixth, dSw = ts * (2.0 * cm + c2) * sixth;
-    const double X = cx.x0 + scan_prefix(cx.vl ? ts * v * Cx : 0.0, lane, N);
-    const double Y = cx.y0 + scan_prefix(cx.vl ? ts * v * Sy : 0.0, lane, N);
+    const double X = cx.x0 + scan_prefix<RV>(cx.vl ? ts * v * Cx : 0.0);
+    const double Y = cx.y0 + scan_prefix<RV>(cx.vl ? ts * v * Sy : 0.0);
     if (cx.vl) { cx.pos[2 * lane] = X; cx.pos[2 * lane + 1] = Y; }
     __syncthreads();
 
@@ -378,7 +431,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     __syncthreads();
 
     // ---- constraint sums: S (static, broadcast into every F2 component), D_i (row sums of H)
-    const double S = wave_sum_u(S_l);
+    const double S = wave_sum_u<RI>(S_l);
     double F2e = 0.0, mult_i = 0.0;
     if (lane < cx.Kd) {
         double D = 0.0;
@@ -386,13 +439,13 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         mult_i = cx.dm[lane];
         F2e = S + D;
     }
-    const double nrm2F2 = wave_sum_u(mult_i * F2e * F2e);
+    const double nrm2F2 = wave_sum_u<2>(mult_i * F2e * F2e);
     out.F2e = F2e;
     out.nrm2F2 = nrm2F2;
 
     // ---- item phase B (only when some penalty constraint is violated): weighted hard-constraint gradients
     if (want_grad && nrm2F2 > 0.0) {
-        const double sumF2 = wave_sum_u(mult_i * F2e);
+        const double sumF2 = wave_sum_u<2>(mult_i * F2e);
         if (lane < cx.Kd) cx.W[lane] = c * mult_i * F2e;
         __syncthreads();
         if (cx.il) {
@@ -454,22 +507,22 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
             gthN = 2.0 * cx.qthN * et;
         }
     }
-    const double f = wave_sum_u(cost_l + vcost);
-    const double dist2 = wave_sum_u(cx.vl ? ea * ea + eb * eb : 0.0);
+    const double f = wave_sum_u<RI>(cost_l + vcost);
+    const double dist2 = wave_sum_u<RV>(cx.vl ? ea * ea + eb * eb : 0.0);
     out.f = f;
     out.psi = f + 0.5 * c * dist2 + 0.5 * c * nrm2F2;
 
     if (want_grad) {
-        gthN = __shfl(gthN, N - 1);
+        gthN = readlane_d(gthN, N - 1);
         const double da = cx.vl ? (2.0 * cx.acc_pen * a + c * ea) * kp.inv_ts : 0.0;
         const double db = cx.vl ? (2.0 * cx.wacc_pen * bacc + c * eb) * kp.inv_ts : 0.0;
-        const double da_n = shift_down1(da, lane), db_n = shift_down1(db, lane);
+        const double da_n = shift_down1(da), db_n = shift_down1(db);
         double gv = 2.0 * cx.qvel * (v - cx.vref) + 2.0 * cx.rv * v + da - da_n;
         double gw = 2.0 * cx.rw * w + db - db_n;
         // adjoint of the rollout: suffix sums instead of a serial backward sweep
-        const double Ax = scan_suffix(Gx, lane, N), Ay = scan_suffix(Gy, lane, N);
+        const double Ax = scan_suffix<RV>(Gx, lane), Ay = scan_suffix<RV>(Gy, lane);
         const double T = cx.vl ? ts * v * (-Sy * Ax + Cx * Ay) : 0.0;
-        const double Bx = scan_suffix(T, lane, N) - T;
+        const double Bx = scan_suffix<RV>(T, lane) - T;
         gv += ts * (Cx * Ax + Sy * Ay);
         gw += ts * v * (dCw * Ax + dSw * Ay) + ts * (Bx + gthN);
         out.gv = cx.vl ? gv : 0.0;
@@ -480,23 +533,24 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
 // ------------------------------------------------------------------------------------------------
 // test-hook kernel: one evaluation per problem through eval_point
 // ------------------------------------------------------------------------------------------------
+template <int NT>
 __global__ __launch_bounds__(WAVE) void cost_grad_kernel(KParams kp, BatchPtrs io, const double* __restrict__ u,
                                                          const double* __restrict__ xi, double* psi, double* f,
                                                          double* grad, double* F1, double* F2, int B) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int b = blockIdx.x;
     if (b >= B) return;
-    const int lane = threadIdx.x, N = kp.N;
+    const int lane = threadIdx.x, N = NT ? NT : kp.N;
     const double* ws = io.ws + (size_t)b * kp.ws_stride;
     Ctx cx;
-    load_problem(kp, ws, lds, cx);
+    load_problem<NT>(kp, ws, lds, cx);
     const double* ub = u + (size_t)b * 2 * N;
     const double* xb = xi + (size_t)b * (1 + 2 * N);
     const double v = cx.vl ? ub[2 * lane] : 0.0, w = cx.vl ? ub[2 * lane + 1] : 0.0;
     const double c = xb[0];
     const double ya = cx.vl ? xb[1 + lane] : 0.0, yb = cx.vl ? xb[1 + N + lane] : 0.0;
     EvalOut o;
-    eval_point(kp, cx, v, w, c, ya, yb, true, o);
+    eval_point<NT>(kp, cx, v, w, c, ya, yb, true, o);
     if (lane == 0) {
         if (psi) psi[b] = o.psi;
         if (f) f[b] = o.f;
@@ -507,7 +561,7 @@ __global__ __launch_bounds__(WAVE) void cost_grad_kernel(KParams kp, BatchPtrs i
     }
     if (F2 && lane < kp.Ndynobs) {
         const int e = (int)ws[H_ENTRY + lane];
-        F2[(size_t)b * kp.Ndynobs + lane] = __shfl(o.F2e, e);
+        F2[(size_t)b * kp.Ndynobs + lane] = __shfl(o.F2e, e);  // test hook only: one LDS-crossbar gather
     }
 }
 
@@ -517,19 +571,22 @@ __global__ __launch_bounds__(WAVE) void cost_grad_kernel(KParams kp, BatchPtrs i
 // ------------------------------------------------------------------------------------------------
 enum { ST_INIT0 = 0, ST_INIT1, ST_LIP, ST_NOLS, ST_LS, ST_OUTER };
 
-__device__ __forceinline__ double dot2(double a0, double a1, double b0, double b1) {
-    return wave_sum_u(a0 * b0 + a1 * b1);
+template <int ROWS>
+__device__ __forceinline__ double dot2r(double a0, double a1, double b0, double b1) {
+    return wave_sum_u<ROWS>(a0 * b0 + a1 * b1);
 }
 
+template <int NT>
 __global__ __launch_bounds__(WAVE) void solve_kernel(KParams kp, BatchPtrs io, int B) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int b = blockIdx.x;
     if (b >= B) return;
     const long long t_start = wall_clock64();
-    const int lane = threadIdx.x, N = kp.N, mem = kp.mem;
+    const int lane = threadIdx.x, N = NT ? NT : kp.N, mem = kp.mem;
+    constexpr int RV = Dim<NT>::ROWS_V;
     const double* ws = io.ws + (size_t)b * kp.ws_stride;
     Ctx cx;
-    load_problem(kp, ws, lds, cx);
+    load_problem<NT>(kp, ws, lds, cx);
     double* LS = lds + kp.l_S;      // [mem][N][2]
     double* LY = lds + kp.l_Y;      // [mem][N][2]
     double* LRHO = lds + kp.l_rho;  // [mem]
@@ -576,7 +633,7 @@ __global__ __launch_bounds__(WAVE) void solve_kernel(KParams kp, BatchPtrs io, i
     EvalOut o;
 
     for (;;) {
-        eval_point(kp, cx, ev, ew, c, ya, yb, want_grad, o);
+        eval_point<NT>(kp, cx, ev, ew, c, ya, yb, want_grad, o);
         bool step_begin = false;
 
         if (state == ST_INIT0) {
@@ -584,12 +641,12 @@ __global__ __launch_bounds__(WAVE) void solve_kernel(KParams kp, BatchPtrs io, i
             cost = o.psi; gv = o.gv; gw = o.gw; g0v = gv; g0w = gw;
             const double h0 = vl ? ((EPS_LIP * uv > DELTA_LIP) ? EPS_LIP * uv : DELTA_LIP) : 0.0;
             const double h1 = vl ? ((EPS_LIP * uw > DELTA_LIP) ? EPS_LIP * uw : DELTA_LIP) : 0.0;
-            nh = sqrt(dot2(h0, h1, h0, h1));
+            nh = sqrt(dot2r<RV>(h0, h1, h0, h1));
             ev = uv + h0; ew = uw + h1; want_grad = true; state = ST_INIT1;
             continue;
         } else if (state == ST_INIT1) {
             const double d0 = o.gv - g0v, d1 = o.gw - g0w;
-            Lip = sqrt(dot2(d0, d1, d0, d1)) / nh;
+            Lip = sqrt(dot2r<RV>(d0, d1, d0, d1)) / nh;
             gamma = GAMMA_L_COEFF / fmax(Lip, MIN_L);
             sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * gamma);
             sv = uv - gamma * gv; sw = uw - gamma * gw;
@@ -597,7 +654,7 @@ __global__ __launch_bounds__(WAVE) void solve_kernel(KParams kp, BatchPtrs io, i
             step_begin = true;
         } else if (state == ST_LIP) {
             const double cost_half = o.psi;
-            const double ip = dot2(gv, gw, rv_, rw_);
+            const double ip = dot2r<RV>(gv, gw, rv_, rw_);
             const double rhs_lip = cost + LIP_UPD_EPS * fabs(cost) - ip + (GAMMA_L_COEFF / (2.0 * gamma)) * nfpr * nfpr;
             if (cost_half > rhs_lip && lip_it < MAX_LIP_IT && Lip < MAX_LIP) {
                 lb_active = 0; lb_first = true;  // invalidate the L-BFGS buffer
@@ -605,7 +662,7 @@ __global__ __launch_bounds__(WAVE) void solve_kernel(KParams kp, BatchPtrs io, i
                 sv = uv - gamma * gv; sw = uw - gamma * gw;
                 hv = vl ? clampd(sv, kp.vmin, kp.vmax) : 0.0; hw = vl ? clampd(sw, -kp.wmax, kp.wmax) : 0.0;
                 rv_ = uv - hv; rw_ = uw - hw;
-                nfpr = sqrt(dot2(rv_, rw_, rv_, rw_));
+                nfpr = sqrt(dot2r<RV>(rv_, rw_, rv_, rw_));
                 ++lip_it;
                 ev = hv; ew = hw; want_grad = false;
                 continue;
@@ -617,7 +674,7 @@ __global__ __launch_bounds__(WAVE) void solve_kernel(KParams kp, BatchPtrs io, i
                 osv = uv; osw = uw; ogv = rv_; ogw = rw_;
             } else {
                 const double s0 = uv - osv, s1 = uw - osw, y0_ = rv_ - ogv, y1_ = rw_ - ogw;
-                const double ys = dot2(s0, s1, y0_, y1_), ss = dot2(s0, s1, s0, s1);
+                const double ys = dot2r<RV>(s0, s1, y0_, y1_), ss = dot2r<RV>(s0, s1, s0, s1);
                 if (!(ss <= DBLMIN || ys <= 1e-10) && (ys / ss > 1e-8 * nfpr)) {
                     osv = uv; osw = uw; ogv = rv_; ogw = rw_;
                     lb_head = (lb_head + mem - 1) % mem;
@@ -626,7 +683,7 @@ __global__ __launch_bounds__(WAVE) void solve_kernel(KParams kp, BatchPtrs io, i
                         LY[(lb_head * N + lane) * 2] = y0_; LY[(lb_head * N + lane) * 2 + 1] = y1_;
                     }
                     if (lane == 0) LRHO[lb_head] = 1.0 / ys;
-                    lb_gamma = ys / dot2(y0_, y1_, y0_, y1_);
+                    lb_gamma = ys / dot2r<RV>(y0_, y1_, y0_, y1_);
                     lb_active = (lb_active + 1 < mem) ? lb_active + 1 : mem;
                     __syncthreads();
                 }
@@ -642,7 +699,7 @@ __global__ __launch_bounds__(WAVE) void solve_kernel(KParams kp, BatchPtrs io, i
             for (int j = 0; j < lb_active; ++j) {
                 const int sl = (lb_head + j) % mem;
                 const double sj0 = vl ? LS[(sl * N + lane) * 2] : 0.0, sj1 = vl ? LS[(sl * N + lane) * 2 + 1] : 0.0;
-                const double al = LRHO[sl] * dot2(sj0, sj1, q0, q1);
+                const double al = LRHO[sl] * dot2r<RV>(sj0, sj1, q0, q1);
                 if (lane == 0) LALPHA[j] = al;
                 if (vl) { q0 -= al * LY[(sl * N + lane) * 2]; q1 -= al * LY[(sl * N + lane) * 2 + 1]; }
             }
@@ -651,16 +708,16 @@ __global__ __launch_bounds__(WAVE) void solve_kernel(KParams kp, BatchPtrs io, i
             for (int j = lb_active - 1; j >= 0; --j) {
                 const int sl = (lb_head + j) % mem;
                 const double yj0 = vl ? LY[(sl * N + lane) * 2] : 0.0, yj1 = vl ? LY[(sl * N + lane) * 2 + 1] : 0.0;
-                const double be = LRHO[sl] * dot2(yj0, yj1, q0, q1);
+                const double be = LRHO[sl] * dot2r<RV>(yj0, yj1, q0, q1);
                 const double co = LALPHA[j] - be;
                 if (vl) { q0 += co * LS[(sl * N + lane) * 2]; q1 += co * LS[(sl * N + lane) * 2 + 1]; }
             }
             dv = q0; dw = q1;
             // ---- line search on the forward-backward envelope
             {
-                const double gg = dot2(gv, gw, gv, gw);
+                const double gg = dot2r<RV>(gv, gw, gv, gw);
                 const double e0 = sv - hv, e1 = sw - hw;
-                const double d2 = dot2(e0, e1, e0, e1);
+                const double d2 = dot2r<RV>(e0, e1, e0, e1);
                 const double fbe = cost - 0.5 * gamma * gg + 0.5 * d2 / gamma;
                 rhs = fbe - sigma * nfpr * nfpr;
             }
@@ -678,9 +735,9 @@ __global__ __launch_bounds__(WAVE) void solve_kernel(KParams kp, BatchPtrs io, i
             cost = o.psi; gv = o.gv; gw = o.gw;
             sv = pv - gamma * gv; sw = pw - gamma * gw;
             hv = vl ? clampd(sv, kp.vmin, kp.vmax) : 0.0; hw = vl ? clampd(sw, -kp.wmax, kp.wmax) : 0.0;
-            const double gg = dot2(gv, gw, gv, gw);
+            const double gg = dot2r<RV>(gv, gw, gv, gw);
             const double e0 = sv - hv, e1 = sw - hw;
-            const double d2 = dot2(e0, e1, e0, e1);
+            const double d2 = dot2r<RV>(e0, e1, e0, e1);
             const double lhs = cost - 0.5 * gamma * gg + 0.5 * d2 / gamma;
             if (lhs > rhs && nls < MAX_LS_IT) {
                 tau *= 0.5; ++nls;
@@ -703,7 +760,7 @@ __global__ __launch_bounds__(WAVE) void solve_kernel(KParams kp, BatchPtrs io, i
                 ypb = yb + c * (o.F1b - clampd(zb, -kp.aamax, kp.aamax));
                 dy2l = (ypa - ya) * (ypa - ya) + (ypb - yb) * (ypb - yb);
             }
-            dy_norm_plus = sqrt(wave_sum_u(dy2l));
+            dy_norm_plus = sqrt(wave_sum_u<RV>(dy2l));
             f2_norm_plus = sqrt(o.nrm2F2);
             const bool crit1 = alm_iteration > 0 && dy_norm_plus <= c * kp.delta_tol + SMALL_EPS;
             const bool crit2 = f2_norm_plus <= kp.delta_tol + SMALL_EPS;
@@ -743,11 +800,11 @@ __global__ __launch_bounds__(WAVE) void solve_kernel(KParams kp, BatchPtrs io, i
             if (!inner_done) {
                 if (iter >= 1) { gpv = gv; gpw = gw; }
                 rv_ = uv - hv; rw_ = uw - hw;
-                nfpr = sqrt(dot2(rv_, rw_, rv_, rw_));
+                nfpr = sqrt(dot2r<RV>(rv_, rw_, rv_, rw_));
                 bool ex = nfpr < kp.tol;
                 if (ex) {  // AKKT residual || gfpr/gamma + grad - grad_prev || < eps_nu
                     const double a0 = rv_ / gamma + gv - gpv, a1 = rw_ / gamma + gw - gpw;
-                    ex = sqrt(dot2(a0, a1, a0, a1)) < akkt_tol;
+                    ex = sqrt(dot2r<RV>(a0, a1, a0, a1)) < akkt_tol;
                 }
                 if (ex) {
                     inner_done = true;

@@ -70,9 +70,7 @@ void fill_static_params(Handle* h) {
     KParams& k = h->kp;
     const int N = c.N;
     k.N = N;
-    k.LPS = WAVE / N;
-    if (k.LPS > 4) k.LPS = 4;
-    if (k.LPS < 1) k.LPS = 1;
+    k.LPS = lps_of(N);
     k.Nother = c.Nother; k.Nstcobs = c.Nstcobs; k.Ndynobs = c.Ndynobs; k.mem = c.lbfgs_mem;
     k.max_inner = c.max_inner; k.max_outer = c.max_outer;
     k.ts = c.ts; k.inv_ts = 1.0 / c.ts;
@@ -245,7 +243,12 @@ int32_t mpcgpu_solve_batch_dev(void* handle, int32_t B, const double* p, const d
     io.u0 = u0; io.y0 = y0; io.c0 = c0; io.u = u; io.cost = cost; io.status = status; io.inner_it = inner_it;
     io.outer_it = outer_it; io.fpr = fpr; io.f2norm = f2norm; io.y_out = y_out; io.ms = ms;
     HIP_OK(h, hipEventRecord(h->ev[2], s));
-    hipLaunchKernelGGL(solve_kernel, dim3(B), dim3(WAVE), h->kp.l_total * sizeof(double), s, h->kp, io, B);
+    const size_t lds = h->kp.l_total * sizeof(double);
+    switch (h->kp.N) {  // compile-time horizons for the configurations the reference uses; generic otherwise
+        case 20: hipLaunchKernelGGL(solve_kernel<20>, dim3(B), dim3(WAVE), lds, s, h->kp, io, B); break;
+        case 40: hipLaunchKernelGGL(solve_kernel<40>, dim3(B), dim3(WAVE), lds, s, h->kp, io, B); break;
+        default: hipLaunchKernelGGL(solve_kernel<0>, dim3(B), dim3(WAVE), lds, s, h->kp, io, B); break;
+    }
     HIP_OK(h, hipGetLastError());
     HIP_OK(h, hipEventRecord(h->ev[3], s));
     h->timing_valid = true;
@@ -319,9 +322,16 @@ int32_t mpcgpu_cost_grad_batch(void* handle, int32_t B, const double* u, const d
     HIP_OK(h, hipMemcpyAsync(h->xi.ptr, xi, Bz * (n + 1) * 8, hipMemcpyHostToDevice, s));
     BatchPtrs io{};
     if (int r = prepare(h, B, (const double*)h->p.ptr, s, io)) return r;
-    hipLaunchKernelGGL(cost_grad_kernel, dim3(B), dim3(WAVE), h->kp.l_total * sizeof(double), s, h->kp, io,
-                       (const double*)h->u.ptr, (const double*)h->xi.ptr, (double*)h->psi.ptr, (double*)h->f.ptr,
-                       (double*)h->grad.ptr, (double*)h->F1.ptr, (double*)h->F2.ptr, B);
+#define LAUNCH_CG(NT)                                                                                          \
+    hipLaunchKernelGGL(cost_grad_kernel<NT>, dim3(B), dim3(WAVE), h->kp.l_total * sizeof(double), s, h->kp, io,  \
+                       (const double*)h->u.ptr, (const double*)h->xi.ptr, (double*)h->psi.ptr, (double*)h->f.ptr, \
+                       (double*)h->grad.ptr, (double*)h->F1.ptr, (double*)h->F2.ptr, B)
+    switch (h->kp.N) {
+        case 20: LAUNCH_CG(20); break;
+        case 40: LAUNCH_CG(40); break;
+        default: LAUNCH_CG(0); break;
+    }
+#undef LAUNCH_CG
     HIP_OK(h, hipGetLastError());
     if (psi) HIP_OK(h, hipMemcpyAsync(psi, h->psi.ptr, Bz * 8, hipMemcpyDeviceToHost, s));
     if (f) HIP_OK(h, hipMemcpyAsync(f, h->f.ptr, Bz * 8, hipMemcpyDeviceToHost, s));

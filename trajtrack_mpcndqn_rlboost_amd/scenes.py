@@ -41,8 +41,11 @@ def work_mode_weights(cfg: MpcConfig) -> np.ndarray:
 
 
 def make_batch(cfg: MpcConfig, B: int, n_dyn: int = 8, seed: int = 1234, n_other: int = 0,
-               with_box: bool = True, with_walls: bool = True) -> Dict[str, np.ndarray]:
-    """Returns dict(p=[B, np] float64, start=[B,3], ref=[B,N,3])."""
+               with_box: bool = True, with_walls: bool = True, v_init_range=(0.0, 1.2)) -> Dict[str, np.ndarray]:
+    """Returns dict(p=[B, np] float64, start=[B,3], ref=[B,N,3]).
+
+    ``v_init_range``: range of the previously applied linear speed (p[6]).  Close to the reference speed
+    (1.2 m/s) the acceleration constraints stay inactive and the ALM loop converges in two outer iterations."""
     N = int(cfg.N_hor)
     off = cfg.offsets()
     assert n_dyn <= cfg.Ndynobs and n_other <= cfg.Nother
@@ -78,7 +81,7 @@ def make_batch(cfg: MpcConfig, B: int, n_dyn: int = 8, seed: int = 1234, n_other
 
     p[:, 0] = x; p[:, 1] = y; p[:, 2] = th
     p[:, 3:6] = ref[:, -1, :]                             # finish_state = current_ref_traj[-1] (:254)
-    p[:, 6] = rng.uniform(0.0, 1.2, B)                    # last_u
+    p[:, 6] = rng.uniform(v_init_range[0], v_init_range[1], B)  # last_u
     p[:, 7] = rng.uniform(-0.2, 0.2, B)
     p[:, off["q"]:off["q"] + 10] = work_mode_weights(cfg)
     p[:, off["r"]:off["r"] + 3 * N] = ref.reshape(B, 3 * N)
