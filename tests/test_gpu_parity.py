@@ -214,11 +214,13 @@ def test_horizon_40_and_generic_horizon(solver40, cfg40):
     assert np.max(np.abs(res.solution - uo)) < 1e-6 and np.array_equal(res.num_inner_iterations, ro["inner_iters"])
     bs.close()
     # full solve, N = 40, easy scene
-    sc = scenes.make_batch(cfg40, 32, n_dyn=0, with_box=False, seed=72, v_init_range=(1.0, 1.2))
+    sc = scenes.make_batch(cfg40, 96, n_dyn=0, with_box=False, seed=72, v_init_range=(1.0, 1.2))
     res = solver40.solve(sc["p"])
     uo, _, ro, _ = oracle.solve_batch(oracle_cfg(cfg40), sc["p"])
     both = (res.status == 0) & (ro["status"] == 0)
-    assert both.sum() >= 4 and np.max(np.abs(res.solution - uo), axis=1)[both].max() <= U_TOL
+    assert both.sum() >= 8, (int((res.status == 0).sum()), int((ro["status"] == 0).sum()), int(both.sum()))
+    assert np.max(np.abs(res.solution - uo), axis=1)[both].max() <= U_TOL
+    assert abs(int((res.status == 0).sum()) - int((ro["status"] == 0).sum())) <= 24
     # a horizon without a compiled specialisation goes through the generic kernel
     cfg12 = make_cfg(12, solver_max_inner_iterations=10, solver_max_outer_iterations=2)
     bs = BatchSolver(cfg12)
@@ -227,6 +229,49 @@ def test_horizon_40_and_generic_horizon(solver40, cfg40):
     res = bs.solve(sc["p"], u0)
     uo, _, ro, _ = oracle.solve_batch(oracle_cfg(cfg12), sc["p"], u0)
     assert np.max(np.abs(res.solution - uo)) < 1e-5
+    bs.close()
+
+
+def test_time_varying_obstacle_shapes_take_the_general_tables(cfg20):
+    """Scanner-style predictions change the semi-axes / angle along the horizon
+    (obstacle_simulator/_obstacle_simulator.py:48-76): the batch then uses the general 9-doubles-per-item LDS
+    tables instead of the shape-constant ones.  Both layouts must give the same numbers as the oracle."""
+    ocfg = oracle_cfg(cfg20)
+    off = cfg20.offsets()
+    N = 20
+    sc = scenes.make_batch(cfg20, 48, n_dyn=6, seed=111)
+    p = sc["p"].copy()
+    od = p[:, off["od"]:off["od"] + cfg20.Ndynobs * 6 * N].reshape(48, cfg20.Ndynobs, N, 6)
+    k = np.arange(N)
+    od[:, :6, :, 2] = 0.6 + 0.05 * k            # growing uncertainty ellipse
+    od[:, :6, :, 3] = 0.4 + 0.03 * k
+    od[:, :6, :, 4] = 0.3 + 0.02 * k
+    od[:, :6, :, 5] = np.linspace(1.0, 0.3, N)
+    rng = np.random.default_rng(5)
+    u = np.stack([rng.uniform(-0.5, 1.5, (48, N)), rng.uniform(-0.5, 0.5, (48, N))], axis=2).reshape(48, 2 * N)
+    bs = BatchSolver(cfg20)
+    r = bs.cost_grad(u, p, np.full(48, 50.0))
+    n_hit = 0
+    for i in range(48):
+        o = oracle.cost_grad(ocfg, u[i], p[i], 50.0)
+        assert _rel(r["psi"][i], o["psi"]) < RTOL_COST and _rel(r["grad"][i], o["grad"]) < RTOL_COST
+        assert _rel(r["F2"][i], o["F2"]) < RTOL_COST
+        n_hit += o["F2"].max() > 0
+    assert n_hit >= 5
+    bs.close()
+    cfgk = make_cfg(20, solver_max_inner_iterations=6, solver_max_outer_iterations=2)
+    bs = BatchSolver(cfgk)
+    u0 = np.tile([0.6, 0.1], (48, 20))
+    res = bs.solve(p, u0)
+    uo, _, ro, _ = oracle.solve_batch(oracle_cfg(cfgk), p, u0)
+    assert np.array_equal(res.num_inner_iterations, ro["inner_iters"])
+    assert np.max(np.abs(res.solution - uo)) < 1e-5
+    # a mixed batch (some rows shape-constant, some not) and the pure shape-constant batch agree bitwise on
+    # the shared problems?  No: the two layouts evaluate the same formulas from the same table values.
+    mixed = np.concatenate([p[:8], sc["p"][:8]])
+    a = bs.solve(mixed, np.tile([0.6, 0.1], (16, 20)))
+    b = bs.solve(sc["p"][:8], np.tile([0.6, 0.1], (8, 20)))
+    assert np.array_equal(a.solution[8:], b.solution)
     bs.close()
 
 

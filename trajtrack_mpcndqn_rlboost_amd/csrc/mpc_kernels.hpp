@@ -3,7 +3,7 @@
 // One problem instance per 64-lane wavefront (one wavefront per workgroup):
 //   * "vector lanes"  k < N hold step k of every horizon vector: (v_k, w_k) of u, grad, FPR, L-BFGS work
 //     vectors, multipliers ... -- 2 doubles per lane, so n = 2N-dim vector algebra is one instruction and an
-//     inner product is one wave reduction;
+//     inner product is one DPP wave reduction;
 //   * "item lanes"    (k, sub) = (lane % N, lane / N), lane < N*LPS, split the (step x object) stage-cost
 //     terms of step k (reference-path segments, static polygons, dynamic ellipses, fleet discs);
 //   * the compacted problem tables and the L-BFGS memory live in LDS; HBM is touched once per solve.
@@ -17,18 +17,26 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef MPC_ITEM_LOOP
+#define MPC_ITEM_LOOP _Pragma("unroll 1")  // item loops: keep the loads of one iteration in flight, not of all
+#endif
+
 namespace mpcgpu {
 
 constexpr int WAVE = 64;
 constexpr int HDR = 64;        // header doubles per problem in the workspace
 constexpr int SEGW = 6;        // doubles per reference segment  (s1x, s1y, dx, dy, 1/(|d|^2+1e-16), pad)
 constexpr int STCW = 12;       // doubles per static obstacle    (b[4], a0[4], a1[4])
-constexpr int DYNW = 9;        // doubles per (dyn entry, step)  (cx, cy, cosA, sinA, ihx, ihy, isx, isy, wgt)
+constexpr int DYNW = 9;        // workspace record per (dyn row, step): cx, cy, cosA, sinA, ihx, ihy, isx, isy, wgt
+constexpr int DYNP = 3;        // shape-constant LDS record per (row, step): cx, cy, wgt
+constexpr int DYNC = 6;        // shape-constant LDS record per row: cosA, sinA, ihx, ihy, isx, isy
 constexpr int PARTW = 5;       // doubles per item-lane partial  (gx, gy, best, bgx, bgy)
 constexpr int MAX_MEM = 16;
 
-// header slots
-enum { H_KS = 18, H_KF = 19, H_KD = 20, H_CTH0 = 21, H_STH0 = 22, H_ENTRY = 24 /* .. +Ndynobs */ };
+// header slots (doubles)
+enum { H_KS = 18, H_KF = 19, H_KD = 20, H_CTH0 = 21, H_STH0 = 22, H_NPF = 23, H_NPD = 24, H_ENTRY = 26 /* .. +Ndynobs */ };
+// batch-wide reductions written by the compaction kernel
+enum { CNT_KS = 0, CNT_KF = 1, CNT_KD = 2, CNT_VARSHAPE = 3 };
 
 struct KParams {
     int N, LPS, Nother, Nstcobs, Ndynobs, np, mem;
@@ -41,10 +49,10 @@ struct KParams {
     // parameter-vector offsets (mpc_generator.py:179-188)
     int r0, c0, os0, od0, qs0, qd0;
     // workspace (global) layout per problem, doubles
-    int ws_stride, ws_vref, ws_seg, ws_stc, ws_fm, ws_fxy, ws_dm, ws_dyn;
+    int ws_stride, ws_vref, ws_seg, ws_stc, ws_fxy, ws_dyn;
     // LDS layout (doubles), strides use the batch maxima mKs/mKf/mKd
     int mKs, mKf, mKd;
-    int l_seg, l_stc, l_fm, l_fxy, l_dm, l_dyn, l_pos, l_H, l_W, l_part, l_S, l_Y, l_rho, l_alpha, l_total;
+    int l_seg, l_stc, l_fxy, l_dyn, l_dync, l_pos, l_H, l_W, l_part, l_S, l_Y, l_rho, l_alpha, l_old, l_total;
 };
 
 // lanes per step for the item phase
@@ -53,7 +61,7 @@ __host__ __device__ constexpr int lps_of(int n) { return n <= 16 ? 4 : (n <= 21 
 template <int NT>
 struct Dim {
     static constexpr int LPS = NT ? lps_of(NT) : 0;
-    static constexpr int ROWS_V = NT ? (NT + 15) / 16 : 4;             // rows holding vector lanes
+    static constexpr int ROWS_V = NT ? (NT + 15) / 16 : 4;               // rows holding vector lanes
     static constexpr int ROWS_I = NT ? (NT * lps_of(NT) + 15) / 16 : 4;  // rows holding item lanes
 };
 
@@ -81,6 +89,14 @@ __device__ __forceinline__ double dpp0(double x) {
     hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
     return __hiloint2double(hi, lo);
 }
+// ... receive `fill` instead (identity element of a multiplicative scan)
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double dppf(double x, double fill) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(__double2loint(fill), lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double readlane_d(double x, int l) {  // uniform broadcast of lane l
     const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
@@ -90,6 +106,13 @@ __device__ __forceinline__ double uniform(double x) {  // tell the compiler x is
     const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
     const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
     return __hiloint2double(hi, lo);
+}
+// One wavefront per workgroup: LDS operations of a wave execute in program order, so cross-lane exchange
+// through LDS needs no s_barrier -- only the compiler must not reorder across the exchange point.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 // inclusive prefix sum inside every 16-lane row
 __device__ __forceinline__ double row_prefix(double x) {
@@ -143,12 +166,39 @@ __device__ __forceinline__ double shift_down1(double x) {  // lane k gets lane k
 }
 __device__ __forceinline__ double clampd(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
 
+// inclusive prefix PRODUCT of unit complex numbers (re, im) over lanes 0..16*ROWS-1 (lanes >= n carry 1+0i)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void cmul_step(double& re, double& im) {
+    const double pr = dppf<CTRL, ROW_MASK>(re, 1.0), pi = dppf<CTRL, ROW_MASK>(im, 0.0);
+    const double nr = re * pr - im * pi, ni = re * pi + im * pr;
+    re = nr; im = ni;
+}
+template <int ROWS>
+__device__ __forceinline__ void scan_cprod(double& re, double& im) {
+    cmul_step<DPP_ROW_SHR0 + 1, 0xf>(re, im);
+    cmul_step<DPP_ROW_SHR0 + 2, 0xf>(re, im);
+    cmul_step<DPP_ROW_SHR0 + 4, 0xf>(re, im);
+    cmul_step<DPP_ROW_SHR0 + 8, 0xf>(re, im);
+    if (ROWS > 1) cmul_step<DPP_BCAST15, 0xA>(re, im);
+    if (ROWS > 2) cmul_step<DPP_BCAST31, 0xC>(re, im);
+}
+// sin / cos on [-pi/4, pi/4] (fdlibm kernel polynomials, error < 1 ulp there)
+__device__ __forceinline__ void sincos_small(double x, double& s, double& c) {
+    const double z = x * x;
+    const double ps = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
+                      z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+    s = x + x * z * ps;
+    const double pc = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                      z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+    c = 1.0 - 0.5 * z + z * z * pc;
+}
+
 // ------------------------------------------------------------------------------------------------
-// parameter compaction: p (mpc_generator.py:179-188 layout, mostly zero padding) -> per-problem tables
+// parameter compaction: p (mpc_generator.py:179-188 layout, mostly zero padding) -> per-problem tables.
+// Only ACTIVE rows get a table entry.  Zero padding keeps its reference semantics analytically:
 //   * all-zero static obstacles contribute exactly 0 (prod of max(0,0)^2)           -> dropped
-//   * all-zero other-robot rows are identical discs at the origin                   -> one entry x multiplicity
-//   * all-zero dynamic-obstacle rows are identical (rx=ry=0, alpha=0) ellipses at 0 -> one entry x multiplicity
-//   (zero padding keeps its reference semantics: a robot near the origin still feels it.)
+//   * all-zero other-robot rows are `npf` identical discs at the origin             -> closed form in the kernel
+//   * all-zero dynamic-obstacle rows are `npd` identical ellipses (rx=ry=0, alpha=0) at the origin -> closed form
 // one 64-thread block per problem.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WAVE) void prep_kernel(KParams kp, BatchPtrs io, int B) {
@@ -200,44 +250,37 @@ __global__ __launch_bounds__(WAVE) void prep_kernel(KParams kp, BatchPtrs io, in
                 nz |= (p[o] != 0.0) | (p[o + 1] != 0.0);
             }
         const unsigned long long m = __ballot(nz);
-        const int na = __popcll(m);
-        const int npad = kp.Nother - na;
-        Kf = na + (npad > 0 ? 1 : 0);
+        Kf = __popcll(m);
         if (nz) {
             const int idx = __popcll(m & ((1ull << lane) - 1ull));
-            ws[kp.ws_fm + idx] = 1.0;
             for (int k = 0; k < N; ++k) {
                 const int o = kp.c0 + lane * 3 * N + 3 * k;
                 ws[kp.ws_fxy + (idx * N + k) * 2] = p[o];
                 ws[kp.ws_fxy + (idx * N + k) * 2 + 1] = p[o + 1];
             }
         }
-        if (npad > 0) {
-            if (lane == 0) ws[kp.ws_fm + na] = (double)npad;
-            for (int k = lane; k < N; k += WAVE) {
-                ws[kp.ws_fxy + (na * N + k) * 2] = 0.0;
-                ws[kp.ws_fxy + (na * N + k) * 2 + 1] = 0.0;
-            }
-        }
+        if (lane == 0) ws[H_NPF] = (double)(kp.Nother - Kf);
     }
     // ---- dynamic obstacles: lane i checks row i
     int Kd;
+    bool varshape = false;
     __shared__ int s_entry[WAVE];  // original row -> entry (or -1 for padded rows)
     {
         bool nz = false;
-        if (lane < kp.Ndynobs)
-            for (int t = 0; t < 6 * N; ++t) nz |= (p[kp.od0 + lane * 6 * N + t] != 0.0);
+        if (lane < kp.Ndynobs) {
+            const double* q = p + kp.od0 + lane * 6 * N;
+            for (int t = 0; t < 6 * N; ++t) nz |= (q[t] != 0.0);
+            for (int k = 1; k < N; ++k)  // semi-axes and angle constant over the horizon?
+                varshape |= (q[6 * k + 2] != q[2]) | (q[6 * k + 3] != q[3]) | (q[6 * k + 4] != q[4]);
+        }
         const unsigned long long m = __ballot(nz);
-        const int na = __popcll(m);
-        const int npad = kp.Ndynobs - na;
-        Kd = na + (npad > 0 ? 1 : 0);
-        const int idx = nz ? __popcll(m & ((1ull << lane) - 1ull)) : na;  // padded rows share entry `na`
+        Kd = __popcll(m);
+        const int idx = nz ? __popcll(m & ((1ull << lane) - 1ull)) : -1;
         if (lane < kp.Ndynobs) {
             ws[H_ENTRY + lane] = (double)idx;
-            s_entry[lane] = nz ? idx : -1;
-            if (nz) ws[kp.ws_dm + idx] = 1.0;
+            s_entry[lane] = idx;
         }
-        if (npad > 0 && lane == 0) ws[kp.ws_dm + na] = (double)npad;
+        if (lane == 0) ws[H_NPD] = (double)(kp.Ndynobs - Kd);
         __syncthreads();
         // (row, step) items: sincos of the ellipse angle and the inverse squared semi-axes, once per solve
         for (int t = lane; t < kp.Ndynobs * N; t += WAVE) {
@@ -256,23 +299,14 @@ __global__ __launch_bounds__(WAVE) void prep_kernel(KParams kp, BatchPtrs io, in
             d[7] = 1.0 / ((ry + kp.social + 1e-6) * (ry + kp.social + 1e-6));
             d[8] = p[kp.qd0 + k] * q[5];  // q_dyn[k] * alpha
         }
-        if (npad > 0) {
-            for (int k = lane; k < N; k += WAVE) {
-                double* d = ws + kp.ws_dyn + (na * N + k) * DYNW;
-                d[0] = 0.0; d[1] = 0.0; d[2] = 1.0; d[3] = 0.0;
-                d[4] = 1.0 / ((0.0 + 1e-6) * (0.0 + 1e-6));
-                d[5] = d[4];
-                d[6] = 1.0 / ((kp.social + 1e-6) * (kp.social + 1e-6));
-                d[7] = d[6];
-                d[8] = 0.0;  // alpha = 0: the soft term of a padded row is exactly 0
-            }
-        }
     }
+    const bool any_var = __ballot(varshape) != 0ull;
     if (lane == 0) {
         ws[H_KS] = (double)Ks; ws[H_KF] = (double)Kf; ws[H_KD] = (double)Kd;
-        atomicMax(io.counts + 0, Ks);
-        atomicMax(io.counts + 1, Kf);
-        atomicMax(io.counts + 2, Kd);
+        atomicMax(io.counts + CNT_KS, Ks);
+        atomicMax(io.counts + CNT_KF, Kf);
+        atomicMax(io.counts + CNT_KD, Kd);
+        if (any_var) atomicMax(io.counts + CNT_VARSHAPE, 1);
     }
 }
 
@@ -283,23 +317,24 @@ struct Ctx {
     // uniform problem scalars
     double x0, y0, th0, cth0, sth0, xg, yg, thg, v_init, w_init;
     double qvel, rv, rw, qN, qthN, qrpd, acc_pen, wacc_pen;
+    double npf, npd;  // multiplicities of the zero-padded other-robot / dynamic-obstacle rows
     int Ks, Kf, Kd;
     // lane roles
     int lane, ik, isub;
     bool vl, il;
     double vref;  // vector lane k: speed reference of step k
     // LDS tables
-    double *seg, *stc, *fm, *fxy, *dm, *dyn, *pos, *H, *W, *part;
+    double *seg, *stc, *fxy, *dyn, *dync, *pos, *H, *W, *part;
 };
 
 struct EvalOut {
     double psi, f, nrm2F2;  // uniform
     double gv, gw;          // vector lanes: d psi / d (v_k, w_k)
     double F1a, F1b;        // vector lanes: acceleration mapping F1[k], F1[N+k]
-    double F2e;             // lane i < Kd: F2 value of dynamic entry i
+    double F2e, F2pad;      // lane i < Kd: F2 of dynamic entry i; uniform: F2 of every padded row
 };
 
-template <int NT>
+template <int NT, bool SC>
 __device__ __forceinline__ void load_problem(const KParams& kp, const double* __restrict__ ws, double* lds,
                                              Ctx& cx) {
     const int lane = threadIdx.x;
@@ -316,24 +351,58 @@ __device__ __forceinline__ void load_problem(const KParams& kp, const double* __
     cx.acc_pen = ws[16]; cx.wacc_pen = ws[17];
     cx.Ks = (int)ws[H_KS]; cx.Kf = (int)ws[H_KF]; cx.Kd = (int)ws[H_KD];
     cx.cth0 = ws[H_CTH0]; cx.sth0 = ws[H_STH0];
+    cx.npf = ws[H_NPF]; cx.npd = ws[H_NPD];
     cx.vref = cx.vl ? ws[kp.ws_vref + lane] : 0.0;
-    cx.seg = lds + kp.l_seg; cx.stc = lds + kp.l_stc; cx.fm = lds + kp.l_fm; cx.fxy = lds + kp.l_fxy;
-    cx.dm = lds + kp.l_dm; cx.dyn = lds + kp.l_dyn; cx.pos = lds + kp.l_pos; cx.H = lds + kp.l_H;
+    cx.seg = lds + kp.l_seg; cx.stc = lds + kp.l_stc; cx.fxy = lds + kp.l_fxy;
+    cx.dyn = lds + kp.l_dyn; cx.dync = lds + kp.l_dync; cx.pos = lds + kp.l_pos; cx.H = lds + kp.l_H;
     cx.W = lds + kp.l_W; cx.part = lds + kp.l_part;
     // coalesced table copies HBM -> LDS (only the active entries of this problem)
     for (int i = lane; i < N * SEGW; i += WAVE) cx.seg[i] = ws[kp.ws_seg + i];
     for (int i = lane; i < cx.Ks * STCW; i += WAVE) cx.stc[i] = ws[kp.ws_stc + i];
-    for (int i = lane; i < cx.Kf; i += WAVE) cx.fm[i] = ws[kp.ws_fm + i];
     for (int i = lane; i < cx.Kf * N * 2; i += WAVE) cx.fxy[i] = ws[kp.ws_fxy + i];
-    for (int i = lane; i < cx.Kd; i += WAVE) cx.dm[i] = ws[kp.ws_dm + i];
-    for (int i = lane; i < cx.Kd * N * DYNW; i += WAVE) cx.dyn[i] = ws[kp.ws_dyn + i];
-    __syncthreads();
+    if (SC) {
+        // shape-constant rows: per-row constants from the step-0 record, per-step (cx, cy, wgt)
+        for (int i = lane; i < cx.Kd * DYNC; i += WAVE) {
+            const int r = i / DYNC, f = i - r * DYNC;
+            cx.dync[i] = ws[kp.ws_dyn + (r * N) * DYNW + 2 + f];
+        }
+        for (int i = lane; i < cx.Kd * N; i += WAVE) {
+            const double* d = ws + kp.ws_dyn + i * DYNW;
+            cx.dyn[i * DYNP] = d[0]; cx.dyn[i * DYNP + 1] = d[1]; cx.dyn[i * DYNP + 2] = d[8];
+        }
+    } else {
+        for (int i = lane; i < cx.Kd * N * DYNW; i += WAVE) cx.dyn[i] = ws[kp.ws_dyn + i];
+    }
+    wave_sync();
+}
+
+// one dynamic-obstacle item: ellipse frame coordinates and inverse squared semi-axes
+struct DynItem {
+    double a, b, ca, sa, ihx, ihy, isx, isy, wgt;
+};
+template <bool SC>
+__device__ __forceinline__ DynItem dyn_item(const Ctx& cx, int i, int k, int N, double px, double py) {
+    DynItem d;
+    double ex, ey;
+    if (SC) {
+        const double* e = cx.dyn + (i * N + k) * DYNP;
+        const double* s = cx.dync + i * DYNC;
+        ex = px - e[0]; ey = py - e[1]; d.wgt = e[2];
+        d.ca = s[0]; d.sa = s[1]; d.ihx = s[2]; d.ihy = s[3]; d.isx = s[4]; d.isy = s[5];
+    } else {
+        const double* e = cx.dyn + (i * N + k) * DYNW;
+        ex = px - e[0]; ey = py - e[1];
+        d.ca = e[2]; d.sa = e[3]; d.ihx = e[4]; d.ihy = e[5]; d.isx = e[6]; d.isy = e[7]; d.wgt = e[8];
+    }
+    d.a = ex * d.ca + ey * d.sa;
+    d.b = ex * d.sa - ey * d.ca;
+    return d;
 }
 
 // ------------------------------------------------------------------------------------------------
 // psi(u; c, y), f(u), F1, F2 and (optionally) grad psi at the point held by the vector lanes.
 // ------------------------------------------------------------------------------------------------
-template <int NT>
+template <int NT, bool SC>
 __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, double v, double w, double c,
                                            double ya, double yb, bool want_grad, EvalOut& out) {
     const int N = NT ? NT : kp.N, LPS = NT ? Dim<NT>::LPS : kp.LPS, lane = cx.lane;
@@ -342,30 +411,50 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     const double inf = __builtin_huge_val();
     if (!cx.vl) { v = 0.0; w = 0.0; }
 
-    // ---- rollout: headings are a prefix sum of ts*w, positions a prefix sum of Simpson increments
-    const double tw = ts * w;
-    const double th1 = cx.th0 + scan_prefix<RV>(tw);  // theta_{k+1}
-    const double thm = th1 - 0.5 * tw;                      // theta_k + ts*w_k/2
-    double sm, cm, s2, c2;
-    sincos(thm, &sm, &cm);
-    sincos(th1, &s2, &c2);
-    const double c0 = shift_up1(c2, lane, cx.cth0), s0 = shift_up1(s2, lane, cx.sth0);
+    // ---- rollout.  Heading phasors e^{i theta}: theta_{k+1} = theta_k + ts*w_k, so they are a prefix PRODUCT of
+    //      unit complex numbers e^{i ts w_k} (DPP scan); positions are a prefix SUM of Simpson increments.
+    double c0, s0, cm, sm, c2, s2;
+    {
+        const double hd = 0.5 * ts * w;  // half-step heading increment
+        const bool small = __ballot(fabs(hd) > 0.78) == 0ull;
+        if (small) {
+            double sh, ch;
+            sincos_small(hd, sh, ch);
+            double er = ch * ch - sh * sh, ei = 2.0 * sh * ch;  // e^{i ts w_k}
+            scan_cprod<RV>(er, ei);                               // prod_{j<=k} e^{i ts w_j}
+            c2 = cx.cth0 * er - cx.sth0 * ei;                      // heading k+1
+            s2 = cx.cth0 * ei + cx.sth0 * er;
+            c0 = shift_up1(c2, lane, cx.cth0);
+            s0 = shift_up1(s2, lane, cx.sth0);
+            cm = c0 * ch - s0 * sh;
+            sm = c0 * sh + s0 * ch;
+        } else {  // a trial point far outside the input box: plain sincos of the summed angles
+            const double tw = ts * w;
+            const double th1 = cx.th0 + scan_prefix<RV>(tw);
+            sincos(th1 - 0.5 * tw, &sm, &cm);
+            sincos(th1, &s2, &c2);
+            c0 = shift_up1(c2, lane, cx.cth0);
+            s0 = shift_up1(s2, lane, cx.sth0);
+        }
+    }
     const double sixth = 1.0 / 6.0;
     const double Cx = (c0 + 4.0 * cm + c2) * sixth, Sy = (s0 + 4.0 * sm + s2) * sixth;
     const double dCw = -ts * (2.0 * sm + s2) * sixth, dSw = ts * (2.0 * cm + c2) * sixth;
     const double X = cx.x0 + scan_prefix<RV>(cx.vl ? ts * v * Cx : 0.0);
     const double Y = cx.y0 + scan_prefix<RV>(cx.vl ? ts * v * Sy : 0.0);
     if (cx.vl) { cx.pos[2 * lane] = X; cx.pos[2 * lane + 1] = Y; }
-    __syncthreads();
+    wave_sync();
 
     // ---- item phase A: stage terms of step ik handled by this lane
     double cost_l = 0.0, S_l = 0.0, gx = 0.0, gy = 0.0, dsx = 0.0, dsy = 0.0;
     double best = inf, bgx = 0.0, bgy = 0.0;
     double px = 0.0, py = 0.0;
+    bool anyh = false;
     if (cx.il) {
         const int k = cx.ik;
         px = cx.pos[2 * k]; py = cx.pos[2 * k + 1];
         // reference-path deviation: min over segments i >= k (mpc_generator.py:207,116-130,28-36)
+        MPC_ITEM_LOOP
         for (int i = k + cx.isub; i < N; i += LPS) {
             const double* sg = cx.seg + SEGW * i;
             const double s1x = sg[0], s1y = sg[1], dx = sg[2], dy = sg[3], inv = sg[4];
@@ -381,18 +470,18 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
             }
         }
         // fleet discs (mpc_generator.py:211-216,105-108)
+        MPC_ITEM_LOOP
         for (int j = cx.isub; j < cx.Kf; j += LPS) {
-            const double mult = cx.fm[j];
             const double ex = px - cx.fxy[(j * N + k) * 2], ey = py - cx.fxy[(j * N + k) * 2 + 1];
             const double hh = kp.W2 - (ex * ex + ey * ey);
             if (hh > 0.0) {
-                const double wj = kp.fleetw * mult;
-                cost_l += wj * hh;
-                gx -= 2.0 * wj * ex;
-                gy -= 2.0 * wj * ey;
+                cost_l += kp.fleetw * hh;
+                gx -= 2.0 * kp.fleetw * ex;
+                gy -= 2.0 * kp.fleetw * ey;
             }
         }
         // static polygons, 4 half-planes each (mpc_generator.py:219-225,46-54)
+        MPC_ITEM_LOOP
         for (int o = cx.isub; o < cx.Ks; o += LPS) {
             const double* s = cx.stc + STCW * o;
             const double m0 = fmax(0.0, s[0] - s[4] * px - s[8] * py);
@@ -411,58 +500,84 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
             }
         }
         // dynamic ellipses: hard indicator -> H, soft cost with social margin (mpc_generator.py:229-241,38-44,85-95)
+        MPC_ITEM_LOOP
         for (int i = cx.isub; i < cx.Kd; i += LPS) {
-            const double* e = cx.dyn + (i * N + k) * DYNW;
-            const double ex = px - e[0], ey = py - e[1], ca = e[2], sa = e[3];
-            const double a = ex * ca + ey * sa, bb = ex * sa - ey * ca;
-            const double a2 = a * a, b2 = bb * bb;
-            const double Ih = 1.0 - a2 * e[4] - b2 * e[5];
+            const DynItem d = dyn_item<SC>(cx, i, k, N, px, py);
+            const double a2 = d.a * d.a, b2 = d.b * d.b;
+            const double Ih = 1.0 - a2 * d.ihx - b2 * d.ihy;
+            anyh |= Ih > 0.0;
             cx.H[i * N + k] = Ih > 0.0 ? Ih : 0.0;
-            const double Is = 1.0 - a2 * e[6] - b2 * e[7];
+            const double Is = 1.0 - a2 * d.isx - b2 * d.isy;
             if (Is > 0.0) {
-                const double wgt = e[8] * cx.dm[i];
-                cost_l += wgt * Is * Is;
-                const double wI = 2.0 * wgt * Is;
-                gx += wI * (-2.0 * a * ca * e[6] - 2.0 * bb * sa * e[7]);
-                gy += wI * (-2.0 * a * sa * e[6] + 2.0 * bb * ca * e[7]);
+                cost_l += d.wgt * Is * Is;
+                const double wI = 2.0 * d.wgt * Is;
+                gx += wI * (-2.0 * d.a * d.ca * d.isx - 2.0 * d.b * d.sa * d.isy);
+                gy += wI * (-2.0 * d.a * d.sa * d.isx + 2.0 * d.b * d.ca * d.isy);
             }
         }
     }
-    __syncthreads();
+    // zero-padded rows, closed form on the vector lanes: npf discs of radius W and npd degenerate ellipses
+    // (semi-axes 1e-6, alpha = 0: hard indicator only) at the origin
+    double hp = 0.0, r2o = 0.0;
+    if (cx.vl) {
+        r2o = X * X + Y * Y;
+        if (cx.npf > 0.0) {
+            const double hh = kp.W2 - r2o;
+            if (hh > 0.0) cost_l += kp.fleetw * cx.npf * hh;  // its gradient is added on the vector lanes below
+        }
+        if (cx.npd > 0.0) {
+            const double ipad = 1.0 / ((0.0 + 1e-6) * (0.0 + 1e-6));
+            hp = fmax(0.0, 1.0 - X * X * ipad - Y * Y * ipad);
+        }
+    }
+    const bool any_hp = __ballot(hp > 0.0) != 0ull;
+    const bool any_h = __ballot(anyh) != 0ull;
+    wave_sync();
 
     // ---- constraint sums: S (static, broadcast into every F2 component), D_i (row sums of H)
     const double S = wave_sum_u<RI>(S_l);
-    double F2e = 0.0, mult_i = 0.0;
+    double F2e = 0.0;
     if (lane < cx.Kd) {
         double D = 0.0;
-        for (int k = 0; k < N; ++k) D += cx.H[lane * N + k];
-        mult_i = cx.dm[lane];
+        if (any_h)
+            for (int k = 0; k < N; ++k) D += cx.H[lane * N + k];
         F2e = S + D;
     }
-    const double nrm2F2 = wave_sum_u<2>(mult_i * F2e * F2e);
+    const double F2pad = cx.npd > 0.0 ? S + (any_hp ? wave_sum_u<RV>(hp) : 0.0) : 0.0;
+    double nrm2F2 = 0.0;
+    if (S > 0.0 || any_h || any_hp) nrm2F2 = wave_sum_u<2>(F2e * F2e) + cx.npd * F2pad * F2pad;
     out.F2e = F2e;
+    out.F2pad = F2pad;
     out.nrm2F2 = nrm2F2;
 
     // ---- item phase B (only when some penalty constraint is violated): weighted hard-constraint gradients
+    double Gpx = 0.0, Gpy = 0.0;  // vector lanes: gradient of the padded-row terms w.r.t. the position
     if (want_grad && nrm2F2 > 0.0) {
-        const double sumF2 = wave_sum_u<2>(mult_i * F2e);
-        if (lane < cx.Kd) cx.W[lane] = c * mult_i * F2e;
-        __syncthreads();
+        const double sumF2 = wave_sum_u<2>(F2e) + cx.npd * F2pad;
+        if (lane < cx.Kd) cx.W[lane] = c * F2e;
+        wave_sync();
         if (cx.il) {
             const int k = cx.ik;
-            for (int i = cx.isub; i < cx.Kd; i += LPS) {
-                const double* e = cx.dyn + (i * N + k) * DYNW;
-                const double ex = px - e[0], ey = py - e[1], ca = e[2], sa = e[3];
-                const double a = ex * ca + ey * sa, bb = ex * sa - ey * ca;
-                const double Ih = 1.0 - a * a * e[4] - bb * bb * e[5];
-                if (Ih > 0.0) {
-                    const double wi = cx.W[i];
-                    gx += wi * (-2.0 * a * ca * e[4] - 2.0 * bb * sa * e[5]);
-                    gy += wi * (-2.0 * a * sa * e[4] + 2.0 * bb * ca * e[5]);
+            if (any_h) {
+                MPC_ITEM_LOOP
+        for (int i = cx.isub; i < cx.Kd; i += LPS) {
+                    const DynItem d = dyn_item<SC>(cx, i, k, N, px, py);
+                    const double Ih = 1.0 - d.a * d.a * d.ihx - d.b * d.b * d.ihy;
+                    if (Ih > 0.0) {
+                        const double wi = cx.W[i];
+                        gx += wi * (-2.0 * d.a * d.ca * d.ihx - 2.0 * d.b * d.sa * d.ihy);
+                        gy += wi * (-2.0 * d.a * d.sa * d.ihx + 2.0 * d.b * d.ca * d.ihy);
+                    }
                 }
             }
             gx += c * sumF2 * dsx;
             gy += c * sumF2 * dsy;
+        }
+        if (any_hp && hp > 0.0) {  // a = X, b = -Y for the padded ellipse (cosA = 1, sinA = 0)
+            const double ipad = 1.0 / ((0.0 + 1e-6) * (0.0 + 1e-6));
+            const double wpad = c * cx.npd * F2pad;
+            Gpx = wpad * (-2.0 * X * ipad);
+            Gpy = wpad * (-2.0 * Y * ipad);
         }
     }
 
@@ -471,8 +586,8 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         double* pp = cx.part + (cx.isub * N + cx.ik) * PARTW;
         pp[0] = gx; pp[1] = gy; pp[2] = best; pp[3] = bgx; pp[4] = bgy;
     }
-    __syncthreads();
-    double Gx = 0.0, Gy = 0.0, vcost = 0.0;
+    wave_sync();
+    double Gx = Gpx, Gy = Gpy, vcost = 0.0;
     if (cx.vl) {
         double bb = inf, wbx = 0.0, wby = 0.0;
         for (int s = 0; s < LPS; ++s) {
@@ -480,11 +595,12 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
             Gx += pp[0]; Gy += pp[1];
             if (pp[2] < bb) { bb = pp[2]; wbx = pp[3]; wby = pp[4]; }
         }
-        // LPS lanes interleave segments; the reference's left fold keeps the lowest index on ties, which is
-        // what "<" over sub = 0.. gives for equal values only up to interleaving -- ties have equal gradients
-        // for end-to-end segments (shared vertex), see DESIGN.md.
         Gx += cx.qrpd * wbx; Gy += cx.qrpd * wby;
         vcost = cx.qrpd * bb;
+        if (cx.npf > 0.0 && kp.W2 - r2o > 0.0) {
+            Gx -= 2.0 * kp.fleetw * cx.npf * X;
+            Gy -= 2.0 * kp.fleetw * cx.npf * Y;
+        }
     }
 
     // ---- per-step terms on the vector lanes (mpc_generator.py:208-209,246,254-267)
@@ -500,12 +616,16 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     if (cx.vl) {
         const double dv = v - cx.vref;
         vcost += cx.qvel * dv * dv + cx.rv * v * v + cx.rw * w * w + cx.acc_pen * a * a + cx.wacc_pen * bacc * bacc;
+    }
+    if (cx.qN != 0.0 || cx.qthN != 0.0) {  // terminal cost (weights are 0 in the reference's yaml)
+        const double thN = cx.th0 + wave_sum_u<RV>(ts * w);
         if (lane == N - 1) {
-            const double ex = X - cx.xg, ey = Y - cx.yg, et = th1 - cx.thg;
+            const double ex = X - cx.xg, ey = Y - cx.yg, et = thN - cx.thg;
             vcost += cx.qN * (ex * ex + ey * ey) + cx.qthN * et * et;
             Gx += 2.0 * cx.qN * ex; Gy += 2.0 * cx.qN * ey;
             gthN = 2.0 * cx.qthN * et;
         }
+        gthN = readlane_d(gthN, N - 1);
     }
     const double f = wave_sum_u<RI>(cost_l + vcost);
     const double dist2 = wave_sum_u<RV>(cx.vl ? ea * ea + eb * eb : 0.0);
@@ -513,7 +633,6 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     out.psi = f + 0.5 * c * dist2 + 0.5 * c * nrm2F2;
 
     if (want_grad) {
-        gthN = readlane_d(gthN, N - 1);
         const double da = cx.vl ? (2.0 * cx.acc_pen * a + c * ea) * kp.inv_ts : 0.0;
         const double db = cx.vl ? (2.0 * cx.wacc_pen * bacc + c * eb) * kp.inv_ts : 0.0;
         const double da_n = shift_down1(da), db_n = shift_down1(db);
@@ -533,7 +652,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
 // ------------------------------------------------------------------------------------------------
 // test-hook kernel: one evaluation per problem through eval_point
 // ------------------------------------------------------------------------------------------------
-template <int NT>
+template <int NT, bool SC>
 __global__ __launch_bounds__(WAVE) void cost_grad_kernel(KParams kp, BatchPtrs io, const double* __restrict__ u,
                                                          const double* __restrict__ xi, double* psi, double* f,
                                                          double* grad, double* F1, double* F2, int B) {
@@ -543,14 +662,14 @@ __global__ __launch_bounds__(WAVE) void cost_grad_kernel(KParams kp, BatchPtrs i
     const int lane = threadIdx.x, N = NT ? NT : kp.N;
     const double* ws = io.ws + (size_t)b * kp.ws_stride;
     Ctx cx;
-    load_problem<NT>(kp, ws, lds, cx);
+    load_problem<NT, SC>(kp, ws, lds, cx);
     const double* ub = u + (size_t)b * 2 * N;
     const double* xb = xi + (size_t)b * (1 + 2 * N);
     const double v = cx.vl ? ub[2 * lane] : 0.0, w = cx.vl ? ub[2 * lane + 1] : 0.0;
     const double c = xb[0];
     const double ya = cx.vl ? xb[1 + lane] : 0.0, yb = cx.vl ? xb[1 + N + lane] : 0.0;
     EvalOut o;
-    eval_point<NT>(kp, cx, v, w, c, ya, yb, true, o);
+    eval_point<NT, SC>(kp, cx, v, w, c, ya, yb, true, o);
     if (lane == 0) {
         if (psi) psi[b] = o.psi;
         if (f) f[b] = o.f;
@@ -561,7 +680,8 @@ __global__ __launch_bounds__(WAVE) void cost_grad_kernel(KParams kp, BatchPtrs i
     }
     if (F2 && lane < kp.Ndynobs) {
         const int e = (int)ws[H_ENTRY + lane];
-        F2[(size_t)b * kp.Ndynobs + lane] = __shfl(o.F2e, e);  // test hook only: one LDS-crossbar gather
+        const double val = __shfl(o.F2e, e < 0 ? 0 : e);  // test hook only: one LDS-crossbar gather
+        F2[(size_t)b * kp.Ndynobs + lane] = e < 0 ? o.F2pad : val;
     }
 }
 
@@ -576,8 +696,11 @@ __device__ __forceinline__ double dot2r(double a0, double a1, double b0, double 
     return wave_sum_u<ROWS>(a0 * b0 + a1 * b1);
 }
 
-template <int NT>
-__global__ __launch_bounds__(WAVE) void solve_kernel(KParams kp, BatchPtrs io, int B) {
+#ifndef MPC_MIN_WAVES
+#define MPC_MIN_WAVES 2  // waves per SIMD the register allocator must leave room for (512 / MPC_MIN_WAVES VGPRs)
+#endif
+template <int NT, bool SC>
+__global__ __launch_bounds__(WAVE, MPC_MIN_WAVES) void solve_kernel(KParams kp, BatchPtrs io, int B) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int b = blockIdx.x;
     if (b >= B) return;
@@ -586,11 +709,12 @@ __global__ __launch_bounds__(WAVE) void solve_kernel(KParams kp, BatchPtrs io, i
     constexpr int RV = Dim<NT>::ROWS_V;
     const double* ws = io.ws + (size_t)b * kp.ws_stride;
     Ctx cx;
-    load_problem<NT>(kp, ws, lds, cx);
+    load_problem<NT, SC>(kp, ws, lds, cx);
     double* LS = lds + kp.l_S;      // [mem][N][2]
     double* LY = lds + kp.l_Y;      // [mem][N][2]
     double* LRHO = lds + kp.l_rho;  // [mem]
     double* LALPHA = lds + kp.l_alpha;
+    double* LOLD = lds + kp.l_old;  // [N][4]: L-BFGS old state (u) and old g (gamma*fpr)
     const bool vl = cx.vl;
 
     // PANOC constants [OpEn]
@@ -609,14 +733,10 @@ __global__ __launch_bounds__(WAVE) void solve_kernel(KParams kp, BatchPtrs io, i
     if (io.c0) { const double c0 = io.c0[b]; if (c0 > 0.0) c = c0; }
     c = uniform(c);
     ya = clampd(ya, -1e12, 1e12); yb = clampd(yb, -1e12, 1e12);  // y <- Proj_Y(y), Y = [-1e12, 1e12]^n1
-    double ypa = ya, ypb = yb;  // y_plus
-
-    // PANOC cache
-    double gv = 0, gw = 0, gpv = 0, gpw = 0, hv = 0, hw = 0 /*u_half*/, sv = 0, sw = 0 /*gradient step*/;
-    double rv_ = 0, rw_ = 0 /*gamma*fpr*/, dv = 0, dw = 0 /*direction*/, pv = 0, pw = 0 /*u_plus*/;
-    double osv = 0, osw = 0, ogv = 0, ogw = 0;  // L-BFGS old state / old g
-    double g0v = 0, g0w = 0;                    // gradient at u kept during the Lipschitz estimate
-    double gamma = 0, Lip = 0, sigma = 0, cost = 0, nfpr = 0, tau = 1, rhs = 0, nh = 1;
+    // PANOC cache: vector state u, grad, u_half, gamma*fpr, direction (2 doubles per vector lane each);
+    // ||grad||^2 and ||gradient_step - u_half||^2 are carried as scalars (they only enter the envelope)
+    double gv = 0, gw = 0, hv = 0, hw = 0, rv_ = 0, rw_ = 0, dv = 0, dw = 0;
+    double gamma = 0, Lip = 0, sigma = 0, cost = 0, nfpr = 0, tau = 1, rhs = 0, nh = 1, gg = 0, d2h = 0;
     double akkt_tol = kp.init_tol;
     int iter = 0, num_iter = 0, lip_it = 0, nls = 0;
     bool cont_iters = true, cont_time = true;
@@ -632,25 +752,34 @@ __global__ __launch_bounds__(WAVE) void solve_kernel(KParams kp, BatchPtrs io, i
     bool want_grad = true;
     EvalOut o;
 
+    // u_half <- Proj_U(base - gamma*grad); returns ||gradient_step - u_half||^2
+    auto half_step = [&](double bv, double bw) -> double {
+        const double sv = bv - gamma * gv, sw = bw - gamma * gw;
+        hv = vl ? clampd(sv, kp.vmin, kp.vmax) : 0.0;
+        hw = vl ? clampd(sw, -kp.wmax, kp.wmax) : 0.0;
+        const double e0 = vl ? sv - hv : 0.0, e1 = vl ? sw - hw : 0.0;
+        return dot2r<RV>(e0, e1, e0, e1);
+    };
+
     for (;;) {
-        eval_point<NT>(kp, cx, ev, ew, c, ya, yb, want_grad, o);
+        eval_point<NT, SC>(kp, cx, ev, ew, c, ya, yb, want_grad, o);
         bool step_begin = false;
 
         if (state == ST_INIT0) {
             // cost + gradient at u; perturbation for the local Lipschitz estimate: h_i = max(delta, eps*u_i)
-            cost = o.psi; gv = o.gv; gw = o.gw; g0v = gv; g0w = gw;
+            cost = uniform(o.psi); gv = o.gv; gw = o.gw;
             const double h0 = vl ? ((EPS_LIP * uv > DELTA_LIP) ? EPS_LIP * uv : DELTA_LIP) : 0.0;
             const double h1 = vl ? ((EPS_LIP * uw > DELTA_LIP) ? EPS_LIP * uw : DELTA_LIP) : 0.0;
-            nh = sqrt(dot2r<RV>(h0, h1, h0, h1));
+            nh = uniform(sqrt(dot2r<RV>(h0, h1, h0, h1)));
             ev = uv + h0; ew = uw + h1; want_grad = true; state = ST_INIT1;
             continue;
         } else if (state == ST_INIT1) {
-            const double d0 = o.gv - g0v, d1 = o.gw - g0w;
-            Lip = sqrt(dot2r<RV>(d0, d1, d0, d1)) / nh;
-            gamma = GAMMA_L_COEFF / fmax(Lip, MIN_L);
-            sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * gamma);
-            sv = uv - gamma * gv; sw = uw - gamma * gw;
-            hv = vl ? clampd(sv, kp.vmin, kp.vmax) : 0.0; hw = vl ? clampd(sw, -kp.wmax, kp.wmax) : 0.0;
+            const double d0 = o.gv - gv, d1 = o.gw - gw;
+            Lip = uniform(sqrt(dot2r<RV>(d0, d1, d0, d1)) / nh);
+            gamma = uniform(GAMMA_L_COEFF / fmax(Lip, MIN_L));
+            sigma = uniform((1.0 - GAMMA_L_COEFF) / (4.0 * gamma));
+            gg = dot2r<RV>(gv, gw, gv, gw);
+            d2h = half_step(uv, uw);
             step_begin = true;
         } else if (state == ST_LIP) {
             const double cost_half = o.psi;
@@ -658,36 +787,39 @@ __global__ __launch_bounds__(WAVE) void solve_kernel(KParams kp, BatchPtrs io, i
             const double rhs_lip = cost + LIP_UPD_EPS * fabs(cost) - ip + (GAMMA_L_COEFF / (2.0 * gamma)) * nfpr * nfpr;
             if (cost_half > rhs_lip && lip_it < MAX_LIP_IT && Lip < MAX_LIP) {
                 lb_active = 0; lb_first = true;  // invalidate the L-BFGS buffer
-                Lip *= 2.0; gamma *= 0.5;
-                sv = uv - gamma * gv; sw = uw - gamma * gw;
-                hv = vl ? clampd(sv, kp.vmin, kp.vmax) : 0.0; hw = vl ? clampd(sw, -kp.wmax, kp.wmax) : 0.0;
+                Lip = uniform(Lip * 2.0); gamma = uniform(gamma * 0.5);
+                d2h = half_step(uv, uw);
                 rv_ = uv - hv; rw_ = uw - hw;
-                nfpr = sqrt(dot2r<RV>(rv_, rw_, rv_, rw_));
+                nfpr = uniform(sqrt(dot2r<RV>(rv_, rw_, rv_, rw_)));
                 ++lip_it;
                 ev = hv; ew = hw; want_grad = false;
                 continue;
             }
-            sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * gamma);
+            sigma = uniform((1.0 - GAMMA_L_COEFF) / (4.0 * gamma));
             // ---- L-BFGS buffer update with (state = u, g = gamma*fpr)   [crate lbfgs: C-BFGS acceptance]
             if (lb_first) {
                 lb_first = false;
-                osv = uv; osw = uw; ogv = rv_; ogw = rw_;
+                if (vl) { LOLD[lane * 4] = uv; LOLD[lane * 4 + 1] = uw; LOLD[lane * 4 + 2] = rv_; LOLD[lane * 4 + 3] = rw_; }
             } else {
-                const double s0 = uv - osv, s1 = uw - osw, y0_ = rv_ - ogv, y1_ = rw_ - ogw;
+                double s0 = 0, s1 = 0, y0_ = 0, y1_ = 0;
+                if (vl) {
+                    s0 = uv - LOLD[lane * 4]; s1 = uw - LOLD[lane * 4 + 1];
+                    y0_ = rv_ - LOLD[lane * 4 + 2]; y1_ = rw_ - LOLD[lane * 4 + 3];
+                }
                 const double ys = dot2r<RV>(s0, s1, y0_, y1_), ss = dot2r<RV>(s0, s1, s0, s1);
                 if (!(ss <= DBLMIN || ys <= 1e-10) && (ys / ss > 1e-8 * nfpr)) {
-                    osv = uv; osw = uw; ogv = rv_; ogw = rw_;
                     lb_head = (lb_head + mem - 1) % mem;
                     if (vl) {
+                        LOLD[lane * 4] = uv; LOLD[lane * 4 + 1] = uw; LOLD[lane * 4 + 2] = rv_; LOLD[lane * 4 + 3] = rw_;
                         LS[(lb_head * N + lane) * 2] = s0; LS[(lb_head * N + lane) * 2 + 1] = s1;
                         LY[(lb_head * N + lane) * 2] = y0_; LY[(lb_head * N + lane) * 2 + 1] = y1_;
                     }
                     if (lane == 0) LRHO[lb_head] = 1.0 / ys;
-                    lb_gamma = ys / dot2r<RV>(y0_, y1_, y0_, y1_);
+                    lb_gamma = uniform(ys / dot2r<RV>(y0_, y1_, y0_, y1_));
                     lb_active = (lb_active + 1 < mem) ? lb_active + 1 : mem;
-                    __syncthreads();
                 }
             }
+            wave_sync();
             if (iter == 0) {
                 // first iteration: no line search, u <- u_half
                 uv = hv; uw = hw;
@@ -703,7 +835,7 @@ __global__ __launch_bounds__(WAVE) void solve_kernel(KParams kp, BatchPtrs io, i
                 if (lane == 0) LALPHA[j] = al;
                 if (vl) { q0 -= al * LY[(sl * N + lane) * 2]; q1 -= al * LY[(sl * N + lane) * 2 + 1]; }
             }
-            __syncthreads();
+            wave_sync();
             if (lb_active > 0) { q0 *= lb_gamma; q1 *= lb_gamma; }
             for (int j = lb_active - 1; j >= 0; --j) {
                 const int sl = (lb_head + j) % mem;
@@ -714,73 +846,74 @@ __global__ __launch_bounds__(WAVE) void solve_kernel(KParams kp, BatchPtrs io, i
             }
             dv = q0; dw = q1;
             // ---- line search on the forward-backward envelope
-            {
-                const double gg = dot2r<RV>(gv, gw, gv, gw);
-                const double e0 = sv - hv, e1 = sw - hw;
-                const double d2 = dot2r<RV>(e0, e1, e0, e1);
-                const double fbe = cost - 0.5 * gamma * gg + 0.5 * d2 / gamma;
-                rhs = fbe - sigma * nfpr * nfpr;
-            }
+            rhs = uniform((cost - 0.5 * gamma * gg + 0.5 * d2h / gamma) - sigma * nfpr * nfpr);
             tau = 1.0; nls = 0;
-            pv = uv - (1.0 - tau) * rv_ - tau * dv; pw = uw - (1.0 - tau) * rw_ - tau * dw;
-            ev = pv; ew = pw; want_grad = true; state = ST_LS;
+            ev = uv - (1.0 - tau) * rv_ - tau * dv; ew = uw - (1.0 - tau) * rw_ - tau * dw;  // u_plus
+            want_grad = true; state = ST_LS;
             continue;
         } else if (state == ST_NOLS) {
-            cost = o.psi; gv = o.gv; gw = o.gw;
-            sv = uv - gamma * gv; sw = uw - gamma * gw;
-            hv = vl ? clampd(sv, kp.vmin, kp.vmax) : 0.0; hw = vl ? clampd(sw, -kp.wmax, kp.wmax) : 0.0;
+            cost = uniform(o.psi); gv = o.gv; gw = o.gw;
+            gg = dot2r<RV>(gv, gw, gv, gw);
+            d2h = half_step(uv, uw);
             ++iter;
             step_begin = true;
         } else if (state == ST_LS) {
-            cost = o.psi; gv = o.gv; gw = o.gw;
-            sv = pv - gamma * gv; sw = pw - gamma * gw;
-            hv = vl ? clampd(sv, kp.vmin, kp.vmax) : 0.0; hw = vl ? clampd(sw, -kp.wmax, kp.wmax) : 0.0;
-            const double gg = dot2r<RV>(gv, gw, gv, gw);
-            const double e0 = sv - hv, e1 = sw - hw;
-            const double d2 = dot2r<RV>(e0, e1, e0, e1);
-            const double lhs = cost - 0.5 * gamma * gg + 0.5 * d2 / gamma;
+            // (ev, ew) is the trial point u_plus
+            cost = uniform(o.psi); gv = o.gv; gw = o.gw;
+            gg = dot2r<RV>(gv, gw, gv, gw);
+            d2h = half_step(ev, ew);
+            const double lhs = cost - 0.5 * gamma * gg + 0.5 * d2h / gamma;
             if (lhs > rhs && nls < MAX_LS_IT) {
-                tau *= 0.5; ++nls;
-                pv = uv - (1.0 - tau) * rv_ - tau * dv; pw = uw - (1.0 - tau) * rw_ - tau * dw;
-                ev = pv; ew = pw; want_grad = true;
+                tau = uniform(tau * 0.5); ++nls;
+                ev = uv - (1.0 - tau) * rv_ - tau * dv; ew = uw - (1.0 - tau) * rw_ - tau * dw;
+                want_grad = true;
                 continue;
             }
-            uv = pv; uw = pw;  // after MAX_LS_IT halvings the last trial point is kept
+            uv = ev; uw = ew;  // after MAX_LS_IT halvings the last trial point is kept
             ++iter;
             step_begin = true;
         } else {  // ST_OUTER: evaluated at the inner solution (c, y still those of the inner problem)
             inner_total += num_iter;
             last_fpr = nfpr;
-            f_final = o.f;
+            f_final = uniform(o.f);
             // y+ <- y + c (F1(u) - Proj_C(F1(u) + y/c))
-            double dy2l = 0.0;
+            double dy2l = 0.0, ypa = 0.0, ypb = 0.0;
             if (vl) {
                 const double za = o.F1a + ya / c, zb = o.F1b + yb / c;
                 ypa = ya + c * (o.F1a - clampd(za, kp.amin, kp.amax));
                 ypb = yb + c * (o.F1b - clampd(zb, -kp.aamax, kp.aamax));
                 dy2l = (ypa - ya) * (ypa - ya) + (ypb - yb) * (ypb - yb);
             }
-            dy_norm_plus = sqrt(wave_sum_u<RV>(dy2l));
-            f2_norm_plus = sqrt(o.nrm2F2);
+            dy_norm_plus = uniform(sqrt(wave_sum_u<RV>(dy2l)));
+            f2_norm_plus = uniform(sqrt(o.nrm2F2));
             const bool crit1 = alm_iteration > 0 && dy_norm_plus <= c * kp.delta_tol + SMALL_EPS;
             const bool crit2 = f2_norm_plus <= kp.delta_tol + SMALL_EPS;
             const bool crit3 = akkt_tol <= kp.tol + SMALL_EPS;
+            bool done = false;
             // converged: status = status of the last inner problem; the outer-iteration cap overrides it
             if ((crit1 && crit2 && crit3) || num_outer == kp.max_outer) {
                 if (num_outer == kp.max_outer) status = 1;
+                done = true;
+            } else if (kp.max_ticks > 0 && wall_clock64() - t_start > kp.max_ticks) {
+                status = 2;
+                done = true;
+            }
+            if (done) {
+                if (vl && io.y_out) {
+                    io.y_out[(size_t)b * 2 * N + lane] = ypa;
+                    io.y_out[(size_t)b * 2 * N + N + lane] = ypb;
+                }
                 break;
             }
-            if (kp.max_ticks > 0 && wall_clock64() - t_start > kp.max_ticks) { status = 2; break; }
             const bool stall = alm_iteration == 0 || (dy_norm_plus <= kp.suff_decrease * dy_norm + SMALL_EPS &&
                                                       f2_norm_plus <= kp.suff_decrease * f2_norm + SMALL_EPS);
-            if (!stall) c *= kp.penalty_update;
-            akkt_tol = fmax(akkt_tol * kp.tol_update, kp.tol);
+            if (!stall) c = uniform(c * kp.penalty_update);
+            akkt_tol = uniform(fmax(akkt_tol * kp.tol_update, kp.tol));
             ++alm_iteration; ++num_outer;
             dy_norm = dy_norm_plus; f2_norm = f2_norm_plus;
             ya = fmin(fmax(ypa, -1e12), 1e12); yb = fmin(fmax(ypb, -1e12), 1e12);  // y <- Proj_Y(y+)
             // reset the PANOC cache for the next inner problem
             lb_active = 0; lb_first = true; tau = 1.0; Lip = 0; sigma = 0; gamma = 0; iter = 0;
-            gpv = 0; gpw = 0;
             num_iter = 0; cont_iters = true; cont_time = true;
             ev = uv; ew = uw; want_grad = true; state = ST_INIT0;
             continue;
@@ -798,12 +931,13 @@ __global__ __launch_bounds__(WAVE) void solve_kernel(KParams kp, BatchPtrs io, i
                 }
             }
             if (!inner_done) {
-                if (iter >= 1) { gpv = gv; gpw = gw; }
                 rv_ = uv - hv; rw_ = uw - hw;
-                nfpr = sqrt(dot2r<RV>(rv_, rw_, rv_, rw_));
+                nfpr = uniform(sqrt(dot2r<RV>(rv_, rw_, rv_, rw_)));
                 bool ex = nfpr < kp.tol;
-                if (ex) {  // AKKT residual || gfpr/gamma + grad - grad_prev || < eps_nu
-                    const double a0 = rv_ / gamma + gv - gpv, a1 = rw_ / gamma + gw - gpw;
+                if (ex) {
+                    // AKKT residual || gfpr/gamma + grad - grad_prev || < eps_nu.  grad_prev is the zero vector
+                    // on the first step of an inner problem and the current gradient afterwards.
+                    const double a0 = rv_ / gamma + (iter == 0 ? gv : 0.0), a1 = rw_ / gamma + (iter == 0 ? gw : 0.0);
                     ex = sqrt(dot2r<RV>(a0, a1, a0, a1)) < akkt_tol;
                 }
                 if (ex) {
@@ -825,7 +959,6 @@ __global__ __launch_bounds__(WAVE) void solve_kernel(KParams kp, BatchPtrs io, i
     if (vl) {
         io.u[(size_t)b * 2 * N + 2 * lane] = uv;
         io.u[(size_t)b * 2 * N + 2 * lane + 1] = uw;
-        if (io.y_out) { io.y_out[(size_t)b * 2 * N + lane] = ypa; io.y_out[(size_t)b * 2 * N + N + lane] = ypb; }
     }
     if (lane == 0) {
         io.cost[b] = f_final;

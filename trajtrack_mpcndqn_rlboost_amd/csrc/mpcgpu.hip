@@ -36,6 +36,7 @@ struct Handle {
     DevBuf ws, counts, p, u0, y0, c0, u, cost, status, inner, outer, fpr, f2, y, ms, xi, psi, f, grad, F1, F2;
     int* h_counts = nullptr;  // pinned
     int last_shape[4] = {0, 0, 0, 0};
+    bool shape_const = true;  // of the batch prepared last
 };
 
 int fail(Handle* h, int code, const char* fmt, ...) {
@@ -93,32 +94,39 @@ void fill_static_params(Handle* h) {
     k.ws_vref = o; o += even(N);
     k.ws_seg = o; o += N * SEGW;
     k.ws_stc = o; o += c.Nstcobs * STCW;
-    k.ws_fm = o; o += even(c.Nother);
     k.ws_fxy = o; o += c.Nother * N * 2;
-    k.ws_dm = o; o += even(c.Ndynobs);
     k.ws_dyn = o; o += even(c.Ndynobs * N * DYNW);
     k.ws_stride = (o + 15) & ~15;
 }
 
-// LDS carve for the batch maxima (doubles; every offset even => 16-byte aligned)
-void fill_lds_layout(KParams& k, int mKs, int mKf, int mKd) {
+// LDS carve for the batch maxima (doubles; every offset even => 16-byte aligned).
+// shape_const: every active dynamic row of the batch keeps (rx, ry, angle) over the horizon -> 3 doubles per
+// (row, step) + 6 per row instead of 9 per (row, step).
+void fill_lds_layout(KParams& k, int mKs, int mKf, int mKd, bool shape_const) {
     const int N = k.N;
     k.mKs = mKs; k.mKf = mKf; k.mKd = mKd;
     int o = 0;
     k.l_seg = o; o += N * SEGW;
     k.l_stc = o; o += mKs * STCW;
-    k.l_fm = o; o += even(mKf);
     k.l_fxy = o; o += mKf * N * 2;
-    k.l_dm = o; o += even(mKd);
-    k.l_dyn = o; o += even(mKd * N * DYNW);
+    if (shape_const) {
+        k.l_dyn = o; o += even(mKd * N * DYNP);
+        k.l_dync = o; o += even(mKd * DYNC);
+    } else {
+        k.l_dyn = o; o += even(mKd * N * DYNW);
+        k.l_dync = k.l_dyn;
+    }
     k.l_pos = o; o += N * 2;
-    k.l_H = o; o += even(mKd * N);
-    k.l_W = o; o += even(mKd);
-    k.l_part = o; o += even(k.LPS * N * PARTW);
+    // H (hinge matrix, read right after it is written) and the item-lane partials are never live together:
+    // LDS operations of the single wave execute in order, so they share one region
+    const int h_sz = even(mKd * N) + even(mKd), part_sz = even(k.LPS * N * PARTW);
+    k.l_H = o; k.l_W = o + even(mKd * N); k.l_part = o;
+    o += h_sz > part_sz ? h_sz : part_sz;
     k.l_S = o; o += k.mem * N * 2;
     k.l_Y = o; o += k.mem * N * 2;
     k.l_rho = o; o += even(k.mem);
     k.l_alpha = o; o += even(k.mem);
+    k.l_old = o; o += N * 4;
     k.l_total = o;
 }
 
@@ -134,10 +142,11 @@ int prepare(Handle* h, int B, const double* d_p, hipStream_t s, BatchPtrs& io) {
     hipLaunchKernelGGL(prep_kernel, dim3(B), dim3(WAVE), 0, s, h->kp, io, B);
     HIP_OK(h, hipGetLastError());
     HIP_OK(h, hipEventRecord(h->ev[1], s));
-    HIP_OK(h, hipMemcpyAsync(h->h_counts, io.counts, 3 * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_OK(h, hipMemcpyAsync(h->h_counts, io.counts, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_OK(h, hipStreamSynchronize(s));
-    const int mKs = h->h_counts[0], mKf = h->h_counts[1], mKd = h->h_counts[2];
-    fill_lds_layout(h->kp, mKs, mKf, mKd);
+    const int mKs = h->h_counts[CNT_KS], mKf = h->h_counts[CNT_KF], mKd = h->h_counts[CNT_KD];
+    h->shape_const = h->h_counts[CNT_VARSHAPE] == 0;
+    fill_lds_layout(h->kp, mKs, mKf, mKd, h->shape_const);
     const int lds_bytes = h->kp.l_total * (int)sizeof(double);
     h->last_shape[0] = mKs; h->last_shape[1] = mKf; h->last_shape[2] = mKd; h->last_shape[3] = lds_bytes;
     if (lds_bytes > 160 * 1024) return fail(h, -5, "LDS carve of %d bytes exceeds 160 KiB", lds_bytes);
@@ -244,11 +253,23 @@ int32_t mpcgpu_solve_batch_dev(void* handle, int32_t B, const double* p, const d
     io.outer_it = outer_it; io.fpr = fpr; io.f2norm = f2norm; io.y_out = y_out; io.ms = ms;
     HIP_OK(h, hipEventRecord(h->ev[2], s));
     const size_t lds = h->kp.l_total * sizeof(double);
-    switch (h->kp.N) {  // compile-time horizons for the configurations the reference uses; generic otherwise
-        case 20: hipLaunchKernelGGL(solve_kernel<20>, dim3(B), dim3(WAVE), lds, s, h->kp, io, B); break;
-        case 40: hipLaunchKernelGGL(solve_kernel<40>, dim3(B), dim3(WAVE), lds, s, h->kp, io, B); break;
-        default: hipLaunchKernelGGL(solve_kernel<0>, dim3(B), dim3(WAVE), lds, s, h->kp, io, B); break;
+    // compile-time horizons for the configurations the reference uses (generic kernel otherwise) x
+    // {shape-constant, general} dynamic-obstacle tables
+#define LAUNCH_SOLVE(NT, SC) hipLaunchKernelGGL((solve_kernel<NT, SC>), dim3(B), dim3(WAVE), lds, s, h->kp, io, B)
+    if (h->shape_const) {
+        switch (h->kp.N) {
+            case 20: LAUNCH_SOLVE(20, true); break;
+            case 40: LAUNCH_SOLVE(40, true); break;
+            default: LAUNCH_SOLVE(0, true); break;
+        }
+    } else {
+        switch (h->kp.N) {
+            case 20: LAUNCH_SOLVE(20, false); break;
+            case 40: LAUNCH_SOLVE(40, false); break;
+            default: LAUNCH_SOLVE(0, false); break;
+        }
     }
+#undef LAUNCH_SOLVE
     HIP_OK(h, hipGetLastError());
     HIP_OK(h, hipEventRecord(h->ev[3], s));
     h->timing_valid = true;
@@ -322,14 +343,22 @@ int32_t mpcgpu_cost_grad_batch(void* handle, int32_t B, const double* u, const d
     HIP_OK(h, hipMemcpyAsync(h->xi.ptr, xi, Bz * (n + 1) * 8, hipMemcpyHostToDevice, s));
     BatchPtrs io{};
     if (int r = prepare(h, B, (const double*)h->p.ptr, s, io)) return r;
-#define LAUNCH_CG(NT)                                                                                          \
-    hipLaunchKernelGGL(cost_grad_kernel<NT>, dim3(B), dim3(WAVE), h->kp.l_total * sizeof(double), s, h->kp, io,  \
-                       (const double*)h->u.ptr, (const double*)h->xi.ptr, (double*)h->psi.ptr, (double*)h->f.ptr, \
-                       (double*)h->grad.ptr, (double*)h->F1.ptr, (double*)h->F2.ptr, B)
-    switch (h->kp.N) {
-        case 20: LAUNCH_CG(20); break;
-        case 40: LAUNCH_CG(40); break;
-        default: LAUNCH_CG(0); break;
+#define LAUNCH_CG(NT, SC)                                                                                      \
+    hipLaunchKernelGGL((cost_grad_kernel<NT, SC>), dim3(B), dim3(WAVE), h->kp.l_total * sizeof(double), s,       \
+                       h->kp, io, (const double*)h->u.ptr, (const double*)h->xi.ptr, (double*)h->psi.ptr,        \
+                       (double*)h->f.ptr, (double*)h->grad.ptr, (double*)h->F1.ptr, (double*)h->F2.ptr, B)
+    if (h->shape_const) {
+        switch (h->kp.N) {
+            case 20: LAUNCH_CG(20, true); break;
+            case 40: LAUNCH_CG(40, true); break;
+            default: LAUNCH_CG(0, true); break;
+        }
+    } else {
+        switch (h->kp.N) {
+            case 20: LAUNCH_CG(20, false); break;
+            case 40: LAUNCH_CG(40, false); break;
+            default: LAUNCH_CG(0, false); break;
+        }
     }
 #undef LAUNCH_CG
     HIP_OK(h, hipGetLastError());
