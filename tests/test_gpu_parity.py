@@ -308,6 +308,22 @@ def test_plugin_contract(cfg20):
     assert s.run(sc["p"][0].tolist(), [0.0] * 3) is None
 
 
+def test_drop_in_module_is_importable_the_way_the_reference_loads_it(cfg20):
+    """trajectory_generator.py:63-71: sys.path.append(<build_directory>/<optimizer_name>); __import__(name).solver()"""
+    import importlib, os, sys
+    from conftest import ROOT
+    path = os.path.join(ROOT, cfg20.build_directory, cfg20.optimizer_name)
+    sys.path.append(path)
+    try:
+        built_solver = importlib.import_module(cfg20.optimizer_name)
+        s = built_solver.solver()
+        sc = scenes.make_batch(cfg20, 1, n_dyn=1, with_box=False, seed=92, v_init_range=(1.0, 1.2))
+        sol = s.run(sc["p"][0].tolist(), None)
+        assert len(sol.solution) == 2 * cfg20.N_hor and sol.exit_status in ("Converged", "NotConvergedIterations")
+    finally:
+        sys.path.remove(path)
+
+
 def test_device_pointer_entry_point(solver20, cfg20):
     import torch
     sc = scenes.make_batch(cfg20, 64, n_dyn=4, seed=95)
