@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Phase-cycle breakdown of the solver kernel (needs a -DMPC_PROFILE build: MPCGPU_LIB=<that .so>)."""
+import ctypes as C, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from trajtrack_mpcndqn_rlboost_amd import MpcConfig, BatchSolver, scenes
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+cfg = MpcConfig()
+bs = BatchSolver(cfg)
+sc = scenes.make_batch(cfg, B, n_dyn=8, seed=1236)
+res = bs.solve(sc["p"])
+out = (C.c_double * 24)()
+bs._L.mpcgpu_debug_read_prof.argtypes = [C.POINTER(C.c_double)]
+bs._L.mpcgpu_debug_read_prof(out)
+res = bs.solve(sc["p"])
+bs._L.mpcgpu_debug_read_prof(out)
+t = np.array(out[:])
+names = ["headings", "positions+publish", "segments", "fleet+static", "dynamic", "pads+constraint sums", "phase B",
+         "combine", "vector terms+psi", "adjoint"]
+states = ["INIT0", "INIT1", "LIP", "NOLS", "LS", "OUTER"]
+evals = t[16:22].sum()
+tot = t[:16].sum() + t[22]
+print(f"solve_ms {bs.last_timing()['solve_ms']:.1f}  evals/solve {evals / B:.0f}  cycles/solve {tot / B:.3g}  cycles/eval(all incl.) {tot / evals:.0f}")
+for i, n in enumerate(names):
+    print(f"  eval: {n:22s} {t[i] / evals:8.0f} cyc/eval  {100 * t[i] / tot:5.1f} %")
+for i, n in enumerate(states):
+    c = t[16 + i]
+    print(f"  logic before {n:6s} evals {c / B:8.0f}/solve  {t[10 + i] / max(c, 1):8.0f} cyc each  {100 * t[10 + i] / tot:5.1f} %")

@@ -23,15 +23,41 @@
 
 namespace mpcgpu {
 
+// Optional phase profiler (build with -DMPC_PROFILE; never in the shipped library): shader-clock cycles per
+// phase, accumulated per wavefront and added to a device-global table at the end of the solve.
+#ifdef MPC_PROFILE
+constexpr int NPROF = 24;
+__device__ unsigned long long g_prof[NPROF];
+struct Prof {
+    long long t[NPROF];
+    long long last;
+    __device__ void start() { for (int i = 0; i < NPROF; ++i) t[i] = 0; last = __builtin_readcyclecounter(); }
+    __device__ void mark(int i) { const long long n = __builtin_readcyclecounter(); t[i] += n - last; last = n; }
+    __device__ void count(int i) { t[i] += 1; }
+    __device__ void flush() { if (threadIdx.x == 0) for (int i = 0; i < NPROF; ++i) atomicAdd(&g_prof[i], (unsigned long long)t[i]); }
+};
+#define PROF_ARG , Prof& prof
+#define PROF_PASS , prof
+#define PROF_MARK(i) prof.mark(i)
+#define PROF_COUNT(i) prof.count(i)
+#else
+#define PROF_ARG
+#define PROF_PASS
+#define PROF_MARK(i)
+#define PROF_COUNT(i)
+#endif
+
 constexpr int WAVE = 64;
 constexpr int HDR = 64;        // header doubles per problem in the workspace
-constexpr int SEGW = 6;        // doubles per reference segment  (s1x, s1y, dx, dy, 1/(|d|^2+1e-16), pad)
+constexpr int SEGW = 12;       // doubles per reference segment: s1x, s1y, dx, dy, 1/(|d|^2+1e-16), midx, midy, half length,
+                               // then the bounding circle (cx, cy, R, -) of ALL segments from this one to the last
 constexpr int STCW = 12;       // doubles per static obstacle    (b[4], a0[4], a1[4])
 constexpr int DYNW = 9;        // workspace record per (dyn row, step): cx, cy, cosA, sinA, ihx, ihy, isx, isy, wgt
 constexpr int DYNP = 3;        // shape-constant LDS record per (row, step): cx, cy, wgt
 constexpr int DYNC = 6;        // shape-constant LDS record per row: cosA, sinA, ihx, ihy, isx, isy
 constexpr int PARTW = 5;       // doubles per item-lane partial  (gx, gy, best, bgx, bgy)
 constexpr int MAX_MEM = 16;
+constexpr int SEG_WIN = 2;     // reference segments per item lane that are evaluated unconditionally
 
 // header slots (doubles)
 enum { H_KS = 18, H_KF = 19, H_KD = 20, H_CTH0 = 21, H_STH0 = 22, H_NPF = 23, H_NPD = 24, H_ENTRY = 26 /* .. +Ndynobs */ };
@@ -224,7 +250,21 @@ __global__ __launch_bounds__(WAVE) void prep_kernel(KParams kp, BatchPtrs io, in
         double* sg = ws + kp.ws_seg + SEGW * i;
         sg[0] = s1x; sg[1] = s1y; sg[2] = dx; sg[3] = dy;
         sg[4] = 1.0 / (dx * dx + dy * dy + 1e-16);
-        sg[5] = 0.0;
+        sg[5] = s1x + 0.5 * dx; sg[6] = s1y + 0.5 * dy;
+        sg[7] = 0.5 * sqrt(dx * dx + dy * dy) * (1.0 + 1e-12);
+        // bounding circle of the reference points i..N-1 (every remaining segment lies inside it)
+        double xlo = s1x, xhi = s1x, ylo = s1y, yhi = s1y;
+        for (int j = i + 1; j < N; ++j) {
+            const double qx = p[kp.r0 + 3 * j], qy = p[kp.r0 + 3 * j + 1];
+            xlo = fmin(xlo, qx); xhi = fmax(xhi, qx); ylo = fmin(ylo, qy); yhi = fmax(yhi, qy);
+        }
+        const double bcx = 0.5 * (xlo + xhi), bcy = 0.5 * (ylo + yhi);
+        double r2 = 0.0;
+        for (int j = i; j < N; ++j) {
+            const double ex = p[kp.r0 + 3 * j] - bcx, ey = p[kp.r0 + 3 * j + 1] - bcy;
+            r2 = fmax(r2, ex * ex + ey * ey);
+        }
+        sg[8] = bcx; sg[9] = bcy; sg[10] = sqrt(r2) * (1.0 + 1e-12) + 1e-300; sg[11] = 0.0;
         ws[kp.ws_vref + i] = p[kp.r0 + 3 * N + i];
     }
     // ---- static obstacles: lane o checks obstacle o
@@ -328,7 +368,8 @@ struct Ctx {
 };
 
 struct EvalOut {
-    double psi, f, nrm2F2;  // uniform
+    double psi;             // uniform
+    double f, nrm2F2;       // uniform; valid only when the evaluation was asked for them (want_f)
     double gv, gw;          // vector lanes: d psi / d (v_k, w_k)
     double F1a, F1b;        // vector lanes: acceleration mapping F1[k], F1[N+k]
     double F2e, F2pad;      // lane i < Kd: F2 of dynamic entry i; uniform: F2 of every padded row
@@ -345,13 +386,16 @@ __device__ __forceinline__ void load_problem(const KParams& kp, const double* __
     cx.il = lane < N * LPS;
     cx.ik = lane % N;
     cx.isub = lane / N;
-    cx.x0 = ws[0]; cx.y0 = ws[1]; cx.th0 = ws[2]; cx.xg = ws[3]; cx.yg = ws[4]; cx.thg = ws[5];
-    cx.v_init = ws[6]; cx.w_init = ws[7];
-    cx.qvel = ws[9]; cx.rv = ws[11]; cx.rw = ws[12]; cx.qN = ws[13]; cx.qthN = ws[14]; cx.qrpd = ws[15];
-    cx.acc_pen = ws[16]; cx.wacc_pen = ws[17];
-    cx.Ks = (int)ws[H_KS]; cx.Kf = (int)ws[H_KF]; cx.Kd = (int)ws[H_KD];
-    cx.cth0 = ws[H_CTH0]; cx.sth0 = ws[H_STH0];
-    cx.npf = ws[H_NPF]; cx.npd = ws[H_NPD];
+    // uniform header values: force them into SGPRs (a plain load of a uniform address is otherwise issued as
+    // a vector load and each value then occupies two VGPRs for the whole solve)
+    auto U = [&](int i) { return uniform(ws[i]); };
+    cx.x0 = U(0); cx.y0 = U(1); cx.th0 = U(2); cx.xg = U(3); cx.yg = U(4); cx.thg = U(5);
+    cx.v_init = U(6); cx.w_init = U(7);
+    cx.qvel = U(9); cx.rv = U(11); cx.rw = U(12); cx.qN = U(13); cx.qthN = U(14); cx.qrpd = U(15);
+    cx.acc_pen = U(16); cx.wacc_pen = U(17);
+    cx.Ks = (int)U(H_KS); cx.Kf = (int)U(H_KF); cx.Kd = (int)U(H_KD);
+    cx.cth0 = U(H_CTH0); cx.sth0 = U(H_STH0);
+    cx.npf = U(H_NPF); cx.npd = U(H_NPD);
     cx.vref = cx.vl ? ws[kp.ws_vref + lane] : 0.0;
     cx.seg = lds + kp.l_seg; cx.stc = lds + kp.l_stc; cx.fxy = lds + kp.l_fxy;
     cx.dyn = lds + kp.l_dyn; cx.dync = lds + kp.l_dync; cx.pos = lds + kp.l_pos; cx.H = lds + kp.l_H;
@@ -404,12 +448,17 @@ __device__ __forceinline__ DynItem dyn_item(const Ctx& cx, int i, int k, int N, 
 // ------------------------------------------------------------------------------------------------
 template <int NT, bool SC>
 __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, double v, double w, double c,
-                                           double ya, double yb, bool want_grad, EvalOut& out) {
-    const int N = NT ? NT : kp.N, LPS = NT ? Dim<NT>::LPS : kp.LPS, lane = cx.lane;
+                                           double ya, double yb, bool want_grad, bool want_f, EvalOut& out PROF_ARG) {
+    const int N = NT ? NT : kp.N, LPS = NT ? Dim<NT>::LPS : kp.LPS;
+    int lane = cx.lane;
+    asm volatile("" : "+v"(lane));  // opaque: per-lane LDS addresses are rebuilt here instead of being hoisted out
+                                    // of the solver loop, where they would stay live across the whole iteration
+    const bool c_vl = lane < N, c_il = lane < N * LPS;
+    const int c_ik = lane % N, c_isub = lane / N;
     constexpr int RV = Dim<NT>::ROWS_V, RI = Dim<NT>::ROWS_I;
     const double ts = kp.ts;
     const double inf = __builtin_huge_val();
-    if (!cx.vl) { v = 0.0; w = 0.0; }
+    if (!c_vl) { v = 0.0; w = 0.0; }
 
     // ---- rollout.  Heading phasors e^{i theta}: theta_{k+1} = theta_k + ts*w_k, so they are a prefix PRODUCT of
     //      unit complex numbers e^{i ts w_k} (DPP scan); positions are a prefix SUM of Simpson increments.
@@ -437,25 +486,32 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
             s0 = shift_up1(s2, lane, cx.sth0);
         }
     }
+    PROF_MARK(0);  // headings
     const double sixth = 1.0 / 6.0;
     const double Cx = (c0 + 4.0 * cm + c2) * sixth, Sy = (s0 + 4.0 * sm + s2) * sixth;
     const double dCw = -ts * (2.0 * sm + s2) * sixth, dSw = ts * (2.0 * cm + c2) * sixth;
-    const double X = cx.x0 + scan_prefix<RV>(cx.vl ? ts * v * Cx : 0.0);
-    const double Y = cx.y0 + scan_prefix<RV>(cx.vl ? ts * v * Sy : 0.0);
-    if (cx.vl) { cx.pos[2 * lane] = X; cx.pos[2 * lane + 1] = Y; }
+    const double X = cx.x0 + scan_prefix<RV>(c_vl ? ts * v * Cx : 0.0);
+    const double Y = cx.y0 + scan_prefix<RV>(c_vl ? ts * v * Sy : 0.0);
+    if (c_vl) { cx.pos[2 * lane] = X; cx.pos[2 * lane + 1] = Y; }
     wave_sync();
+    PROF_MARK(1);  // positions + publish
 
     // ---- item phase A: stage terms of step ik handled by this lane
     double cost_l = 0.0, S_l = 0.0, gx = 0.0, gy = 0.0, dsx = 0.0, dsy = 0.0;
     double best = inf, bgx = 0.0, bgy = 0.0;
     double px = 0.0, py = 0.0;
     bool anyh = false;
-    if (cx.il) {
-        const int k = cx.ik;
+    if (c_il) {
+        const int k = c_ik;
         px = cx.pos[2 * k]; py = cx.pos[2 * k + 1];
-        // reference-path deviation: min over segments i >= k (mpc_generator.py:207,116-130,28-36)
+        // reference-path deviation: min over segments i >= k (mpc_generator.py:207,116-130,28-36).
+        // Exact pruning: a segment whose midpoint is farther than sqrt(best) + half its length cannot hold the
+        // minimum (nor tie with it), so its distance is not evaluated; the value and arg-min are unchanged.
+        double sb = inf;  // upper bound of sqrt(best)
+        // (1) the SEG_WIN * LPS segments nearest in index are always evaluated
+        int i = k + c_isub;
         MPC_ITEM_LOOP
-        for (int i = k + cx.isub; i < N; i += LPS) {
+        for (int it = 0; it < SEG_WIN && i < N; ++it, i += LPS) {
             const double* sg = cx.seg + SEGW * i;
             const double s1x = sg[0], s1y = sg[1], dx = sg[2], dy = sg[3], inv = sg[4];
             const double th = ((px - s1x) * dx + (py - s1y) * dy) * inv;
@@ -469,9 +525,41 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
                 bgy = 2.0 * (wd * dy - wy);
             }
         }
+        // (2) all remaining segments of this lane lie in the bounding circle stored with segment k + SEG_WIN*LPS:
+        //     if that circle is farther than sqrt(best) for every lane, nobody evaluates them
+        bool more = false;
+        if (i < N) {
+            sb = sqrt(best) * (1.0 + 1e-12);
+            const double* sg = cx.seg + SEGW * (k + SEG_WIN * LPS);
+            const double bx = px - sg[8], by = py - sg[9], reach = (sb + sg[10]) * (1.0 + 1e-9);
+            more = bx * bx + by * by < reach * reach;
+        }
+        if (__ballot(more) != 0ull) {
+            // (3) rare: per-segment test (midpoint distance vs sqrt(best) + half length), evaluate on demand
+            MPC_ITEM_LOOP
+            for (; i < N; i += LPS) {
+                const double* sg = cx.seg + SEGW * i;
+                const double mx = px - sg[5], my = py - sg[6], reach = (sb + sg[7]) * (1.0 + 1e-9);
+                if (mx * mx + my * my < reach * reach) {
+                    const double s1x = sg[0], s1y = sg[1], dx = sg[2], dy = sg[3], inv = sg[4];
+                    const double th = ((px - s1x) * dx + (py - s1y) * dy) * inv;
+                    const double t = clampd(th, 0.0, 1.0);
+                    const double wx = s1x + t * dx - px, wy = s1y + t * dy - py;
+                    const double d2 = wx * wx + wy * wy;
+                    if (d2 < best) {
+                        best = d2;
+                        sb = sqrt(d2) * (1.0 + 1e-12);
+                        const double wd = (th >= 0.0 && th <= 1.0) ? (wx * dx + wy * dy) * inv : 0.0;
+                        bgx = 2.0 * (wd * dx - wx);
+                        bgy = 2.0 * (wd * dy - wy);
+                    }
+                }
+            }
+        }
+        PROF_MARK(2);  // segments
         // fleet discs (mpc_generator.py:211-216,105-108)
         MPC_ITEM_LOOP
-        for (int j = cx.isub; j < cx.Kf; j += LPS) {
+        for (int j = c_isub; j < cx.Kf; j += LPS) {
             const double ex = px - cx.fxy[(j * N + k) * 2], ey = py - cx.fxy[(j * N + k) * 2 + 1];
             const double hh = kp.W2 - (ex * ex + ey * ey);
             if (hh > 0.0) {
@@ -482,7 +570,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         }
         // static polygons, 4 half-planes each (mpc_generator.py:219-225,46-54)
         MPC_ITEM_LOOP
-        for (int o = cx.isub; o < cx.Ks; o += LPS) {
+        for (int o = c_isub; o < cx.Ks; o += LPS) {
             const double* s = cx.stc + STCW * o;
             const double m0 = fmax(0.0, s[0] - s[4] * px - s[8] * py);
             const double m1 = fmax(0.0, s[1] - s[5] * px - s[9] * py);
@@ -499,9 +587,10 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
                 dsy -= r0 * s[8] + r1 * s[9] + r2 * s[10] + r3 * s[11];
             }
         }
+        PROF_MARK(3);  // fleet + static
         // dynamic ellipses: hard indicator -> H, soft cost with social margin (mpc_generator.py:229-241,38-44,85-95)
         MPC_ITEM_LOOP
-        for (int i = cx.isub; i < cx.Kd; i += LPS) {
+        for (int i = c_isub; i < cx.Kd; i += LPS) {
             const DynItem d = dyn_item<SC>(cx, i, k, N, px, py);
             const double a2 = d.a * d.a, b2 = d.b * d.b;
             const double Ih = 1.0 - a2 * d.ihx - b2 * d.ihy;
@@ -516,10 +605,11 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
             }
         }
     }
+    PROF_MARK(4);  // dynamic
     // zero-padded rows, closed form on the vector lanes: npf discs of radius W and npd degenerate ellipses
     // (semi-axes 1e-6, alpha = 0: hard indicator only) at the origin
     double hp = 0.0, r2o = 0.0;
-    if (cx.vl) {
+    if (c_vl) {
         r2o = X * X + Y * Y;
         if (cx.npf > 0.0) {
             const double hh = kp.W2 - r2o;
@@ -534,8 +624,10 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     const bool any_h = __ballot(anyh) != 0ull;
     wave_sync();
 
-    // ---- constraint sums: S (static, broadcast into every F2 component), D_i (row sums of H)
-    const double S = wave_sum_u<RI>(S_l);
+    // ---- constraint sums: S (static, broadcast into every F2 component), D_i (row sums of H).
+    //      Every reduction is skipped when the ballots show that all its terms are zero.
+    const bool any_S = __ballot(S_l > 0.0) != 0ull;
+    const double S = any_S ? wave_sum_u<RI>(S_l) : 0.0;
     double F2e = 0.0;
     if (lane < cx.Kd) {
         double D = 0.0;
@@ -544,23 +636,22 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         F2e = S + D;
     }
     const double F2pad = cx.npd > 0.0 ? S + (any_hp ? wave_sum_u<RV>(hp) : 0.0) : 0.0;
-    double nrm2F2 = 0.0;
-    if (S > 0.0 || any_h || any_hp) nrm2F2 = wave_sum_u<2>(F2e * F2e) + cx.npd * F2pad * F2pad;
+    const bool viol = any_S || any_h || any_hp;  // some penalty constraint is violated
     out.F2e = F2e;
     out.F2pad = F2pad;
-    out.nrm2F2 = nrm2F2;
 
+    PROF_MARK(5);  // pads + constraint sums
     // ---- item phase B (only when some penalty constraint is violated): weighted hard-constraint gradients
     double Gpx = 0.0, Gpy = 0.0;  // vector lanes: gradient of the padded-row terms w.r.t. the position
-    if (want_grad && nrm2F2 > 0.0) {
+    if (want_grad && viol) {
         const double sumF2 = wave_sum_u<2>(F2e) + cx.npd * F2pad;
         if (lane < cx.Kd) cx.W[lane] = c * F2e;
         wave_sync();
-        if (cx.il) {
-            const int k = cx.ik;
+        if (c_il) {
+            const int k = c_ik;
             if (any_h) {
                 MPC_ITEM_LOOP
-        for (int i = cx.isub; i < cx.Kd; i += LPS) {
+        for (int i = c_isub; i < cx.Kd; i += LPS) {
                     const DynItem d = dyn_item<SC>(cx, i, k, N, px, py);
                     const double Ih = 1.0 - d.a * d.a * d.ihx - d.b * d.b * d.ihy;
                     if (Ih > 0.0) {
@@ -581,14 +672,15 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         }
     }
 
+    PROF_MARK(6);  // phase B
     // ---- combine the LPS item lanes of each step on its vector lane
-    if (cx.il) {
-        double* pp = cx.part + (cx.isub * N + cx.ik) * PARTW;
+    if (c_il) {
+        double* pp = cx.part + (c_isub * N + c_ik) * PARTW;
         pp[0] = gx; pp[1] = gy; pp[2] = best; pp[3] = bgx; pp[4] = bgy;
     }
     wave_sync();
     double Gx = Gpx, Gy = Gpy, vcost = 0.0;
-    if (cx.vl) {
+    if (c_vl) {
         double bb = inf, wbx = 0.0, wby = 0.0;
         for (int s = 0; s < LPS; ++s) {
             const double* pp = cx.part + (s * N + lane) * PARTW;
@@ -603,17 +695,18 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         }
     }
 
+    PROF_MARK(7);  // combine
     // ---- per-step terms on the vector lanes (mpc_generator.py:208-209,246,254-267)
     const double vprev = shift_up1(v, lane, cx.v_init), wprev = shift_up1(w, lane, cx.w_init);
-    const double a = cx.vl ? (v - vprev) * kp.inv_ts : 0.0;
-    const double bacc = cx.vl ? (w - wprev) * kp.inv_ts : 0.0;
+    const double a = c_vl ? (v - vprev) * kp.inv_ts : 0.0;
+    const double bacc = c_vl ? (w - wprev) * kp.inv_ts : 0.0;
     out.F1a = a; out.F1b = bacc;
     const double icm = 1.0 / fmax(c, 1.0);
     const double za = a + ya * icm, zb = bacc + yb * icm;
     const double ea = za > kp.amax ? za - kp.amax : (za < kp.amin ? za - kp.amin : 0.0);
     const double eb = zb > kp.aamax ? zb - kp.aamax : (zb < -kp.aamax ? zb + kp.aamax : 0.0);
     double gthN = 0.0;
-    if (cx.vl) {
+    if (c_vl) {
         const double dv = v - cx.vref;
         vcost += cx.qvel * dv * dv + cx.rv * v * v + cx.rw * w * w + cx.acc_pen * a * a + cx.wacc_pen * bacc * bacc;
     }
@@ -627,26 +720,34 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         }
         gthN = readlane_d(gthN, N - 1);
     }
-    const double f = wave_sum_u<RI>(cost_l + vcost);
-    const double dist2 = wave_sum_u<RV>(cx.vl ? ea * ea + eb * eb : 0.0);
-    out.f = f;
-    out.psi = f + 0.5 * c * dist2 + 0.5 * c * nrm2F2;
+    // psi = f + c/2 dist^2_C(F1 + y/max(c,1)) + c/2 ||F2||^2 in ONE wave reduction of per-lane partials
+    // (item lanes: stage costs; vector lanes: per-step costs + box distance; lanes < Kd: their F2 entry)
+    const double dist_l = c_vl ? ea * ea + eb * eb : 0.0;
+    const double f2_l = viol ? F2e * F2e : 0.0;
+    const double pad2 = viol ? cx.npd * F2pad * F2pad : 0.0;
+    out.psi = wave_sum_u<RI>(cost_l + vcost + 0.5 * c * (dist_l + f2_l)) + 0.5 * c * pad2;
+    if (want_f) {  // f and ||F2||^2 on their own (outer loop, test hook): two more reductions
+        out.f = wave_sum_u<RI>(cost_l + vcost);
+        out.nrm2F2 = viol ? wave_sum_u<2>(f2_l) + pad2 : 0.0;
+    }
 
+    PROF_MARK(8);  // vector terms + psi
     if (want_grad) {
-        const double da = cx.vl ? (2.0 * cx.acc_pen * a + c * ea) * kp.inv_ts : 0.0;
-        const double db = cx.vl ? (2.0 * cx.wacc_pen * bacc + c * eb) * kp.inv_ts : 0.0;
+        const double da = c_vl ? (2.0 * cx.acc_pen * a + c * ea) * kp.inv_ts : 0.0;
+        const double db = c_vl ? (2.0 * cx.wacc_pen * bacc + c * eb) * kp.inv_ts : 0.0;
         const double da_n = shift_down1(da), db_n = shift_down1(db);
         double gv = 2.0 * cx.qvel * (v - cx.vref) + 2.0 * cx.rv * v + da - da_n;
         double gw = 2.0 * cx.rw * w + db - db_n;
         // adjoint of the rollout: suffix sums instead of a serial backward sweep
         const double Ax = scan_suffix<RV>(Gx, lane), Ay = scan_suffix<RV>(Gy, lane);
-        const double T = cx.vl ? ts * v * (-Sy * Ax + Cx * Ay) : 0.0;
+        const double T = c_vl ? ts * v * (-Sy * Ax + Cx * Ay) : 0.0;
         const double Bx = scan_suffix<RV>(T, lane) - T;
         gv += ts * (Cx * Ax + Sy * Ay);
         gw += ts * v * (dCw * Ax + dSw * Ay) + ts * (Bx + gthN);
-        out.gv = cx.vl ? gv : 0.0;
-        out.gw = cx.vl ? gw : 0.0;
+        out.gv = c_vl ? gv : 0.0;
+        out.gw = c_vl ? gw : 0.0;
     }
+    PROF_MARK(9);  // adjoint
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -669,7 +770,10 @@ __global__ __launch_bounds__(WAVE) void cost_grad_kernel(KParams kp, BatchPtrs i
     const double c = xb[0];
     const double ya = cx.vl ? xb[1 + lane] : 0.0, yb = cx.vl ? xb[1 + N + lane] : 0.0;
     EvalOut o;
-    eval_point<NT, SC>(kp, cx, v, w, c, ya, yb, true, o);
+#ifdef MPC_PROFILE
+    Prof prof; prof.start();
+#endif
+    eval_point<NT, SC>(kp, cx, v, w, c, ya, yb, true, true, o PROF_PASS);
     if (lane == 0) {
         if (psi) psi[b] = o.psi;
         if (f) f[b] = o.f;
@@ -686,8 +790,12 @@ __global__ __launch_bounds__(WAVE) void cost_grad_kernel(KParams kp, BatchPtrs i
 }
 
 // ------------------------------------------------------------------------------------------------
-// solver kernel: ALM/PM outer loop around PANOC, one problem per wavefront.
+// solver kernels: ALM/PM outer loop around PANOC, one problem per wavefront.
 // The iteration is organised as a small state machine around ONE call site of eval_point.
+//   solve_kernel_pair: lane k holds (v_k, w_k) of every horizon vector, L-BFGS memory in LDS.
+//   (An element-per-lane variant with the L-BFGS memory in 40 VGPRs was built and measured in round 1: the
+//   unrolled register-resident two-loop recursion pushed the kernel past 256 VGPRs and it ran 1.6-2.8x slower;
+//   see DESIGN.md section 7.)
 // ------------------------------------------------------------------------------------------------
 enum { ST_INIT0 = 0, ST_INIT1, ST_LIP, ST_NOLS, ST_LS, ST_OUTER };
 
@@ -700,7 +808,7 @@ __device__ __forceinline__ double dot2r(double a0, double a1, double b0, double 
 #define MPC_MIN_WAVES 2  // waves per SIMD the register allocator must leave room for (512 / MPC_MIN_WAVES VGPRs)
 #endif
 template <int NT, bool SC>
-__global__ __launch_bounds__(WAVE, MPC_MIN_WAVES) void solve_kernel(KParams kp, BatchPtrs io, int B) {
+__global__ __launch_bounds__(WAVE, MPC_MIN_WAVES) void solve_kernel_pair(KParams kp, BatchPtrs io, int B) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int b = blockIdx.x;
     if (b >= B) return;
@@ -751,6 +859,9 @@ __global__ __launch_bounds__(WAVE, MPC_MIN_WAVES) void solve_kernel(KParams kp, 
     double ev = uv, ew = uw;  // evaluation point
     bool want_grad = true;
     EvalOut o;
+#ifdef MPC_PROFILE
+    Prof prof; prof.start();
+#endif
 
     // u_half <- Proj_U(base - gamma*grad); returns ||gradient_step - u_half||^2
     auto half_step = [&](double bv, double bw) -> double {
@@ -762,7 +873,9 @@ __global__ __launch_bounds__(WAVE, MPC_MIN_WAVES) void solve_kernel(KParams kp, 
     };
 
     for (;;) {
-        eval_point<NT, SC>(kp, cx, ev, ew, c, ya, yb, want_grad, o);
+        PROF_MARK(10 + state);  // solver logic that led to this evaluation (by the state it was issued for)
+        PROF_COUNT(16 + state);
+        eval_point<NT, SC>(kp, cx, ev, ew, c, ya, yb, want_grad, state == ST_OUTER, o PROF_PASS);
         bool step_begin = false;
 
         if (state == ST_INIT0) {
@@ -955,6 +1068,9 @@ __global__ __launch_bounds__(WAVE, MPC_MIN_WAVES) void solve_kernel(KParams kp, 
         }
     }
 
+#ifdef MPC_PROFILE
+    prof.mark(22); prof.flush();
+#endif
     // ---- write results (coalesced per problem)
     if (vl) {
         io.u[(size_t)b * 2 * N + 2 * lane] = uv;
@@ -970,5 +1086,6 @@ __global__ __launch_bounds__(WAVE, MPC_MIN_WAVES) void solve_kernel(KParams kp, 
         if (io.ms) io.ms[b] = (double)(wall_clock64() - t_start) * 1e-5;  // 100 MHz ticks -> ms
     }
 }
+
 
 }  // namespace mpcgpu

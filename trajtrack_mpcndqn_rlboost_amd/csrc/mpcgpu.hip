@@ -253,23 +253,16 @@ int32_t mpcgpu_solve_batch_dev(void* handle, int32_t B, const double* p, const d
     io.outer_it = outer_it; io.fpr = fpr; io.f2norm = f2norm; io.y_out = y_out; io.ms = ms;
     HIP_OK(h, hipEventRecord(h->ev[2], s));
     const size_t lds = h->kp.l_total * sizeof(double);
+#define LAUNCH_PAIR(NT, SC) hipLaunchKernelGGL((solve_kernel_pair<NT, SC>), dim3(B), dim3(WAVE), lds, s, h->kp, io, B)
     // compile-time horizons for the configurations the reference uses (generic kernel otherwise) x
     // {shape-constant, general} dynamic-obstacle tables
-#define LAUNCH_SOLVE(NT, SC) hipLaunchKernelGGL((solve_kernel<NT, SC>), dim3(B), dim3(WAVE), lds, s, h->kp, io, B)
-    if (h->shape_const) {
-        switch (h->kp.N) {
-            case 20: LAUNCH_SOLVE(20, true); break;
-            case 40: LAUNCH_SOLVE(40, true); break;
-            default: LAUNCH_SOLVE(0, true); break;
-        }
-    } else {
-        switch (h->kp.N) {
-            case 20: LAUNCH_SOLVE(20, false); break;
-            case 40: LAUNCH_SOLVE(40, false); break;
-            default: LAUNCH_SOLVE(0, false); break;
-        }
+    const bool sc = h->shape_const;
+    switch (h->kp.N) {
+        case 20: if (sc) LAUNCH_PAIR(20, true); else LAUNCH_PAIR(20, false); break;
+        case 40: if (sc) LAUNCH_PAIR(40, true); else LAUNCH_PAIR(40, false); break;
+        default: if (sc) LAUNCH_PAIR(0, true); else LAUNCH_PAIR(0, false); break;
     }
-#undef LAUNCH_SOLVE
+#undef LAUNCH_PAIR
     HIP_OK(h, hipGetLastError());
     HIP_OK(h, hipEventRecord(h->ev[3], s));
     h->timing_valid = true;
@@ -395,5 +388,17 @@ int32_t mpcgpu_last_shape(void* handle, int32_t* max_static, int32_t* max_fleet,
     if (lds_bytes) *lds_bytes = h->last_shape[3];
     return 0;
 }
+
+#ifdef MPC_PROFILE
+// profiling builds only: read and clear the phase-cycle table (24 counters)
+int32_t mpcgpu_debug_read_prof(double* out24) {
+    unsigned long long hbuf[NPROF];
+    if (hipMemcpyFromSymbol(hbuf, HIP_SYMBOL(g_prof), sizeof(hbuf)) != hipSuccess) return -1;
+    for (int i = 0; i < NPROF; ++i) out24[i] = (double)hbuf[i];
+    unsigned long long z[NPROF] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
 
 }  // extern "C"
