@@ -105,6 +105,7 @@ def main():
         elapsed = float(tt.item())
 
     if rank == 0:
+        traffic = measured_traffic(N, args.n_dyn, B)
         status = out["status"].cpu().numpy()
         inner = out["inner_it"].cpu().numpy()
         k_ms = float(np.mean(kernel_ms))
@@ -130,7 +131,7 @@ def main():
                        "mean_inner_iterations": float(inner.mean()),
                        "status_histogram": np.bincount(status, minlength=3).tolist()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "solve_kernel", "kernel_ms": k_ms, "prep_kernel_ms": float(np.mean(prep_ms)),
                          "algorithmic_bytes_per_solve": algo_bytes // B,
                          "note": "LDS-resident solver: HBM is read once per solve; the kernel is VALU-f64/latency bound"},
@@ -141,6 +142,21 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measured_traffic(N, n_dyn, B):
+    """HBM bytes per launch of solve_kernel from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE,
+    profiles/r01_hbm_traffic_bench_B8192.json) -- only when it was collected on this very workload."""
+    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic_bench_B8192.json")
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+        w = d["workload"]
+        if (w["N_hor"], w["n_dyn"], w["batch_per_gpu"]) == (N, n_dyn, B):
+            return d["solve_kernel_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
 
 
 def cpu_baseline(cfg, p_all, budget_s):
