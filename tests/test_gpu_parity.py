@@ -373,3 +373,42 @@ def test_closed_loop_batched_tracker_matches_single_robot_tracker_and_makes_prog
     for i in range(B):                                                          # predictions avoid the box interior
         inside = (pred[i][:, 0] > 6.7) & (pred[i][:, 0] < 9.3) & (pred[i][:, 1] > 2.2) & (pred[i][:, 1] < 4.8)
         assert inside.sum() <= 2
+
+
+@pytest.mark.parametrize("N,n_dyn,B", [(20, 8, 8192), (40, 8, 4096), (20, 4, 1024)])
+def test_full_size_configurations_through_size_independent_properties(N, n_dyn, B):
+    """BASELINE.json configurations at their full batch sizes.  The oracle cannot solve thousands of problems in
+    seconds, so the whole batch is checked through properties that do not need it: every control sequence lies in
+    the input box; the reported cost is f(u) (oracle cost function, sampled); a re-solve of a random sub-batch in a
+    different order is bitwise identical (batch-composition / sharding invariance); statuses and iteration counts
+    are consistent with the caps; and a 48-problem sample agrees with the oracle like the small-batch tests."""
+    cfg = make_cfg(N)
+    ocfg = oracle_cfg(cfg)
+    bs = BatchSolver(cfg)
+    sc = scenes.make_batch(cfg, B, n_dyn=n_dyn, seed=1234)
+    res = bs.solve(sc["p"])
+    uu = res.solution.reshape(B, N, 2)
+    assert np.all(np.isfinite(res.solution)) and np.all(np.isfinite(res.cost))
+    assert uu[..., 0].min() >= cfg.lin_vel_min and uu[..., 0].max() <= cfg.lin_vel_max
+    assert np.abs(uu[..., 1]).max() <= cfg.ang_vel_max
+    assert set(np.unique(res.status)) <= {0, 1}
+    assert res.num_outer_iterations.min() >= 1 and res.num_outer_iterations.max() <= cfg.solver_max_outer_iterations
+    assert res.num_inner_iterations.max() <= cfg.solver_max_outer_iterations * cfg.solver_max_inner_iterations
+    assert np.all(res.num_outer_iterations[res.status == 0] < cfg.solver_max_outer_iterations)
+    rng = np.random.default_rng(B)
+    pick = rng.choice(B, 48, replace=False)
+    for i in pick[:16]:
+        assert _rel(res.cost[i], oracle.cost_grad(ocfg, res.solution[i], sc["p"][i])["f"]) < 1e-10
+    again = bs.solve(sc["p"][pick[::-1]])
+    assert np.array_equal(again.solution, res.solution[pick[::-1]])
+    assert np.array_equal(again.num_inner_iterations, res.num_inner_iterations[pick[::-1]])
+    uo, _, ro, _ = oracle.solve_batch(ocfg, sc["p"][pick])
+    assert (res.status[pick] == ro["status"]).mean() >= 0.85
+    assert abs(res.num_inner_iterations[pick].mean() / ro["inner_iters"].mean() - 1.0) < 0.15
+    # capped solves land in different local basins (costs span an order of magnitude): the per-problem cost ratio
+    # must scatter around 1 without bias
+    assert abs(np.median(np.log(res.cost[pick] / ro["cost"]))) < 0.25
+    both = (res.status[pick] == 0) & (ro["status"] == 0)
+    if both.any():
+        assert np.max(np.abs(res.solution[pick] - uo), axis=1)[both].max() <= U_TOL
+    bs.close()
