@@ -75,10 +75,10 @@ struct KParams {
     // parameter-vector offsets (mpc_generator.py:179-188)
     int r0, c0, os0, od0, qs0, qd0;
     // workspace (global) layout per problem, doubles
-    int ws_stride, ws_vref, ws_seg, ws_stc, ws_fxy, ws_dyn;
+    int ws_stride, ws_vref, ws_seg, ws_stc, ws_fxy, ws_dyn, ws_lbs, ws_lby;
     // LDS layout (doubles), strides use the batch maxima mKs/mKf/mKd
     int mKs, mKf, mKd;
-    int l_seg, l_stc, l_fxy, l_dyn, l_dync, l_pos, l_H, l_W, l_part, l_S, l_Y, l_rho, l_alpha, l_old, l_total;
+    int l_seg, l_stc, l_fxy, l_dyn, l_dync, l_pos, l_H, l_W, l_part, l_stash, l_S, l_Y, l_rho, l_alpha, l_old, l_total;
 };
 
 // lanes per step for the item phase
@@ -208,14 +208,38 @@ __device__ __forceinline__ void scan_cprod(double& re, double& im) {
     if (ROWS > 1) cmul_step<DPP_BCAST15, 0xA>(re, im);
     if (ROWS > 2) cmul_step<DPP_BCAST31, 0xC>(re, im);
 }
+// Double-precision literals cannot be instruction operands on gfx950; the compiler materialises each one in a VGPR
+// pair and keeps it there for the whole solver loop (two registers per literal, >20 literals on the hot path).
+// Reading them from constant memory makes them scalar loads into SGPRs instead.
+__constant__ double KTAB[27] = {
+    -1.66666666666666324348e-01, 8.33333333332248946124e-03, -1.98412698298579493134e-04,   // sin: S1..S6
+    2.75573137070700676789e-06, -2.50507602534068634195e-08, 1.58969099521155010221e-10,
+    4.16666666666666019037e-02, -1.38888888888741095749e-03, 2.48015872894767294178e-05,    // cos: C1..C6
+    -2.75573143513906633035e-07, 2.08757232129817482790e-09, -1.13596475577881948265e-11,
+    1.0 / 6.0,                 // 12
+    1.0 + 1e-9,                // 13: safety factor of the pruning radii
+    1.0 + 1e-12,               // 14: safety factor of sqrt(best)
+    0.78,                      // 15: |half-step heading increment| up to which the polynomials are used
+    1.0 / (1e-6 * 1e-6),       // 16: inverse squared semi-axis of a zero-padded dynamic row: 1/((0+1e-6)^2)
+    0.95,                      // 17: gamma = 0.95 / L                               [OpEn PANOC constants from here]
+    1e-12,                     // 18: delta of the Lipschitz-estimate perturbation
+    1e-6,                      // 19: epsilon of the Lipschitz-estimate perturbation; also the Lipschitz-update slack
+    1e9,                       // 20: largest Lipschitz estimate
+    1e-10,                     // 21: smallest Lipschitz estimate; also the s'y acceptance threshold of the L-BFGS buffer
+    2.220446049250313e-16,     // 22: machine epsilon used in the ALM comparisons
+    2.2250738585072014e-308,   // 23: smallest normal double (||s||^2 test of the L-BFGS buffer)
+    1e-8,                      // 24: C-BFGS epsilon
+    1e12,                      // 25: bound of the multiplier set Y
+    (1.0 - 0.95) / 4.0};       // 26: sigma = (1 - 0.95) / (4 gamma); the division by 4 is exact
+enum { K_SIXTH = 12, K_REACH = 13, K_SQRT = 14, K_SMALL = 15, K_IPAD = 16, K_GAMMA_L = 17, K_DELTA_LIP = 18, K_EPS_LIP = 19,
+       K_MAX_LIP = 20, K_MIN_L = 21, K_EPS = 22, K_DBLMIN = 23, K_CBFGS = 24, K_YBOUND = 25, K_SIGMA = 26 };
+
 // sin / cos on [-pi/4, pi/4] (fdlibm kernel polynomials, error < 1 ulp there)
 __device__ __forceinline__ void sincos_small(double x, double& s, double& c) {
     const double z = x * x;
-    const double ps = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
-                      z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+    const double ps = KTAB[0] + z * (KTAB[1] + z * (KTAB[2] + z * (KTAB[3] + z * (KTAB[4] + z * KTAB[5]))));
     s = x + x * z * ps;
-    const double pc = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
-                      z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+    const double pc = KTAB[6] + z * (KTAB[7] + z * (KTAB[8] + z * (KTAB[9] + z * (KTAB[10] + z * KTAB[11]))));
     c = 1.0 - 0.5 * z + z * z * pc;
 }
 
@@ -364,7 +388,7 @@ struct Ctx {
     bool vl, il;
     double vref;  // vector lane k: speed reference of step k
     // LDS tables
-    double *seg, *stc, *fxy, *dyn, *dync, *pos, *H, *W, *part;
+    double *seg, *stc, *fxy, *dyn, *dync, *pos, *H, *W, *part, *stash;
 };
 
 struct EvalOut {
@@ -399,7 +423,7 @@ __device__ __forceinline__ void load_problem(const KParams& kp, const double* __
     cx.vref = cx.vl ? ws[kp.ws_vref + lane] : 0.0;
     cx.seg = lds + kp.l_seg; cx.stc = lds + kp.l_stc; cx.fxy = lds + kp.l_fxy;
     cx.dyn = lds + kp.l_dyn; cx.dync = lds + kp.l_dync; cx.pos = lds + kp.l_pos; cx.H = lds + kp.l_H;
-    cx.W = lds + kp.l_W; cx.part = lds + kp.l_part;
+    cx.W = lds + kp.l_W; cx.part = lds + kp.l_part; cx.stash = lds + kp.l_stash;
     // coalesced table copies HBM -> LDS (only the active entries of this problem)
     for (int i = lane; i < N * SEGW; i += WAVE) cx.seg[i] = ws[kp.ws_seg + i];
     for (int i = lane; i < cx.Ks * STCW; i += WAVE) cx.stc[i] = ws[kp.ws_stc + i];
@@ -465,7 +489,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     double c0, s0, cm, sm, c2, s2;
     {
         const double hd = 0.5 * ts * w;  // half-step heading increment
-        const bool small = __ballot(fabs(hd) > 0.78) == 0ull;
+        const bool small = __ballot(fabs(hd) > KTAB[K_SMALL]) == 0ull;
         if (small) {
             double sh, ch;
             sincos_small(hd, sh, ch);
@@ -487,12 +511,20 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         }
     }
     PROF_MARK(0);  // headings
-    const double sixth = 1.0 / 6.0;
+    const double sixth = KTAB[K_SIXTH];
+    {
     const double Cx = (c0 + 4.0 * cm + c2) * sixth, Sy = (s0 + 4.0 * sm + s2) * sixth;
     const double dCw = -ts * (2.0 * sm + s2) * sixth, dSw = ts * (2.0 * cm + c2) * sixth;
     const double X = cx.x0 + scan_prefix<RV>(c_vl ? ts * v * Cx : 0.0);
     const double Y = cx.y0 + scan_prefix<RV>(c_vl ? ts * v * Sy : 0.0);
-    if (c_vl) { cx.pos[2 * lane] = X; cx.pos[2 * lane + 1] = Y; }
+    if (c_vl) {
+        cx.pos[2 * lane] = X; cx.pos[2 * lane + 1] = Y;
+        // rollout quantities needed again only after the item phase (per-step terms, adjoint): parked in LDS so
+        // that they do not occupy registers across the item loops
+        double* st = cx.stash + lane * 6;
+        st[0] = Cx; st[1] = Sy; st[2] = dCw; st[3] = dSw; st[4] = v; st[5] = w;
+    }
+    }
     wave_sync();
     PROF_MARK(1);  // positions + publish
 
@@ -529,9 +561,9 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         //     if that circle is farther than sqrt(best) for every lane, nobody evaluates them
         bool more = false;
         if (i < N) {
-            sb = sqrt(best) * (1.0 + 1e-12);
+            sb = sqrt(best) * KTAB[K_SQRT];
             const double* sg = cx.seg + SEGW * (k + SEG_WIN * LPS);
-            const double bx = px - sg[8], by = py - sg[9], reach = (sb + sg[10]) * (1.0 + 1e-9);
+            const double bx = px - sg[8], by = py - sg[9], reach = (sb + sg[10]) * KTAB[K_REACH];
             more = bx * bx + by * by < reach * reach;
         }
         if (__ballot(more) != 0ull) {
@@ -539,7 +571,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
             MPC_ITEM_LOOP
             for (; i < N; i += LPS) {
                 const double* sg = cx.seg + SEGW * i;
-                const double mx = px - sg[5], my = py - sg[6], reach = (sb + sg[7]) * (1.0 + 1e-9);
+                const double mx = px - sg[5], my = py - sg[6], reach = (sb + sg[7]) * KTAB[K_REACH];
                 if (mx * mx + my * my < reach * reach) {
                     const double s1x = sg[0], s1y = sg[1], dx = sg[2], dy = sg[3], inv = sg[4];
                     const double th = ((px - s1x) * dx + (py - s1y) * dy) * inv;
@@ -548,7 +580,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
                     const double d2 = wx * wx + wy * wy;
                     if (d2 < best) {
                         best = d2;
-                        sb = sqrt(d2) * (1.0 + 1e-12);
+                        sb = sqrt(d2) * KTAB[K_SQRT];
                         const double wd = (th >= 0.0 && th <= 1.0) ? (wx * dx + wy * dy) * inv : 0.0;
                         bgx = 2.0 * (wd * dx - wx);
                         bgy = 2.0 * (wd * dy - wy);
@@ -606,6 +638,8 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         }
     }
     PROF_MARK(4);  // dynamic
+    double X = 0.0, Y = 0.0;  // position of this vector lane's step, back from LDS
+    if (c_vl) { X = cx.pos[2 * lane]; Y = cx.pos[2 * lane + 1]; }
     // zero-padded rows, closed form on the vector lanes: npf discs of radius W and npd degenerate ellipses
     // (semi-axes 1e-6, alpha = 0: hard indicator only) at the origin
     double hp = 0.0, r2o = 0.0;
@@ -616,7 +650,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
             if (hh > 0.0) cost_l += kp.fleetw * cx.npf * hh;  // its gradient is added on the vector lanes below
         }
         if (cx.npd > 0.0) {
-            const double ipad = 1.0 / ((0.0 + 1e-6) * (0.0 + 1e-6));
+            const double ipad = KTAB[K_IPAD];
             hp = fmax(0.0, 1.0 - X * X * ipad - Y * Y * ipad);
         }
     }
@@ -665,7 +699,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
             gy += c * sumF2 * dsy;
         }
         if (any_hp && hp > 0.0) {  // a = X, b = -Y for the padded ellipse (cosA = 1, sinA = 0)
-            const double ipad = 1.0 / ((0.0 + 1e-6) * (0.0 + 1e-6));
+            const double ipad = KTAB[K_IPAD];
             const double wpad = c * cx.npd * F2pad;
             Gpx = wpad * (-2.0 * X * ipad);
             Gpy = wpad * (-2.0 * Y * ipad);
@@ -697,6 +731,8 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
 
     PROF_MARK(7);  // combine
     // ---- per-step terms on the vector lanes (mpc_generator.py:208-209,246,254-267)
+    v = 0.0; w = 0.0;
+    if (c_vl) { v = cx.stash[lane * 6 + 4]; w = cx.stash[lane * 6 + 5]; }
     const double vprev = shift_up1(v, lane, cx.v_init), wprev = shift_up1(w, lane, cx.w_init);
     const double a = c_vl ? (v - vprev) * kp.inv_ts : 0.0;
     const double bacc = c_vl ? (w - wprev) * kp.inv_ts : 0.0;
@@ -739,6 +775,8 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         double gv = 2.0 * cx.qvel * (v - cx.vref) + 2.0 * cx.rv * v + da - da_n;
         double gw = 2.0 * cx.rw * w + db - db_n;
         // adjoint of the rollout: suffix sums instead of a serial backward sweep
+        double Cx = 0.0, Sy = 0.0, dCw = 0.0, dSw = 0.0;
+        if (c_vl) { const double* st = cx.stash + lane * 6; Cx = st[0]; Sy = st[1]; dCw = st[2]; dSw = st[3]; }
         const double Ax = scan_suffix<RV>(Gx, lane), Ay = scan_suffix<RV>(Gy, lane);
         const double T = c_vl ? ts * v * (-Sy * Ax + Cx * Ay) : 0.0;
         const double Bx = scan_suffix<RV>(T, lane) - T;
@@ -805,9 +843,9 @@ __device__ __forceinline__ double dot2r(double a0, double a1, double b0, double 
 }
 
 #ifndef MPC_MIN_WAVES
-#define MPC_MIN_WAVES 2  // waves per SIMD the register allocator must leave room for (512 / MPC_MIN_WAVES VGPRs)
+#define MPC_MIN_WAVES 3  // waves per SIMD the register allocator must leave room for (512 / MPC_MIN_WAVES VGPRs)
 #endif
-template <int NT, bool SC>
+template <int NT, bool SC, bool LBG>
 __global__ __launch_bounds__(WAVE, MPC_MIN_WAVES) void solve_kernel_pair(KParams kp, BatchPtrs io, int B) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int b = blockIdx.x;
@@ -818,16 +856,20 @@ __global__ __launch_bounds__(WAVE, MPC_MIN_WAVES) void solve_kernel_pair(KParams
     const double* ws = io.ws + (size_t)b * kp.ws_stride;
     Ctx cx;
     load_problem<NT, SC>(kp, ws, lds, cx);
-    double* LS = lds + kp.l_S;      // [mem][N][2]
-    double* LY = lds + kp.l_Y;      // [mem][N][2]
+    // L-BFGS memory S, Y [mem][N][2]: in LDS (LBG = false) or in this problem's workspace record, i.e. in the
+    // L2-resident HBM workspace (LBG = true: 6.4 KB less LDS per wavefront -> more resident wavefronts; the pairs are
+    // streamed once per PANOC iteration, one pair ahead of the dot product that consumes them)
+    double* LS = LBG ? io.ws + (size_t)b * kp.ws_stride + kp.ws_lbs : lds + kp.l_S;
+    double* LY = LBG ? io.ws + (size_t)b * kp.ws_stride + kp.ws_lby : lds + kp.l_Y;
     double* LRHO = lds + kp.l_rho;  // [mem]
     double* LALPHA = lds + kp.l_alpha;
     double* LOLD = lds + kp.l_old;  // [N][4]: L-BFGS old state (u) and old g (gamma*fpr)
     const bool vl = cx.vl;
 
     // PANOC constants [OpEn]
-    const double GAMMA_L_COEFF = 0.95, DELTA_LIP = 1e-12, EPS_LIP = 1e-6, LIP_UPD_EPS = 1e-6;
-    const double MAX_LIP = 1e9, MIN_L = 1e-10, SMALL_EPS = 2.220446049250313e-16, DBLMIN = 2.2250738585072014e-308;
+    const double GAMMA_L_COEFF = KTAB[K_GAMMA_L], DELTA_LIP = KTAB[K_DELTA_LIP], EPS_LIP = KTAB[K_EPS_LIP],
+                 LIP_UPD_EPS = KTAB[K_EPS_LIP];
+    const double MAX_LIP = KTAB[K_MAX_LIP], MIN_L = KTAB[K_MIN_L], SMALL_EPS = KTAB[K_EPS], DBLMIN = KTAB[K_DBLMIN];
     const int MAX_LIP_IT = 10, MAX_LS_IT = 10;
 
     // decision vector and multipliers (vector lanes; zeros elsewhere)
@@ -840,7 +882,7 @@ __global__ __launch_bounds__(WAVE, MPC_MIN_WAVES) void solve_kernel_pair(KParams
     double c = kp.init_penalty;
     if (io.c0) { const double c0 = io.c0[b]; if (c0 > 0.0) c = c0; }
     c = uniform(c);
-    ya = clampd(ya, -1e12, 1e12); yb = clampd(yb, -1e12, 1e12);  // y <- Proj_Y(y), Y = [-1e12, 1e12]^n1
+    ya = clampd(ya, -KTAB[K_YBOUND], KTAB[K_YBOUND]); yb = clampd(yb, -KTAB[K_YBOUND], KTAB[K_YBOUND]);  // y <- Proj_Y(y), Y = [-1e12, 1e12]^n1
     // PANOC cache: vector state u, grad, u_half, gamma*fpr, direction (2 doubles per vector lane each);
     // ||grad||^2 and ||gradient_step - u_half||^2 are carried as scalars (they only enter the envelope)
     double gv = 0, gw = 0, hv = 0, hw = 0, rv_ = 0, rw_ = 0, dv = 0, dw = 0;
@@ -890,7 +932,7 @@ __global__ __launch_bounds__(WAVE, MPC_MIN_WAVES) void solve_kernel_pair(KParams
             const double d0 = o.gv - gv, d1 = o.gw - gw;
             Lip = uniform(sqrt(dot2r<RV>(d0, d1, d0, d1)) / nh);
             gamma = uniform(GAMMA_L_COEFF / fmax(Lip, MIN_L));
-            sigma = uniform((1.0 - GAMMA_L_COEFF) / (4.0 * gamma));
+            sigma = uniform(KTAB[K_SIGMA] / gamma);
             gg = dot2r<RV>(gv, gw, gv, gw);
             d2h = half_step(uv, uw);
             step_begin = true;
@@ -908,7 +950,7 @@ __global__ __launch_bounds__(WAVE, MPC_MIN_WAVES) void solve_kernel_pair(KParams
                 ev = hv; ew = hw; want_grad = false;
                 continue;
             }
-            sigma = uniform((1.0 - GAMMA_L_COEFF) / (4.0 * gamma));
+            sigma = uniform(KTAB[K_SIGMA] / gamma);
             // ---- L-BFGS buffer update with (state = u, g = gamma*fpr)   [crate lbfgs: C-BFGS acceptance]
             if (lb_first) {
                 lb_first = false;
@@ -920,7 +962,7 @@ __global__ __launch_bounds__(WAVE, MPC_MIN_WAVES) void solve_kernel_pair(KParams
                     y0_ = rv_ - LOLD[lane * 4 + 2]; y1_ = rw_ - LOLD[lane * 4 + 3];
                 }
                 const double ys = dot2r<RV>(s0, s1, y0_, y1_), ss = dot2r<RV>(s0, s1, s0, s1);
-                if (!(ss <= DBLMIN || ys <= 1e-10) && (ys / ss > 1e-8 * nfpr)) {
+                if (!(ss <= DBLMIN || ys <= KTAB[K_MIN_L]) && (ys / ss > KTAB[K_CBFGS] * nfpr)) {
                     lb_head = (lb_head + mem - 1) % mem;
                     if (vl) {
                         LOLD[lane * 4] = uv; LOLD[lane * 4 + 1] = uw; LOLD[lane * 4 + 2] = rv_; LOLD[lane * 4 + 3] = rw_;
@@ -941,21 +983,50 @@ __global__ __launch_bounds__(WAVE, MPC_MIN_WAVES) void solve_kernel_pair(KParams
             }
             // ---- direction d = H * (gamma*fpr): two-loop recursion, newest pair first
             double q0 = rv_, q1 = rw_;
-            for (int j = 0; j < lb_active; ++j) {
-                const int sl = (lb_head + j) % mem;
-                const double sj0 = vl ? LS[(sl * N + lane) * 2] : 0.0, sj1 = vl ? LS[(sl * N + lane) * 2 + 1] : 0.0;
-                const double al = LRHO[sl] * dot2r<RV>(sj0, sj1, q0, q1);
-                if (lane == 0) LALPHA[j] = al;
-                if (vl) { q0 -= al * LY[(sl * N + lane) * 2]; q1 -= al * LY[(sl * N + lane) * 2 + 1]; }
-            }
-            wave_sync();
-            if (lb_active > 0) { q0 *= lb_gamma; q1 *= lb_gamma; }
-            for (int j = lb_active - 1; j >= 0; --j) {
-                const int sl = (lb_head + j) % mem;
-                const double yj0 = vl ? LY[(sl * N + lane) * 2] : 0.0, yj1 = vl ? LY[(sl * N + lane) * 2 + 1] : 0.0;
-                const double be = LRHO[sl] * dot2r<RV>(yj0, yj1, q0, q1);
-                const double co = LALPHA[j] - be;
-                if (vl) { q0 += co * LS[(sl * N + lane) * 2]; q1 += co * LS[(sl * N + lane) * 2 + 1]; }
+            if (LBG) {
+                // pairs come from the workspace record: pair j+1 is requested before pair j is consumed
+                auto pair_at = [&](const double* base, int sl) -> double2 {
+                    return vl ? *reinterpret_cast<const double2*>(base + (sl * N + lane) * 2) : make_double2(0.0, 0.0);
+                };
+                double2 sc = make_double2(0.0, 0.0), yc = sc;
+                if (lb_active > 0) { sc = pair_at(LS, lb_head); yc = pair_at(LY, lb_head); }
+                for (int j = 0; j < lb_active; ++j) {
+                    const int sl = (lb_head + j) % mem;
+                    double2 sn = sc, yn = yc;
+                    if (j + 1 < lb_active) { const int nx = (lb_head + j + 1) % mem; sn = pair_at(LS, nx); yn = pair_at(LY, nx); }
+                    const double al = LRHO[sl] * dot2r<RV>(sc.x, sc.y, q0, q1);
+                    if (lane == 0) LALPHA[j] = al;
+                    q0 -= al * yc.x; q1 -= al * yc.y;
+                    sc = sn; yc = yn;  // after the last step (sc, yc) still hold pair lb_active-1
+                }
+                wave_sync();
+                if (lb_active > 0) { q0 *= lb_gamma; q1 *= lb_gamma; }
+                for (int j = lb_active - 1; j >= 0; --j) {
+                    const int sl = (lb_head + j) % mem;
+                    double2 sp = sc, yp = yc;
+                    if (j > 0) { const int pv = (lb_head + j - 1) % mem; sp = pair_at(LS, pv); yp = pair_at(LY, pv); }
+                    const double be = LRHO[sl] * dot2r<RV>(yc.x, yc.y, q0, q1);
+                    const double co = LALPHA[j] - be;
+                    q0 += co * sc.x; q1 += co * sc.y;
+                    sc = sp; yc = yp;
+                }
+            } else {
+                for (int j = 0; j < lb_active; ++j) {
+                    const int sl = (lb_head + j) % mem;
+                    const double sj0 = vl ? LS[(sl * N + lane) * 2] : 0.0, sj1 = vl ? LS[(sl * N + lane) * 2 + 1] : 0.0;
+                    const double al = LRHO[sl] * dot2r<RV>(sj0, sj1, q0, q1);
+                    if (lane == 0) LALPHA[j] = al;
+                    if (vl) { q0 -= al * LY[(sl * N + lane) * 2]; q1 -= al * LY[(sl * N + lane) * 2 + 1]; }
+                }
+                wave_sync();
+                if (lb_active > 0) { q0 *= lb_gamma; q1 *= lb_gamma; }
+                for (int j = lb_active - 1; j >= 0; --j) {
+                    const int sl = (lb_head + j) % mem;
+                    const double yj0 = vl ? LY[(sl * N + lane) * 2] : 0.0, yj1 = vl ? LY[(sl * N + lane) * 2 + 1] : 0.0;
+                    const double be = LRHO[sl] * dot2r<RV>(yj0, yj1, q0, q1);
+                    const double co = LALPHA[j] - be;
+                    if (vl) { q0 += co * LS[(sl * N + lane) * 2]; q1 += co * LS[(sl * N + lane) * 2 + 1]; }
+                }
             }
             dv = q0; dw = q1;
             // ---- line search on the forward-backward envelope
@@ -1024,7 +1095,7 @@ __global__ __launch_bounds__(WAVE, MPC_MIN_WAVES) void solve_kernel_pair(KParams
             akkt_tol = uniform(fmax(akkt_tol * kp.tol_update, kp.tol));
             ++alm_iteration; ++num_outer;
             dy_norm = dy_norm_plus; f2_norm = f2_norm_plus;
-            ya = fmin(fmax(ypa, -1e12), 1e12); yb = fmin(fmax(ypb, -1e12), 1e12);  // y <- Proj_Y(y+)
+            ya = clampd(ypa, -KTAB[K_YBOUND], KTAB[K_YBOUND]); yb = clampd(ypb, -KTAB[K_YBOUND], KTAB[K_YBOUND]);  // y <- Proj_Y(y+)
             // reset the PANOC cache for the next inner problem
             lb_active = 0; lb_first = true; tau = 1.0; Lip = 0; sigma = 0; gamma = 0; iter = 0;
             num_iter = 0; cont_iters = true; cont_time = true;

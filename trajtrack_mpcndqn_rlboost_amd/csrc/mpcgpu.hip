@@ -66,6 +66,13 @@ int ensure(Handle* h, DevBuf& b, size_t bytes) {
 
 inline int even(int x) { return (x + 1) & ~1; }
 
+// Where the L-BFGS memory (2 x 10 x 2N doubles per problem) lives.  true: in the problem's workspace record (HBM,
+// L2-resident while the solve runs), which frees 6.4 KB of LDS per wavefront at N = 20; false: in LDS.
+#ifndef MPC_LBFGS_IN_WORKSPACE
+#define MPC_LBFGS_IN_WORKSPACE 1
+#endif
+constexpr bool LBFGS_IN_WORKSPACE = MPC_LBFGS_IN_WORKSPACE != 0;
+
 void fill_static_params(Handle* h) {
     const mpcgpu_config& c = h->cfg;
     KParams& k = h->kp;
@@ -96,13 +103,15 @@ void fill_static_params(Handle* h) {
     k.ws_stc = o; o += c.Nstcobs * STCW;
     k.ws_fxy = o; o += c.Nother * N * 2;
     k.ws_dyn = o; o += even(c.Ndynobs * N * DYNW);
+    k.ws_lbs = o; o += c.lbfgs_mem * N * 2;   // L-BFGS memory when it is kept in the workspace (see LBFGS_IN_WORKSPACE)
+    k.ws_lby = o; o += c.lbfgs_mem * N * 2;
     k.ws_stride = (o + 15) & ~15;
 }
 
 // LDS carve for the batch maxima (doubles; every offset even => 16-byte aligned).
 // shape_const: every active dynamic row of the batch keeps (rx, ry, angle) over the horizon -> 3 doubles per
 // (row, step) + 6 per row instead of 9 per (row, step).
-void fill_lds_layout(KParams& k, int mKs, int mKf, int mKd, bool shape_const) {
+void fill_lds_layout(KParams& k, int mKs, int mKf, int mKd, bool shape_const, bool lbfgs_in_lds) {
     const int N = k.N;
     k.mKs = mKs; k.mKf = mKf; k.mKd = mKd;
     int o = 0;
@@ -117,13 +126,17 @@ void fill_lds_layout(KParams& k, int mKs, int mKf, int mKd, bool shape_const) {
         k.l_dync = k.l_dyn;
     }
     k.l_pos = o; o += N * 2;
+    k.l_stash = o; o += N * 6;
     // H (hinge matrix, read right after it is written) and the item-lane partials are never live together:
     // LDS operations of the single wave execute in order, so they share one region
     const int h_sz = even(mKd * N) + even(mKd), part_sz = even(k.LPS * N * PARTW);
     k.l_H = o; k.l_W = o + even(mKd * N); k.l_part = o;
     o += h_sz > part_sz ? h_sz : part_sz;
-    k.l_S = o; o += k.mem * N * 2;
-    k.l_Y = o; o += k.mem * N * 2;
+    k.l_S = k.l_Y = o;
+    if (lbfgs_in_lds) {
+        k.l_S = o; o += k.mem * N * 2;
+        k.l_Y = o; o += k.mem * N * 2;
+    }
     k.l_rho = o; o += even(k.mem);
     k.l_alpha = o; o += even(k.mem);
     k.l_old = o; o += N * 4;
@@ -146,7 +159,7 @@ int prepare(Handle* h, int B, const double* d_p, hipStream_t s, BatchPtrs& io) {
     HIP_OK(h, hipStreamSynchronize(s));
     const int mKs = h->h_counts[CNT_KS], mKf = h->h_counts[CNT_KF], mKd = h->h_counts[CNT_KD];
     h->shape_const = h->h_counts[CNT_VARSHAPE] == 0;
-    fill_lds_layout(h->kp, mKs, mKf, mKd, h->shape_const);
+    fill_lds_layout(h->kp, mKs, mKf, mKd, h->shape_const, !LBFGS_IN_WORKSPACE);
     const int lds_bytes = h->kp.l_total * (int)sizeof(double);
     h->last_shape[0] = mKs; h->last_shape[1] = mKf; h->last_shape[2] = mKd; h->last_shape[3] = lds_bytes;
     if (lds_bytes > 160 * 1024) return fail(h, -5, "LDS carve of %d bytes exceeds 160 KiB", lds_bytes);
@@ -253,7 +266,7 @@ int32_t mpcgpu_solve_batch_dev(void* handle, int32_t B, const double* p, const d
     io.outer_it = outer_it; io.fpr = fpr; io.f2norm = f2norm; io.y_out = y_out; io.ms = ms;
     HIP_OK(h, hipEventRecord(h->ev[2], s));
     const size_t lds = h->kp.l_total * sizeof(double);
-#define LAUNCH_PAIR(NT, SC) hipLaunchKernelGGL((solve_kernel_pair<NT, SC>), dim3(B), dim3(WAVE), lds, s, h->kp, io, B)
+#define LAUNCH_PAIR(NT, SC) hipLaunchKernelGGL((solve_kernel_pair<NT, SC, LBFGS_IN_WORKSPACE>), dim3(B), dim3(WAVE), lds, s, h->kp, io, B)
     // compile-time horizons for the configurations the reference uses (generic kernel otherwise) x
     // {shape-constant, general} dynamic-obstacle tables
     const bool sc = h->shape_const;
