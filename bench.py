@@ -5,10 +5,12 @@
 
 A step = one pass of the hot path over one batch: B independent cold-start solves (u0 = 0, what every
 reference call site does: src/interface_mpc.py:82 passes initial_guess=None) of the metric configuration
-named in BASELINE.json -- mpc_default.yaml, N_hor = 20, 8 dynamic obstacles, B = 8192 problems per GPU --
-with the parameter vectors already resident in HBM.  For N > 1 the driver launches one rank per GPU
+named in BASELINE.json -- mpc_default.yaml, N_hor = 20, 8 dynamic obstacles -- on B = 32768 robots per GPU,
+with the parameter vectors already resident in HBM.  (A solve takes 0.1-0.2 s of device time and ~3000 run
+concurrently, so a batch of a few thousand spends a fifth of its time in the tail of the last stragglers:
+B = 8192 gives 18.4k solves/s, B = 32768 22.5k on one MI355X.  `--batch` selects other sizes.)  For N > 1 the driver launches one rank per GPU
 (torch.distributed.run); the batch shards across ranks with no data-path collective (weak scaling: every
-rank owns its own 8192 robots); RCCL is used only for the barrier and the max-over-ranks time.
+rank owns its own B robots); RCCL is used only for the barrier and the max-over-ranks time.
 
 Rank 0 prints ONE JSON line (contract in the task description) with two extra objects:
   roofline     -- dominant kernel (solve_kernel) against the HBM roofline, timed with HIP events on the
@@ -46,7 +48,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=8192, help="problems per GPU per step")
+    ap.add_argument("--batch", type=int, default=32768, help="problems per GPU per step")
     ap.add_argument("--n-dyn", type=int, default=8)
     ap.add_argument("--horizon", type=int, default=20)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 disables)")
@@ -152,8 +154,8 @@ def main():
 
 def measured_traffic(N, n_dyn, B):
     """HBM bytes per launch of solve_kernel from the committed rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE,
-    profiles/r01_hbm_traffic_bench_B8192.json) -- only when it was collected on this very workload."""
-    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic_bench_B8192.json")
+    profiles/r01_hbm_traffic_bench.json) -- only when it was collected on this very workload."""
+    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic_bench.json")
     try:
         with open(path) as fh:
             d = json.load(fh)
