@@ -59,7 +59,9 @@ constexpr int PARTW = 5;       // doubles per item-lane partial  (gx, gy, best, 
 constexpr int MAX_MEM = 16;
 constexpr int SEG_WIN = 2;     // reference segments per item lane that are evaluated unconditionally
 
-// header slots (doubles)
+// header slots (doubles); 0..17 are p[0..17] of the reference layout
+enum { H_X0 = 0, H_Y0 = 1, H_TH0 = 2, H_XG = 3, H_YG = 4, H_THG = 5, H_VINIT = 6, H_WINIT = 7, H_QVEL = 9, H_RV = 11, H_RW = 12,
+       H_QN = 13, H_QTHN = 14, H_QRPD = 15, H_ACC = 16, H_WACC = 17 };
 enum { H_KS = 18, H_KF = 19, H_KD = 20, H_CTH0 = 21, H_STH0 = 22, H_NPF = 23, H_NPD = 24, H_ENTRY = 26 /* .. +Ndynobs */ };
 // batch-wide reductions written by the compaction kernel
 enum { CNT_KS = 0, CNT_KF = 1, CNT_KD = 2, CNT_VARSHAPE = 3 };
@@ -78,7 +80,7 @@ struct KParams {
     int ws_stride, ws_vref, ws_seg, ws_stc, ws_fxy, ws_dyn, ws_lbs, ws_lby;
     // LDS layout (doubles), strides use the batch maxima mKs/mKf/mKd
     int mKs, mKf, mKd;
-    int l_seg, l_stc, l_fxy, l_dyn, l_dync, l_pos, l_H, l_W, l_part, l_stash, l_S, l_Y, l_rho, l_alpha, l_old, l_total;
+    int l_seg, l_stc, l_fxy, l_dyn, l_dync, l_pos, l_H, l_W, l_part, l_stash, l_hd, l_S, l_Y, l_rho, l_alpha, l_old, l_total;
 };
 
 // lanes per step for the item phase
@@ -235,11 +237,11 @@ enum { K_SIXTH = 12, K_REACH = 13, K_SQRT = 14, K_SMALL = 15, K_IPAD = 16, K_GAM
        K_MAX_LIP = 20, K_MIN_L = 21, K_EPS = 22, K_DBLMIN = 23, K_CBFGS = 24, K_YBOUND = 25, K_SIGMA = 26 };
 
 // sin / cos on [-pi/4, pi/4] (fdlibm kernel polynomials, error < 1 ulp there)
-__device__ __forceinline__ void sincos_small(double x, double& s, double& c) {
+__device__ __forceinline__ void sincos_small(double x, const double* k, double& s, double& c) {
     const double z = x * x;
-    const double ps = KTAB[0] + z * (KTAB[1] + z * (KTAB[2] + z * (KTAB[3] + z * (KTAB[4] + z * KTAB[5]))));
+    const double ps = k[0] + z * (k[1] + z * (k[2] + z * (k[3] + z * (k[4] + z * k[5]))));
     s = x + x * z * ps;
-    const double pc = KTAB[6] + z * (KTAB[7] + z * (KTAB[8] + z * (KTAB[9] + z * (KTAB[10] + z * KTAB[11]))));
+    const double pc = k[6] + z * (k[7] + z * (k[8] + z * (k[9] + z * (k[10] + z * k[11]))));
     c = 1.0 - 0.5 * z + z * z * pc;
 }
 
@@ -378,10 +380,11 @@ __global__ __launch_bounds__(WAVE) void prep_kernel(KParams kp, BatchPtrs io, in
 // per-wave problem context
 // ------------------------------------------------------------------------------------------------
 struct Ctx {
-    // uniform problem scalars
-    double x0, y0, th0, cth0, sth0, xg, yg, thg, v_init, w_init;
-    double qvel, rv, rw, qN, qthN, qrpd, acc_pen, wacc_pen;
-    double npf, npd;  // multiplicities of the zero-padded other-robot / dynamic-obstacle rows
+    // The problem header (state, goal, weights, theta_0 phasor, padding multiplicities) and the table of f64
+    // literals are kept in LDS and read where they are used: as SGPR residents they overflowed the scalar file and
+    // every spilled access became a v_readlane on the (saturated) VALU.
+    const double* hd;   // [64]: header slots H_*, then KTAB at KC_BASE
+    bool pad_f, pad_d, terminal;  // any zero-padded other-robot / dynamic rows; non-zero terminal weights
     int Ks, Kf, Kd;
     // lane roles
     int lane, ik, isub;
@@ -390,6 +393,9 @@ struct Ctx {
     // LDS tables
     double *seg, *stc, *fxy, *dyn, *dync, *pos, *H, *W, *part, *stash;
 };
+constexpr int KC_BASE = 32;
+#define KC(i) (cx.hd[KC_BASE + (i)])
+#define HD(i) (cx.hd[(i)])
 
 struct EvalOut {
     double psi;             // uniform
@@ -410,16 +416,14 @@ __device__ __forceinline__ void load_problem(const KParams& kp, const double* __
     cx.il = lane < N * LPS;
     cx.ik = lane % N;
     cx.isub = lane / N;
-    // uniform header values: force them into SGPRs (a plain load of a uniform address is otherwise issued as
-    // a vector load and each value then occupies two VGPRs for the whole solve)
+    double* hd = lds + kp.l_hd;
+    if (lane < KC_BASE) hd[lane] = ws[lane];
+    if (lane < 27) hd[KC_BASE + lane] = KTAB[lane];
+    cx.hd = hd;
     auto U = [&](int i) { return uniform(ws[i]); };
-    cx.x0 = U(0); cx.y0 = U(1); cx.th0 = U(2); cx.xg = U(3); cx.yg = U(4); cx.thg = U(5);
-    cx.v_init = U(6); cx.w_init = U(7);
-    cx.qvel = U(9); cx.rv = U(11); cx.rw = U(12); cx.qN = U(13); cx.qthN = U(14); cx.qrpd = U(15);
-    cx.acc_pen = U(16); cx.wacc_pen = U(17);
     cx.Ks = (int)U(H_KS); cx.Kf = (int)U(H_KF); cx.Kd = (int)U(H_KD);
-    cx.cth0 = U(H_CTH0); cx.sth0 = U(H_STH0);
-    cx.npf = U(H_NPF); cx.npd = U(H_NPD);
+    cx.pad_f = U(H_NPF) > 0.0; cx.pad_d = U(H_NPD) > 0.0;
+    cx.terminal = U(H_QN) != 0.0 || U(H_QTHN) != 0.0;
     cx.vref = cx.vl ? ws[kp.ws_vref + lane] : 0.0;
     cx.seg = lds + kp.l_seg; cx.stc = lds + kp.l_stc; cx.fxy = lds + kp.l_fxy;
     cx.dyn = lds + kp.l_dyn; cx.dync = lds + kp.l_dync; cx.pos = lds + kp.l_pos; cx.H = lds + kp.l_H;
@@ -489,34 +493,34 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     double c0, s0, cm, sm, c2, s2;
     {
         const double hd = 0.5 * ts * w;  // half-step heading increment
-        const bool small = __ballot(fabs(hd) > KTAB[K_SMALL]) == 0ull;
+        const bool small = __ballot(fabs(hd) > KC(K_SMALL)) == 0ull;
         if (small) {
             double sh, ch;
-            sincos_small(hd, sh, ch);
+            sincos_small(hd, cx.hd + KC_BASE, sh, ch);
             double er = ch * ch - sh * sh, ei = 2.0 * sh * ch;  // e^{i ts w_k}
             scan_cprod<RV>(er, ei);                               // prod_{j<=k} e^{i ts w_j}
-            c2 = cx.cth0 * er - cx.sth0 * ei;                      // heading k+1
-            s2 = cx.cth0 * ei + cx.sth0 * er;
-            c0 = shift_up1(c2, lane, cx.cth0);
-            s0 = shift_up1(s2, lane, cx.sth0);
+            c2 = HD(H_CTH0) * er - HD(H_STH0) * ei;                      // heading k+1
+            s2 = HD(H_CTH0) * ei + HD(H_STH0) * er;
+            c0 = shift_up1(c2, lane, HD(H_CTH0));
+            s0 = shift_up1(s2, lane, HD(H_STH0));
             cm = c0 * ch - s0 * sh;
             sm = c0 * sh + s0 * ch;
         } else {  // a trial point far outside the input box: plain sincos of the summed angles
             const double tw = ts * w;
-            const double th1 = cx.th0 + scan_prefix<RV>(tw);
+            const double th1 = HD(H_TH0) + scan_prefix<RV>(tw);
             sincos(th1 - 0.5 * tw, &sm, &cm);
             sincos(th1, &s2, &c2);
-            c0 = shift_up1(c2, lane, cx.cth0);
-            s0 = shift_up1(s2, lane, cx.sth0);
+            c0 = shift_up1(c2, lane, HD(H_CTH0));
+            s0 = shift_up1(s2, lane, HD(H_STH0));
         }
     }
     PROF_MARK(0);  // headings
-    const double sixth = KTAB[K_SIXTH];
+    const double sixth = KC(K_SIXTH);
     {
     const double Cx = (c0 + 4.0 * cm + c2) * sixth, Sy = (s0 + 4.0 * sm + s2) * sixth;
     const double dCw = -ts * (2.0 * sm + s2) * sixth, dSw = ts * (2.0 * cm + c2) * sixth;
-    const double X = cx.x0 + scan_prefix<RV>(c_vl ? ts * v * Cx : 0.0);
-    const double Y = cx.y0 + scan_prefix<RV>(c_vl ? ts * v * Sy : 0.0);
+    const double X = HD(H_X0) + scan_prefix<RV>(c_vl ? ts * v * Cx : 0.0);
+    const double Y = HD(H_Y0) + scan_prefix<RV>(c_vl ? ts * v * Sy : 0.0);
     if (c_vl) {
         cx.pos[2 * lane] = X; cx.pos[2 * lane + 1] = Y;
         // rollout quantities needed again only after the item phase (per-step terms, adjoint): parked in LDS so
@@ -561,9 +565,9 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         //     if that circle is farther than sqrt(best) for every lane, nobody evaluates them
         bool more = false;
         if (i < N) {
-            sb = sqrt(best) * KTAB[K_SQRT];
+            sb = sqrt(best) * KC(K_SQRT);
             const double* sg = cx.seg + SEGW * (k + SEG_WIN * LPS);
-            const double bx = px - sg[8], by = py - sg[9], reach = (sb + sg[10]) * KTAB[K_REACH];
+            const double bx = px - sg[8], by = py - sg[9], reach = (sb + sg[10]) * KC(K_REACH);
             more = bx * bx + by * by < reach * reach;
         }
         if (__ballot(more) != 0ull) {
@@ -571,7 +575,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
             MPC_ITEM_LOOP
             for (; i < N; i += LPS) {
                 const double* sg = cx.seg + SEGW * i;
-                const double mx = px - sg[5], my = py - sg[6], reach = (sb + sg[7]) * KTAB[K_REACH];
+                const double mx = px - sg[5], my = py - sg[6], reach = (sb + sg[7]) * KC(K_REACH);
                 if (mx * mx + my * my < reach * reach) {
                     const double s1x = sg[0], s1y = sg[1], dx = sg[2], dy = sg[3], inv = sg[4];
                     const double th = ((px - s1x) * dx + (py - s1y) * dy) * inv;
@@ -580,7 +584,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
                     const double d2 = wx * wx + wy * wy;
                     if (d2 < best) {
                         best = d2;
-                        sb = sqrt(d2) * KTAB[K_SQRT];
+                        sb = sqrt(d2) * KC(K_SQRT);
                         const double wd = (th >= 0.0 && th <= 1.0) ? (wx * dx + wy * dy) * inv : 0.0;
                         bgx = 2.0 * (wd * dx - wx);
                         bgy = 2.0 * (wd * dy - wy);
@@ -645,12 +649,12 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     double hp = 0.0, r2o = 0.0;
     if (c_vl) {
         r2o = X * X + Y * Y;
-        if (cx.npf > 0.0) {
+        if (cx.pad_f) {
             const double hh = kp.W2 - r2o;
-            if (hh > 0.0) cost_l += kp.fleetw * cx.npf * hh;  // its gradient is added on the vector lanes below
+            if (hh > 0.0) cost_l += kp.fleetw * HD(H_NPF) * hh;  // its gradient is added on the vector lanes below
         }
-        if (cx.npd > 0.0) {
-            const double ipad = KTAB[K_IPAD];
+        if (cx.pad_d) {
+            const double ipad = KC(K_IPAD);
             hp = fmax(0.0, 1.0 - X * X * ipad - Y * Y * ipad);
         }
     }
@@ -669,7 +673,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
             for (int k = 0; k < N; ++k) D += cx.H[lane * N + k];
         F2e = S + D;
     }
-    const double F2pad = cx.npd > 0.0 ? S + (any_hp ? wave_sum_u<RV>(hp) : 0.0) : 0.0;
+    const double F2pad = cx.pad_d ? S + (any_hp ? wave_sum_u<RV>(hp) : 0.0) : 0.0;
     const bool viol = any_S || any_h || any_hp;  // some penalty constraint is violated
     out.F2e = F2e;
     out.F2pad = F2pad;
@@ -678,7 +682,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     // ---- item phase B (only when some penalty constraint is violated): weighted hard-constraint gradients
     double Gpx = 0.0, Gpy = 0.0;  // vector lanes: gradient of the padded-row terms w.r.t. the position
     if (want_grad && viol) {
-        const double sumF2 = wave_sum_u<2>(F2e) + cx.npd * F2pad;
+        const double sumF2 = wave_sum_u<2>(F2e) + HD(H_NPD) * F2pad;
         if (lane < cx.Kd) cx.W[lane] = c * F2e;
         wave_sync();
         if (c_il) {
@@ -699,8 +703,8 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
             gy += c * sumF2 * dsy;
         }
         if (any_hp && hp > 0.0) {  // a = X, b = -Y for the padded ellipse (cosA = 1, sinA = 0)
-            const double ipad = KTAB[K_IPAD];
-            const double wpad = c * cx.npd * F2pad;
+            const double ipad = KC(K_IPAD);
+            const double wpad = c * HD(H_NPD) * F2pad;
             Gpx = wpad * (-2.0 * X * ipad);
             Gpy = wpad * (-2.0 * Y * ipad);
         }
@@ -721,11 +725,11 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
             Gx += pp[0]; Gy += pp[1];
             if (pp[2] < bb) { bb = pp[2]; wbx = pp[3]; wby = pp[4]; }
         }
-        Gx += cx.qrpd * wbx; Gy += cx.qrpd * wby;
-        vcost = cx.qrpd * bb;
-        if (cx.npf > 0.0 && kp.W2 - r2o > 0.0) {
-            Gx -= 2.0 * kp.fleetw * cx.npf * X;
-            Gy -= 2.0 * kp.fleetw * cx.npf * Y;
+        Gx += HD(H_QRPD) * wbx; Gy += HD(H_QRPD) * wby;
+        vcost = HD(H_QRPD) * bb;
+        if (cx.pad_f && kp.W2 - r2o > 0.0) {
+            Gx -= 2.0 * kp.fleetw * HD(H_NPF) * X;
+            Gy -= 2.0 * kp.fleetw * HD(H_NPF) * Y;
         }
     }
 
@@ -733,7 +737,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     // ---- per-step terms on the vector lanes (mpc_generator.py:208-209,246,254-267)
     v = 0.0; w = 0.0;
     if (c_vl) { v = cx.stash[lane * 6 + 4]; w = cx.stash[lane * 6 + 5]; }
-    const double vprev = shift_up1(v, lane, cx.v_init), wprev = shift_up1(w, lane, cx.w_init);
+    const double vprev = shift_up1(v, lane, HD(H_VINIT)), wprev = shift_up1(w, lane, HD(H_WINIT));
     const double a = c_vl ? (v - vprev) * kp.inv_ts : 0.0;
     const double bacc = c_vl ? (w - wprev) * kp.inv_ts : 0.0;
     out.F1a = a; out.F1b = bacc;
@@ -744,15 +748,15 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     double gthN = 0.0;
     if (c_vl) {
         const double dv = v - cx.vref;
-        vcost += cx.qvel * dv * dv + cx.rv * v * v + cx.rw * w * w + cx.acc_pen * a * a + cx.wacc_pen * bacc * bacc;
+        vcost += HD(H_QVEL) * dv * dv + HD(H_RV) * v * v + HD(H_RW) * w * w + HD(H_ACC) * a * a + HD(H_WACC) * bacc * bacc;
     }
-    if (cx.qN != 0.0 || cx.qthN != 0.0) {  // terminal cost (weights are 0 in the reference's yaml)
-        const double thN = cx.th0 + wave_sum_u<RV>(ts * w);
+    if (cx.terminal) {  // terminal cost (weights are 0 in the reference's yaml)
+        const double thN = HD(H_TH0) + wave_sum_u<RV>(ts * w);
         if (lane == N - 1) {
-            const double ex = X - cx.xg, ey = Y - cx.yg, et = thN - cx.thg;
-            vcost += cx.qN * (ex * ex + ey * ey) + cx.qthN * et * et;
-            Gx += 2.0 * cx.qN * ex; Gy += 2.0 * cx.qN * ey;
-            gthN = 2.0 * cx.qthN * et;
+            const double ex = X - HD(H_XG), ey = Y - HD(H_YG), et = thN - HD(H_THG);
+            vcost += HD(H_QN) * (ex * ex + ey * ey) + HD(H_QTHN) * et * et;
+            Gx += 2.0 * HD(H_QN) * ex; Gy += 2.0 * HD(H_QN) * ey;
+            gthN = 2.0 * HD(H_QTHN) * et;
         }
         gthN = readlane_d(gthN, N - 1);
     }
@@ -760,7 +764,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     // (item lanes: stage costs; vector lanes: per-step costs + box distance; lanes < Kd: their F2 entry)
     const double dist_l = c_vl ? ea * ea + eb * eb : 0.0;
     const double f2_l = viol ? F2e * F2e : 0.0;
-    const double pad2 = viol ? cx.npd * F2pad * F2pad : 0.0;
+    const double pad2 = viol ? HD(H_NPD) * F2pad * F2pad : 0.0;
     out.psi = wave_sum_u<RI>(cost_l + vcost + 0.5 * c * (dist_l + f2_l)) + 0.5 * c * pad2;
     if (want_f) {  // f and ||F2||^2 on their own (outer loop, test hook): two more reductions
         out.f = wave_sum_u<RI>(cost_l + vcost);
@@ -769,11 +773,11 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
 
     PROF_MARK(8);  // vector terms + psi
     if (want_grad) {
-        const double da = c_vl ? (2.0 * cx.acc_pen * a + c * ea) * kp.inv_ts : 0.0;
-        const double db = c_vl ? (2.0 * cx.wacc_pen * bacc + c * eb) * kp.inv_ts : 0.0;
+        const double da = c_vl ? (2.0 * HD(H_ACC) * a + c * ea) * kp.inv_ts : 0.0;
+        const double db = c_vl ? (2.0 * HD(H_WACC) * bacc + c * eb) * kp.inv_ts : 0.0;
         const double da_n = shift_down1(da), db_n = shift_down1(db);
-        double gv = 2.0 * cx.qvel * (v - cx.vref) + 2.0 * cx.rv * v + da - da_n;
-        double gw = 2.0 * cx.rw * w + db - db_n;
+        double gv = 2.0 * HD(H_QVEL) * (v - cx.vref) + 2.0 * HD(H_RV) * v + da - da_n;
+        double gw = 2.0 * HD(H_RW) * w + db - db_n;
         // adjoint of the rollout: suffix sums instead of a serial backward sweep
         double Cx = 0.0, Sy = 0.0, dCw = 0.0, dSw = 0.0;
         if (c_vl) { const double* st = cx.stash + lane * 6; Cx = st[0]; Sy = st[1]; dCw = st[2]; dSw = st[3]; }
@@ -867,9 +871,15 @@ __global__ __launch_bounds__(WAVE, MPC_MIN_WAVES) void solve_kernel_pair(KParams
     const bool vl = cx.vl;
 
     // PANOC constants [OpEn]
-    const double GAMMA_L_COEFF = KTAB[K_GAMMA_L], DELTA_LIP = KTAB[K_DELTA_LIP], EPS_LIP = KTAB[K_EPS_LIP],
-                 LIP_UPD_EPS = KTAB[K_EPS_LIP];
-    const double MAX_LIP = KTAB[K_MAX_LIP], MIN_L = KTAB[K_MIN_L], SMALL_EPS = KTAB[K_EPS], DBLMIN = KTAB[K_DBLMIN];
+    // (each use reads the literal from the LDS table; a local copy would live in two VGPRs across the whole loop)
+#define GAMMA_L_COEFF KC(K_GAMMA_L)
+#define DELTA_LIP KC(K_DELTA_LIP)
+#define EPS_LIP KC(K_EPS_LIP)
+#define LIP_UPD_EPS KC(K_EPS_LIP)
+#define MAX_LIP KC(K_MAX_LIP)
+#define MIN_L KC(K_MIN_L)
+#define SMALL_EPS KC(K_EPS)
+#define DBLMIN KC(K_DBLMIN)
     const int MAX_LIP_IT = 10, MAX_LS_IT = 10;
 
     // decision vector and multipliers (vector lanes; zeros elsewhere)
@@ -882,7 +892,7 @@ __global__ __launch_bounds__(WAVE, MPC_MIN_WAVES) void solve_kernel_pair(KParams
     double c = kp.init_penalty;
     if (io.c0) { const double c0 = io.c0[b]; if (c0 > 0.0) c = c0; }
     c = uniform(c);
-    ya = clampd(ya, -KTAB[K_YBOUND], KTAB[K_YBOUND]); yb = clampd(yb, -KTAB[K_YBOUND], KTAB[K_YBOUND]);  // y <- Proj_Y(y), Y = [-1e12, 1e12]^n1
+    ya = clampd(ya, -KC(K_YBOUND), KC(K_YBOUND)); yb = clampd(yb, -KC(K_YBOUND), KC(K_YBOUND));  // y <- Proj_Y(y), Y = [-1e12, 1e12]^n1
     // PANOC cache: vector state u, grad, u_half, gamma*fpr, direction (2 doubles per vector lane each);
     // ||grad||^2 and ||gradient_step - u_half||^2 are carried as scalars (they only enter the envelope)
     double gv = 0, gw = 0, hv = 0, hw = 0, rv_ = 0, rw_ = 0, dv = 0, dw = 0;
@@ -932,7 +942,7 @@ __global__ __launch_bounds__(WAVE, MPC_MIN_WAVES) void solve_kernel_pair(KParams
             const double d0 = o.gv - gv, d1 = o.gw - gw;
             Lip = uniform(sqrt(dot2r<RV>(d0, d1, d0, d1)) / nh);
             gamma = uniform(GAMMA_L_COEFF / fmax(Lip, MIN_L));
-            sigma = uniform(KTAB[K_SIGMA] / gamma);
+            sigma = uniform(KC(K_SIGMA) / gamma);
             gg = dot2r<RV>(gv, gw, gv, gw);
             d2h = half_step(uv, uw);
             step_begin = true;
@@ -950,7 +960,7 @@ __global__ __launch_bounds__(WAVE, MPC_MIN_WAVES) void solve_kernel_pair(KParams
                 ev = hv; ew = hw; want_grad = false;
                 continue;
             }
-            sigma = uniform(KTAB[K_SIGMA] / gamma);
+            sigma = uniform(KC(K_SIGMA) / gamma);
             // ---- L-BFGS buffer update with (state = u, g = gamma*fpr)   [crate lbfgs: C-BFGS acceptance]
             if (lb_first) {
                 lb_first = false;
@@ -962,7 +972,7 @@ __global__ __launch_bounds__(WAVE, MPC_MIN_WAVES) void solve_kernel_pair(KParams
                     y0_ = rv_ - LOLD[lane * 4 + 2]; y1_ = rw_ - LOLD[lane * 4 + 3];
                 }
                 const double ys = dot2r<RV>(s0, s1, y0_, y1_), ss = dot2r<RV>(s0, s1, s0, s1);
-                if (!(ss <= DBLMIN || ys <= KTAB[K_MIN_L]) && (ys / ss > KTAB[K_CBFGS] * nfpr)) {
+                if (!(ss <= DBLMIN || ys <= KC(K_MIN_L)) && (ys / ss > KC(K_CBFGS) * nfpr)) {
                     lb_head = (lb_head + mem - 1) % mem;
                     if (vl) {
                         LOLD[lane * 4] = uv; LOLD[lane * 4 + 1] = uw; LOLD[lane * 4 + 2] = rv_; LOLD[lane * 4 + 3] = rw_;
@@ -1095,7 +1105,7 @@ __global__ __launch_bounds__(WAVE, MPC_MIN_WAVES) void solve_kernel_pair(KParams
             akkt_tol = uniform(fmax(akkt_tol * kp.tol_update, kp.tol));
             ++alm_iteration; ++num_outer;
             dy_norm = dy_norm_plus; f2_norm = f2_norm_plus;
-            ya = clampd(ypa, -KTAB[K_YBOUND], KTAB[K_YBOUND]); yb = clampd(ypb, -KTAB[K_YBOUND], KTAB[K_YBOUND]);  // y <- Proj_Y(y+)
+            ya = clampd(ypa, -KC(K_YBOUND), KC(K_YBOUND)); yb = clampd(ypb, -KC(K_YBOUND), KC(K_YBOUND));  // y <- Proj_Y(y+)
             // reset the PANOC cache for the next inner problem
             lb_active = 0; lb_first = true; tau = 1.0; Lip = 0; sigma = 0; gamma = 0; iter = 0;
             num_iter = 0; cont_iters = true; cont_time = true;
@@ -1158,5 +1168,14 @@ __global__ __launch_bounds__(WAVE, MPC_MIN_WAVES) void solve_kernel_pair(KParams
     }
 }
 
+
+#undef GAMMA_L_COEFF
+#undef DELTA_LIP
+#undef EPS_LIP
+#undef LIP_UPD_EPS
+#undef MAX_LIP
+#undef MIN_L
+#undef SMALL_EPS
+#undef DBLMIN
 
 }  // namespace mpcgpu

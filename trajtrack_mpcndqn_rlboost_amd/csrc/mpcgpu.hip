@@ -127,6 +127,7 @@ void fill_lds_layout(KParams& k, int mKs, int mKf, int mKd, bool shape_const, bo
     }
     k.l_pos = o; o += N * 2;
     k.l_stash = o; o += N * 6;
+    k.l_hd = o; o += 64;
     // H (hinge matrix, read right after it is written) and the item-lane partials are never live together:
     // LDS operations of the single wave execute in order, so they share one region
     const int h_sz = even(mKd * N) + even(mKd), part_sz = even(k.LPS * N * PARTW);
