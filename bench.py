@@ -142,7 +142,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "solve_kernel", "kernel_ms": k_ms, "prep_kernel_ms": float(np.mean(prep_ms)),
                          "algorithmic_bytes_per_solve": algo_bytes // B,
-                         "note": "LDS-resident solver: HBM is read once per solve; the kernel is VALU-f64/latency bound"},
+                         "note": "state is register/LDS/L2 resident: the kernel is VALU-f64 issue bound, see valu_f64",
+                         "valu_f64": valu_profile()},
         }
         if args.cpu_seconds > 0 and world == 1:
             line["cpu_baseline"] = cpu_baseline(cfg, sc["p"], args.cpu_seconds)
@@ -165,6 +166,19 @@ def measured_traffic(N, n_dyn, B):
     except (OSError, KeyError, ValueError):
         pass
     return None
+
+
+def valu_profile():
+    """What actually bounds solve_kernel: VALU issue.  From the committed rocprofv3 PMC passes of the same kernel
+    (profiles/r01_final_pmc_solve_kernel_B40960.json): fraction of SIMD cycles with a VALU instruction executing."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_final_pmc_solve_kernel_B40960.json")) as fh:
+            d = json.load(fh)["derived"]
+        return {"valu_busy_frac": d["valu_busy_fraction"], "resident_waves_per_simd": d["mean_resident_waves_per_simd"],
+                "valu_instructions_per_solve": d["valu_instructions_per_solve"], "clock_GHz": d["effective_clock_GHz"],
+                "source": "profiles/r01_final_pmc_solve_kernel_B40960.json (SQ_ACTIVE_INST_VALU, SQ_WAVE_CYCLES, GRBM_GUI_ACTIVE)"}
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(cfg, p_all, budget_s):
