@@ -105,3 +105,16 @@ def test_termination_and_modes():
     assert tg.base_speed == 1.5
     with pytest.raises(ModuleNotFoundError):
         tg.set_work_mode("warp")
+
+
+def test_prediction_feeders_have_the_reference_formats():
+    """row f4: est_dyn_obs_positions (src/main.py:77-85) and the scanner tuple order
+    (src/obstacle_simulator/_obstacle_simulator.py:72-75)."""
+    from trajtrack_mpcndqn_rlboost_amd.feeders import constant_velocity_prediction, scanner_prediction
+    got = constant_velocity_prediction([9.88, 3.51], [10.0, 3.5])
+    want = np.array(est_dyn_obs_positions([9.88, 3.51], [10.0, 3.5]), dtype=float)   # the reference's own formula
+    assert got.shape == (20, 6) and np.allclose(got, want, rtol=0, atol=1e-15)
+    batch = constant_velocity_prediction(np.zeros((3, 2)), np.ones((3, 2)), steps=40)
+    assert batch.shape == (3, 40, 6) and np.allclose(batch[:, -1, 0], 41.0)
+    pred = np.array([[[0.7, 1.0, 2.0, 0.3, 0.2, 0.5]]])
+    assert np.allclose(scanner_prediction(pred, inflation_radius=0.5, factor=2.0), [[[1.0, 2.0, 1.1, 0.9, 0.5, 0.7]]])
