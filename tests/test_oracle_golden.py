@@ -113,7 +113,7 @@ def test_iteration_caps_and_status_codes():
     assert np.all(res["inner_iters"] <= 2 * 3)
 
 
-@pytest.mark.parametrize("max_inner,max_outer,tol", [(3, 1, 1e-9), (8, 2, 1e-7), (25, 3, 5e-3)])
+@pytest.mark.parametrize("max_inner,max_outer,tol", [(3, 1, 1e-9), (8, 2, 1e-7), (12, 3, 1e-4), (20, 1, 1e-4)])
 def test_c_oracle_follows_the_independent_numpy_restatement(max_inner, max_outer, tol):
     """The solver iteration cannot be pinned against OpEn itself, so it is written twice -- in C (the oracle) and in
     numpy from the algorithm statement of DESIGN.md section 3 -- and the two must agree step for step (rounding
