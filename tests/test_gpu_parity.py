@@ -412,3 +412,47 @@ def test_full_size_configurations_through_size_independent_properties(N, n_dyn, 
     if both.any():
         assert np.max(np.abs(res.solution[pick] - uo), axis=1)[both].max() <= U_TOL
     bs.close()
+
+
+@pytest.mark.parametrize("N", [2, 5, 16, 17, 21, 22, 32, 33, 48, 64])
+def test_generic_horizons_cover_every_lane_mapping(N):
+    """Horizons without a compiled specialisation run the generic kernel; the lanes-per-step split changes at
+    N = 16 / 21 / 32 and the DPP row count with it.  Cost/gradient against the oracle plus a short tracked solve."""
+    cfg = make_cfg(N)
+    ocfg = oracle_cfg(cfg)
+    bs = BatchSolver(cfg)
+    B = 12
+    n_dyn = min(6, cfg.Ndynobs)
+    if N >= 8:
+        sc = scenes.make_batch(cfg, B, n_dyn=n_dyn, n_other=2, seed=300 + N)
+        p = sc["p"]
+    else:  # scenes need a few steps of horizon for their geometry; tiny horizons get random but valid parameters
+        rng0 = np.random.default_rng(N)
+        p = np.zeros((B, cfg.num_params))
+        off = cfg.offsets()
+        p[:, 0:3] = rng0.uniform(-1, 1, (B, 3)); p[:, 8:18] = [0, 10, 0, 0.5, 0.5, 2, 1, 100, 10, 20]
+        ref = np.cumsum(np.full((B, N, 1), 0.24), axis=1) * np.array([1.0, 0.2, 0.0]) + p[:, None, 0:3] * [1, 1, 0]
+        p[:, off["r"]:off["r"] + 3 * N] = ref.reshape(B, 3 * N); p[:, 3:6] = ref[:, -1]
+        p[:, off["vref"]:off["vref"] + N] = 1.0
+        p[:, off["od"]:off["od"] + 6 * N] = np.tile([0.3, 0.1, 0.8, 0.5, 0.2, 1.0], N)
+        p[:, off["qdyn"]:off["qdyn"] + N] = 1e3
+    rng = np.random.default_rng(N)
+    u = np.stack([rng.uniform(-0.6, 1.6, (B, N)), rng.uniform(-0.6, 0.6, (B, N))], axis=2).reshape(B, 2 * N)
+    c = rng.choice([0.0, 10.0, 250.0], B)
+    y = rng.uniform(-2, 2, (B, 2 * N))
+    r = bs.cost_grad(u, p, c, y)
+    for i in range(B):
+        o = oracle.cost_grad(ocfg, u[i], p[i], float(c[i]), y[i])
+        assert _rel(r["psi"][i], o["psi"]) < RTOL_COST and _rel(r["f"][i], o["f"]) < RTOL_COST
+        assert _rel(r["grad"][i], o["grad"]) < RTOL_COST
+        assert _rel(r["F1"][i], o["F1"]) < RTOL_COST and _rel(r["F2"][i], o["F2"]) < RTOL_COST
+    bs.close()
+    cfgk = make_cfg(N, solver_max_inner_iterations=5, solver_max_outer_iterations=2)
+    bs = BatchSolver(cfgk)
+    u0 = np.tile([0.6, 0.1], (B, N))
+    res = bs.solve(p, u0)
+    uo, _, ro, _ = oracle.solve_batch(oracle_cfg(cfgk), p, u0)
+    assert np.array_equal(res.num_inner_iterations, ro["inner_iters"])
+    du = np.max(np.abs(res.solution - uo), axis=1)
+    assert np.median(du) < 1e-7 and du.max() < 1e-3      # one stiff problem may already have amplified rounding
+    bs.close()
