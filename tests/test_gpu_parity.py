@@ -456,3 +456,43 @@ def test_generic_horizons_cover_every_lane_mapping(N):
     du = np.max(np.abs(res.solution - uo), axis=1)
     assert np.median(du) < 1e-7 and du.max() < 1e-3      # one stiff problem may already have amplified rounding
     bs.close()
+
+
+def test_large_lds_carve_long_horizon_with_time_varying_obstacles():
+    """N = 64 with 15 time-varying ellipses needs > 64 KiB of LDS per wavefront (general 9-doubles-per-item tables):
+    the library opts the kernels into the larger dynamic-LDS limit.  An impossible carve is reported, not launched."""
+    N = 64
+    cfg = make_cfg(N)
+    ocfg = oracle_cfg(cfg)
+    off = cfg.offsets()
+    B = 6
+    sc = scenes.make_batch(cfg, B, n_dyn=15, n_other=3, seed=77)
+    p = sc["p"].copy()
+    od = p[:, off["od"]:off["od"] + 15 * 6 * N].reshape(B, 15, N, 6)
+    od[..., 2] = 0.5 + 0.01 * np.arange(N)
+    od[..., 4] = 0.02 * np.arange(N)
+    bs = BatchSolver(cfg)
+    rng = np.random.default_rng(1)
+    u = np.stack([rng.uniform(-0.5, 1.5, (B, N)), rng.uniform(-0.5, 0.5, (B, N))], axis=2).reshape(B, 2 * N)
+    r = bs.cost_grad(u, p, np.full(B, 10.0))
+    assert bs.last_shape()["lds_bytes"] > 64 * 1024
+    for i in range(B):
+        o = oracle.cost_grad(ocfg, u[i], p[i], 10.0)
+        assert _rel(r["psi"][i], o["psi"]) < RTOL_COST and _rel(r["grad"][i], o["grad"]) < RTOL_COST
+    bs.close()
+    cfgk = make_cfg(N, solver_max_inner_iterations=4, solver_max_outer_iterations=1)
+    bs = BatchSolver(cfgk)
+    u0 = np.tile([0.6, 0.1], (B, N))
+    res = bs.solve(p, u0)
+    uo, _, ro, _ = oracle.solve_batch(oracle_cfg(cfgk), p, u0)
+    assert np.array_equal(res.num_inner_iterations, ro["inner_iters"]) and np.max(np.abs(res.solution - uo)) < 1e-6
+    bs.close()
+    big = make_cfg(N, Ndynobs=32)
+    bs = BatchSolver(big)
+    pb = np.zeros((1, big.num_params))
+    ob = big.offsets()
+    blk = np.ones((32, N, 6)) * np.arange(1, N + 1)[None, :, None]      # every row active and time-varying
+    pb[0, ob["od"]:ob["od"] + 32 * 6 * N] = blk.reshape(-1)
+    with pytest.raises(MpcGpuError, match="LDS carve"):
+        bs.solve(pb)
+    bs.close()

@@ -267,7 +267,14 @@ int32_t mpcgpu_solve_batch_dev(void* handle, int32_t B, const double* p, const d
     io.outer_it = outer_it; io.fpr = fpr; io.f2norm = f2norm; io.y_out = y_out; io.ms = ms;
     HIP_OK(h, hipEventRecord(h->ev[2], s));
     const size_t lds = h->kp.l_total * sizeof(double);
-#define LAUNCH_PAIR(NT, SC) hipLaunchKernelGGL((solve_kernel_pair<NT, SC, LBFGS_IN_WORKSPACE>), dim3(B), dim3(WAVE), lds, s, h->kp, io, B)
+    // more than 64 KiB of dynamic LDS (long horizons with many time-varying obstacles) must be opted into per kernel
+#define LAUNCH_PAIR(NT, SC)                                                                                        \
+    do {                                                                                                             \
+        auto kern = solve_kernel_pair<NT, SC, LBFGS_IN_WORKSPACE>;                                                   \
+        if (lds > 64 * 1024)                                                                                         \
+            HIP_OK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
+        hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE), lds, s, h->kp, io, B);                                         \
+    } while (0)
     // compile-time horizons for the configurations the reference uses (generic kernel otherwise) x
     // {shape-constant, general} dynamic-obstacle tables
     const bool sc = h->shape_const;
@@ -350,10 +357,16 @@ int32_t mpcgpu_cost_grad_batch(void* handle, int32_t B, const double* u, const d
     HIP_OK(h, hipMemcpyAsync(h->xi.ptr, xi, Bz * (n + 1) * 8, hipMemcpyHostToDevice, s));
     BatchPtrs io{};
     if (int r = prepare(h, B, (const double*)h->p.ptr, s, io)) return r;
-#define LAUNCH_CG(NT, SC)                                                                                      \
-    hipLaunchKernelGGL((cost_grad_kernel<NT, SC>), dim3(B), dim3(WAVE), h->kp.l_total * sizeof(double), s,       \
-                       h->kp, io, (const double*)h->u.ptr, (const double*)h->xi.ptr, (double*)h->psi.ptr,        \
-                       (double*)h->f.ptr, (double*)h->grad.ptr, (double*)h->F1.ptr, (double*)h->F2.ptr, B)
+    const size_t lds_cg = h->kp.l_total * sizeof(double);
+#define LAUNCH_CG(NT, SC)                                                                                          \
+    do {                                                                                                             \
+        auto kern = cost_grad_kernel<NT, SC>;                                                                        \
+        if (lds_cg > 64 * 1024)                                                                                      \
+            HIP_OK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cg)); \
+        hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE), lds_cg, s, h->kp, io, (const double*)h->u.ptr,                 \
+                           (const double*)h->xi.ptr, (double*)h->psi.ptr, (double*)h->f.ptr, (double*)h->grad.ptr,   \
+                           (double*)h->F1.ptr, (double*)h->F2.ptr, B);                                               \
+    } while (0)
     if (h->shape_const) {
         switch (h->kp.N) {
             case 20: LAUNCH_CG(20, true); break;
