@@ -114,6 +114,7 @@ def main():
 
     if rank == 0:
         traffic = measured_traffic(N, args.n_dyn, B)
+        n_psi, n_grad = solver.last_eval_counts(B, stream)
         status = out["status"].cpu().numpy()
         inner = out["inner_it"].cpu().numpy()
         k_ms = float(np.mean(kernel_ms))
@@ -137,6 +138,7 @@ def main():
                                    f"batch={B} robots per GPU (BASELINE.json metric configuration)",
                        "batch_per_gpu": B, "N_hor": N, "n_dyn": args.n_dyn, "parallelism": f"shard{world}",
                        "mean_inner_iterations": float(inner.mean()),
+                       "mean_psi_evaluations": float(n_psi.mean()), "mean_grad_evaluations": float(n_grad.mean()),
                        "status_histogram": np.bincount(status, minlength=3).tolist()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -112,6 +112,11 @@ int32_t mpcgpu_cost_grad_batch(void* handle, int32_t B, const double* u, const d
  * solve kernel.  Valid after the stream has been synchronised. */
 int32_t mpcgpu_last_timing(void* handle, double* prep_ms, double* solve_ms);
 
+/* Work counters of the last solve call, per problem: psi evaluations executed and how many of them also produced
+ * grad psi (the counts OpEn's generated `cost` / `grad_cost` functions would see, minus the redundant re-evaluation of
+ * psi(u) in the Lipschitz update).  Synchronises `stream` (NULL = the handle's own stream).  HOST output pointers. */
+int32_t mpcgpu_last_eval_counts(void* handle, int32_t B, int32_t* n_psi, int32_t* n_grad, void* stream);
+
 /* Batch-wide maxima of active entries seen by the last solve / cost_grad call: static obstacles, fleet
  * entries, dynamic-obstacle entries (sizes the LDS carve), and the LDS bytes per wavefront used. */
 int32_t mpcgpu_last_shape(void* handle, int32_t* max_static, int32_t* max_fleet, int32_t* max_dyn,

@@ -170,6 +170,10 @@ def test_hard_scenes_agree_within_intrinsic_sensitivity(solver20, cfg20):
     assert abs(np.median(res.f2_norm) - np.median(ro["f2_norm"])) <= 0.25 * np.median(ro["f2_norm"]) + 1e-6
     assert (res.status == ro["status"]).mean() >= 0.9
     assert abs(res.num_inner_iterations.mean() / ro["inner_iters"].mean() - 1.0) < 0.1
+    # work counters: the oracle counts the same evaluations
+    n_psi, n_grad = solver20.last_eval_counts(B)
+    assert abs(n_psi.mean() / ro["n_cost_evals"].mean() - 1.0) < 0.1 and abs(n_grad.mean() / ro["n_grad_evals"].mean() - 1.0) < 0.1
+    assert np.all(n_grad <= n_psi) and np.all(n_psi >= res.num_inner_iterations)
 
 
 def test_warm_start_multipliers_and_penalty_arguments(solver20, cfg20):

@@ -98,6 +98,7 @@ struct BatchPtrs {
     double* u; double* cost; int32_t* status; int32_t* inner_it; int32_t* outer_it;
     double* fpr; double* f2norm; double* y_out; double* ms;
     double* ws; int* counts;
+    int32_t* evals;  // [B][2] psi evaluations / of those with gradient (library-owned; read by mpcgpu_last_eval_counts)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -907,6 +908,7 @@ __global__ __launch_bounds__(WAVE, MPC_MIN_WAVES) void solve_kernel_pair(KParams
     int alm_iteration = 0, num_outer = 1, inner_total = 0, status = 0;
     double dy_norm = 0, dy_norm_plus = 0, f2_norm = 0, f2_norm_plus = 0, last_fpr = 0, f_final = 0;
 
+    int n_eval = 0, n_eval_grad = 0;
     int state = ST_INIT0;
     double ev = uv, ew = uw;  // evaluation point
     bool want_grad = true;
@@ -927,6 +929,7 @@ __global__ __launch_bounds__(WAVE, MPC_MIN_WAVES) void solve_kernel_pair(KParams
     for (;;) {
         PROF_MARK(10 + state);  // solver logic that led to this evaluation (by the state it was issued for)
         PROF_COUNT(16 + state);
+        ++n_eval; n_eval_grad += want_grad ? 1 : 0;
         eval_point<NT, SC>(kp, cx, ev, ew, c, ya, yb, want_grad, state == ST_OUTER, o PROF_PASS);
         bool step_begin = false;
 
@@ -1161,6 +1164,7 @@ __global__ __launch_bounds__(WAVE, MPC_MIN_WAVES) void solve_kernel_pair(KParams
         io.cost[b] = f_final;
         io.status[b] = status;
         if (io.inner_it) io.inner_it[b] = inner_total;
+        if (io.evals) { io.evals[2 * b] = n_eval; io.evals[2 * b + 1] = n_eval_grad; }
         if (io.outer_it) io.outer_it[b] = num_outer;
         if (io.fpr) io.fpr[b] = last_fpr;
         if (io.f2norm) io.f2norm[b] = f2_norm_plus;

@@ -33,9 +33,10 @@ struct Handle {
     bool timing_valid = false;
     std::string err;
     // grow-only device buffers
-    DevBuf ws, counts, p, u0, y0, c0, u, cost, status, inner, outer, fpr, f2, y, ms, xi, psi, f, grad, F1, F2;
+    DevBuf ws, counts, evals, p, u0, y0, c0, u, cost, status, inner, outer, fpr, f2, y, ms, xi, psi, f, grad, F1, F2;
     int* h_counts = nullptr;  // pinned
     int last_shape[4] = {0, 0, 0, 0};
+    int last_B = 0;  // batch size of the last solve (for mpcgpu_last_eval_counts)
     bool shape_const = true;  // of the batch prepared last
 };
 
@@ -229,7 +230,7 @@ void mpcgpu_destroy(void* handle) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf* bufs[] = {&h->ws, &h->counts, &h->p, &h->u0, &h->y0, &h->c0, &h->u, &h->cost, &h->status, &h->inner,
+    DevBuf* bufs[] = {&h->ws, &h->counts, &h->evals, &h->p, &h->u0, &h->y0, &h->c0, &h->u, &h->cost, &h->status, &h->inner,
                       &h->outer, &h->fpr, &h->f2, &h->y, &h->ms, &h->xi, &h->psi, &h->f, &h->grad, &h->F1, &h->F2};
     for (DevBuf* b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
@@ -265,6 +266,9 @@ int32_t mpcgpu_solve_batch_dev(void* handle, int32_t B, const double* p, const d
     if (int r = prepare(h, B, p, s, io)) return r;
     io.u0 = u0; io.y0 = y0; io.c0 = c0; io.u = u; io.cost = cost; io.status = status; io.inner_it = inner_it;
     io.outer_it = outer_it; io.fpr = fpr; io.f2norm = f2norm; io.y_out = y_out; io.ms = ms;
+    if (int r = ensure(h, h->evals, (size_t)B * 2 * sizeof(int32_t))) return r;
+    io.evals = (int32_t*)h->evals.ptr;
+    h->last_B = B;
     HIP_OK(h, hipEventRecord(h->ev[2], s));
     const size_t lds = h->kp.l_total * sizeof(double);
     // more than 64 KiB of dynamic LDS (long horizons with many time-varying obstacles) must be opted into per kernel
@@ -402,6 +406,24 @@ int32_t mpcgpu_last_timing(void* handle, double* prep_ms, double* solve_ms) {
     HIP_OK(h, hipEventElapsedTime(&b, h->ev[2], h->ev[3]));
     if (prep_ms) *prep_ms = a;
     if (solve_ms) *solve_ms = b;
+    return 0;
+}
+
+int32_t mpcgpu_last_eval_counts(void* handle, int32_t B, int32_t* n_psi, int32_t* n_grad, void* stream) {
+    Handle* h = (Handle*)handle;
+    if (!h) return -1;
+    if (B != h->last_B || !h->evals.ptr) return fail(h, -4, "no solve of %d problems precedes this call (last: %d)", B, h->last_B);
+    HIP_OK(h, hipSetDevice(h->device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    HIP_OK(h, hipStreamSynchronize(s));
+    HIP_OK(h, hipEventSynchronize(h->ev[3]));
+    int32_t* tmp = new (std::nothrow) int32_t[(size_t)B * 2];
+    if (!tmp) return fail(h, -3, "out of host memory");
+    hipError_t e = hipMemcpy(tmp, h->evals.ptr, (size_t)B * 2 * sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess)
+        for (int i = 0; i < B; ++i) { if (n_psi) n_psi[i] = tmp[2 * i]; if (n_grad) n_grad[i] = tmp[2 * i + 1]; }
+    delete[] tmp;
+    if (e != hipSuccess) return fail(h, -10, "hipMemcpy failed: %s", hipGetErrorString(e));
     return 0;
 }
 

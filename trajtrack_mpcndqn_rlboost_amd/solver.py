@@ -44,7 +44,7 @@ class _CConfig(C.Structure):
 
 EXPORTS = ("mpcgpu_abi_version", "mpcgpu_create", "mpcgpu_destroy", "mpcgpu_last_error", "mpcgpu_num_params",
            "mpcgpu_solve_batch", "mpcgpu_solve_batch_dev", "mpcgpu_cost_grad_batch", "mpcgpu_last_timing",
-           "mpcgpu_last_shape")
+           "mpcgpu_last_eval_counts", "mpcgpu_last_shape")
 
 
 def library_path() -> str:
@@ -89,6 +89,8 @@ def load_library():
     L.mpcgpu_cost_grad_batch.restype = C.c_int32
     L.mpcgpu_last_timing.argtypes = [vp, dp, dp]
     L.mpcgpu_last_timing.restype = C.c_int32
+    L.mpcgpu_last_eval_counts.argtypes = [vp, C.c_int32, ip, ip, vp]
+    L.mpcgpu_last_eval_counts.restype = C.c_int32
     L.mpcgpu_last_shape.argtypes = [vp, ip, ip, ip, ip]
     L.mpcgpu_last_shape.restype = C.c_int32
     _lib = L
@@ -233,6 +235,13 @@ class BatchSolver:
         a, b = C.c_double(), C.c_double()
         self._check(self._L.mpcgpu_last_timing(self._h, C.byref(a), C.byref(b)), "mpcgpu_last_timing")
         return dict(prep_ms=a.value, solve_ms=b.value)
+
+    def last_eval_counts(self, B: int, stream: int = 0):
+        """(psi evaluations, of which with gradient) per problem of the last solve of B problems."""
+        n_psi = np.empty(B, np.int32); n_grad = np.empty(B, np.int32)
+        self._check(self._L.mpcgpu_last_eval_counts(self._h, B, _ip(n_psi), _ip(n_grad),
+                                                    C.c_void_p(stream) if stream else None), "mpcgpu_last_eval_counts")
+        return n_psi, n_grad
 
     def last_shape(self):
         v = [C.c_int32() for _ in range(4)]
