@@ -61,7 +61,9 @@ typedef struct mpcgpu_config {
 } mpcgpu_config;
 
 /* exit_status codes; names as in config/mpc_default.yaml:54 */
-enum { MPCGPU_CONVERGED = 0, MPCGPU_NOT_CONVERGED_ITERATIONS = 1, MPCGPU_NOT_CONVERGED_OUT_OF_TIME = 2 };
+enum { MPCGPU_CONVERGED = 0, MPCGPU_NOT_CONVERGED_ITERATIONS = 1, MPCGPU_NOT_CONVERGED_OUT_OF_TIME = 2,
+       /* OpEn reports this case as an error (SolverError::NotFiniteComputation -> the binding returns None) */
+       MPCGPU_NOT_FINITE_COMPUTATION = 3 };
 
 /* replaces: MpcModule.build + __import__(optimizer_name).solver()  (trajectory_generator.py:63-71) */
 int32_t mpcgpu_create(const mpcgpu_config* cfg, void** handle);

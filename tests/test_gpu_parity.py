@@ -293,6 +293,11 @@ def test_edge_cases_and_error_behaviour(solver20, cfg20):
         solver20.solve(sc["p"], initial_guess=np.zeros((3, 39)))
     with pytest.raises(MpcGpuError, match="1700"):
         solver20.solve(sc["p"], initial_lagrange_multipliers=np.zeros((3, 41)))
+    # non-finite parameters poison the iteration: reported as status 3 / None, never as a "solution"
+    bad = sc["p"].copy(); bad[1, 0] = np.nan
+    rb = solver20.solve(bad)
+    assert rb.status[1] == 3 and rb.exit_status[1] == "NotFiniteComputation" and rb.status[0] != 3
+    assert Solver(cfg20).run(bad[1].tolist(), None) is None
     # an all-zero parameter vector (every block padded) is still a valid problem
     z = solver20.solve(np.zeros((1, cfg20.num_params)))
     uo, _, ro, _ = oracle.solve_batch(oracle_cfg(cfg20), np.zeros((1, cfg20.num_params)))

@@ -1155,6 +1155,9 @@ __global__ __launch_bounds__(WAVE, MPC_MIN_WAVES) void solve_kernel_pair(KParams
 #ifdef MPC_PROFILE
     prof.mark(22); prof.flush();
 #endif
+    // a NaN / inf anywhere in the iteration ends here too (every comparison with it is false): report it the way
+    // OpEn does (SolverError::NotFiniteComputation) instead of returning the garbage as a solution
+    if (__ballot(vl && !(isfinite(uv) && isfinite(uw))) != 0ull || !isfinite(f_final)) status = 3;
     // ---- write results (coalesced per problem)
     if (vl) {
         io.u[(size_t)b * 2 * N + 2 * lane] = uv;

@@ -66,6 +66,9 @@ class Solver:
             None if initial_lagrange_multipliers is None else
             np.asarray(initial_lagrange_multipliers, dtype=np.float64).reshape(1, -1),
             None if initial_penalty is None else np.array([float(initial_penalty)]))
+        if int(res.status[0]) == 3:      # OpEn: Err(NotFiniteComputation) -> the binding prints and returns None
+            print("2000 -> Problem solution failed (solver error)")
+            return None
         return SolverStatus(res, 0)
 
     def run_batch(self, p, initial_guess=None, initial_lagrange_multipliers=None, initial_penalty=None) -> BatchResult:

@@ -20,7 +20,7 @@ from .config import MpcConfig
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.environ.get("MPCGPU_LIB", os.path.join(_PKG, "libmpcgpu.so"))  # override: kernel A/B experiments
 
-STATUS_NAMES = ("Converged", "NotConvergedIterations", "NotConvergedOutOfTime")
+STATUS_NAMES = ("Converged", "NotConvergedIterations", "NotConvergedOutOfTime", "NotFiniteComputation")
 
 
 class MpcGpuError(RuntimeError):
