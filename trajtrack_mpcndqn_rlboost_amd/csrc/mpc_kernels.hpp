@@ -4,7 +4,7 @@
 //   * "vector lanes"  k < N hold step k of every horizon vector: (v_k, w_k) of u, grad, FPR, L-BFGS work
 //     vectors, multipliers ... -- 2 doubles per lane, so n = 2N-dim vector algebra is one instruction and an
 //     inner product is one DPP wave reduction;
-//   * "item lanes"    (k, sub) = (lane % N, lane / N), lane < N*LPS, split the (step x object) stage-cost
+//   * "item lanes"    all 64 lanes: (k, sub) = (lane % N, lane / N) split the (step x object) stage-cost
 //     terms of step k (reference-path segments, static polygons, dynamic ellipses, fleet discs);
 //   * the compacted problem tables and the L-BFGS memory live in LDS; HBM is touched once per solve.
 //
@@ -67,7 +67,7 @@ enum { H_KS = 18, H_KF = 19, H_KD = 20, H_CTH0 = 21, H_STH0 = 22, H_NPF = 23, H_
 enum { CNT_KS = 0, CNT_KF = 1, CNT_KD = 2, CNT_VARSHAPE = 3 };
 
 struct KParams {
-    int N, LPS, Nother, Nstcobs, Ndynobs, np, mem;
+    int N, Nother, Nstcobs, Ndynobs, np, mem;
     int max_inner, max_outer;
     double ts, inv_ts;
     double vmin, vmax, wmax, amin, amax, aamax;
@@ -83,14 +83,11 @@ struct KParams {
     int l_seg, l_stc, l_fxy, l_dyn, l_dync, l_pos, l_H, l_W, l_part, l_stash, l_hd, l_S, l_Y, l_rho, l_alpha, l_old, l_total;
 };
 
-// lanes per step for the item phase
-__host__ __device__ constexpr int lps_of(int n) { return n <= 16 ? 4 : (n <= 21 ? 3 : (n <= 32 ? 2 : 1)); }
 // compile-time horizon NT (0 = runtime horizon from KParams; DPP row counts then cover the whole wave)
 template <int NT>
 struct Dim {
-    static constexpr int LPS = NT ? lps_of(NT) : 0;
-    static constexpr int ROWS_V = NT ? (NT + 15) / 16 : 4;               // rows holding vector lanes
-    static constexpr int ROWS_I = NT ? (NT * lps_of(NT) + 15) / 16 : 4;  // rows holding item lanes
+    static constexpr int ROWS_V = NT ? (NT + 15) / 16 : 4;  // rows holding vector lanes
+    static constexpr int ROWS_I = 4;                        // every lane is an item lane
 };
 
 struct BatchPtrs {
@@ -411,10 +408,9 @@ __device__ __forceinline__ void load_problem(const KParams& kp, const double* __
                                              Ctx& cx) {
     const int lane = threadIdx.x;
     const int N = NT ? NT : kp.N;
-    const int LPS = NT ? Dim<NT>::LPS : kp.LPS;
     cx.lane = lane;
     cx.vl = lane < N;
-    cx.il = lane < N * LPS;
+    cx.il = true;
     cx.ik = lane % N;
     cx.isub = lane / N;
     double* hd = lds + kp.l_hd;
@@ -478,12 +474,18 @@ __device__ __forceinline__ DynItem dyn_item(const Ctx& cx, int i, int k, int N, 
 template <int NT, bool SC>
 __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, double v, double w, double c,
                                            double ya, double yb, bool want_grad, bool want_f, EvalOut& out PROF_ARG) {
-    const int N = NT ? NT : kp.N, LPS = NT ? Dim<NT>::LPS : kp.LPS;
+    const int N = NT ? NT : kp.N;
     int lane = cx.lane;
     asm volatile("" : "+v"(lane));  // opaque: per-lane LDS addresses are rebuilt here instead of being hoisted out
                                     // of the solver loop, where they would stay live across the whole iteration
-    const bool c_vl = lane < N, c_il = lane < N * LPS;
+    // item lanes: lane = sub*N + k.  Step k is served by LPS = (63-k)/N + 1 lanes (3-4 at N = 20; at N = 40 the 24 spare
+    // lanes double up on the first 24 steps, which also carry the most reference segments)
+    // When 64 is almost a multiple of N (N = 20: 60 lanes) a uniform split is cheaper: the loop strides are constants.
+    constexpr bool UNIFORM = NT != 0 && (WAVE % NT) * 5 <= NT;
+    const bool c_vl = lane < N;
+    const bool c_il = UNIFORM ? lane < (WAVE / N) * N : true;
     const int c_ik = lane % N, c_isub = lane / N;
+    const int LPS = UNIFORM ? WAVE / N : (WAVE - 1 - c_ik) / N + 1;
     constexpr int RV = Dim<NT>::ROWS_V, RI = Dim<NT>::ROWS_I;
     const double ts = kp.ts;
     const double inf = __builtin_huge_val();
@@ -545,7 +547,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         // Exact pruning: a segment whose midpoint is farther than sqrt(best) + half its length cannot hold the
         // minimum (nor tie with it), so its distance is not evaluated; the value and arg-min are unchanged.
         double sb = inf;  // upper bound of sqrt(best)
-        // (1) the SEG_WIN * LPS segments nearest in index are always evaluated
+        // (1) the SEG_WIN * LPS segments of this step nearest in index are always evaluated
         int i = k + c_isub;
         MPC_ITEM_LOOP
         for (int it = 0; it < SEG_WIN && i < N; ++it, i += LPS) {

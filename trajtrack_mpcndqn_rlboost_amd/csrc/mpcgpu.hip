@@ -79,7 +79,6 @@ void fill_static_params(Handle* h) {
     KParams& k = h->kp;
     const int N = c.N;
     k.N = N;
-    k.LPS = lps_of(N);
     k.Nother = c.Nother; k.Nstcobs = c.Nstcobs; k.Ndynobs = c.Ndynobs; k.mem = c.lbfgs_mem;
     k.max_inner = c.max_inner; k.max_outer = c.max_outer;
     k.ts = c.ts; k.inv_ts = 1.0 / c.ts;
@@ -131,7 +130,7 @@ void fill_lds_layout(KParams& k, int mKs, int mKf, int mKd, bool shape_const, bo
     k.l_hd = o; o += 64;
     // H (hinge matrix, read right after it is written) and the item-lane partials are never live together:
     // LDS operations of the single wave execute in order, so they share one region
-    const int h_sz = even(mKd * N) + even(mKd), part_sz = even(k.LPS * N * PARTW);
+    const int h_sz = even(mKd * N) + even(mKd), part_sz = WAVE * PARTW;
     k.l_H = o; k.l_W = o + even(mKd * N); k.l_part = o;
     o += h_sz > part_sz ? h_sz : part_sz;
     k.l_S = k.l_Y = o;
