@@ -1,0 +1,360 @@
+// envgpu.hip -- batched DRL environment step for gfx950 (MI355X): C-ABI of include/mpcgpu_env.h.
+//
+// One wavefront = one environment, grid = B.  The 64 lanes split the padded obstacle / boundary edges (sector and
+// ray distances, inside tests), the obstacles (key-frame poses) and the reference-path segments (projection); the
+// cross-lane results are DPP minima and ballots, and one lane finishes the scalar bookkeeping (flags, reward,
+// observation vectors).  The map record is read once per step, coalesced (lanes stride over consecutive edges).
+// Reference semantics: see the file:line list in include/mpcgpu_env.h; CPU restatement: oracle/rl_env_numpy.py.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "../../include/mpcgpu_env.h"
+
+namespace envgpu {
+
+constexpr int WAVE = 64;
+constexpr int NSEG = 8;      // sectors / rays (rays_reward1.py:20)
+constexpr int NCORNER = 3;   // corner samples (rays_reward1.py:18)
+constexpr int HDR = 16;
+constexpr int SDIM = MPCGPU_ENV_STATE_DOUBLES;
+constexpr int MAX_OBST = 31;
+constexpr double L_SECTOR = 1000.0;  // ext_obsv_sector_and_ray.py:32
+
+struct EnvK {
+    mpcgpu_env_params p;
+    int rec, o_cum, o_len, o_xy, o_anim, an, o_edge;
+};
+
+__host__ __device__ inline int anim_doubles(int K) { return 4 + (K + 1) + 3 * K; }
+
+static bool layout(const mpcgpu_env_params& p, EnvK& k) {
+    if (p.n_path_max < 2 || p.n_path_max > WAVE || p.n_obst_max < 0 || p.n_obst_max > MAX_OBST || p.n_kf_max < 1 ||
+        p.n_kf_max > 4 || p.n_edge_max < 1)
+        return false;
+    k.p = p;
+    k.o_cum = HDR;
+    k.o_len = k.o_cum + p.n_path_max;
+    k.o_xy = k.o_len + p.n_path_max;
+    k.o_anim = k.o_xy + 2 * p.n_path_max;
+    k.an = anim_doubles(p.n_kf_max);
+    k.o_edge = k.o_anim + p.n_obst_max * k.an;
+    k.rec = k.o_edge + 5 * p.n_edge_max;
+    k.rec += k.rec & 1;
+    return true;
+}
+
+// ---- wave primitives (DPP: cross-lane operands inside VALU instructions) ------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_fill(double x, double fill) {  // lanes without a source receive `fill`
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(__double2loint(fill), lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_value(double x, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_min(double x) {  // uniform result
+    const double inf = INFINITY;
+    x = fmin(x, dpp_fill<0x111>(x, inf));  // row_shr:1
+    x = fmin(x, dpp_fill<0x112>(x, inf));
+    x = fmin(x, dpp_fill<0x114>(x, inf));
+    x = fmin(x, dpp_fill<0x118>(x, inf));
+    return fmin(fmin(lane_value(x, 15), lane_value(x, 31)), fmin(lane_value(x, 47), lane_value(x, 63)));
+}
+__device__ __forceinline__ unsigned wave_xor(unsigned m) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m ^= (unsigned)__shfl_xor((int)m, off, WAVE);
+    return m;
+}
+__device__ __forceinline__ double normalize_distance(double d) {  // components/utils.py:10-15
+    return 2.0 / (1.0 + exp(-2.0 * d / 10.0)) - 1.0;
+}
+
+// cos / sin of j * pi / 8, j = 0..15
+__constant__ double DIRC[16] = {1.0, 0.92387953251128673848, 0.70710678118654757274, 0.38268343236508978178,
+                                0.0, -0.38268343236508978178, -0.70710678118654757274, -0.92387953251128673848,
+                                -1.0, -0.92387953251128673848, -0.70710678118654757274, -0.38268343236508978178,
+                                0.0, 0.38268343236508978178, 0.70710678118654757274, 0.92387953251128673848};
+__constant__ double DIRS[16] = {0.0, 0.38268343236508978178, 0.70710678118654757274, 0.92387953251128673848,
+                                1.0, 0.92387953251128673848, 0.70710678118654757274, 0.38268343236508978178,
+                                0.0, -0.38268343236508978178, -0.70710678118654757274, -0.92387953251128673848,
+                                -1.0, -0.92387953251128673848, -0.70710678118654757274, -0.38268343236508978178};
+
+__global__ __launch_bounds__(WAVE) void env_step_kernel(EnvK k, const double* __restrict__ rec_all, double* state_all,
+                                                        const int32_t* __restrict__ action, float* obs_int,
+                                                        float* obs_ext, double* reward, uint8_t* terminated, int B) {
+    __shared__ double pose[MAX_OBST + 1][4];
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    const int lane = threadIdx.x;
+    const double* rec = rec_all + (size_t)b * k.rec;
+    double* st = state_all + (size_t)b * SDIM;
+    const mpcgpu_env_params& P = k.p;
+    const int n_path = (int)rec[0], n_obst = (int)rec[1], n_edge = (int)rec[2];
+    const double gx = rec[3], gy = rec[4];
+    double x = st[0], y = st[1], th = st[2], v = st[3], w = st[4], clock = st[5];
+    const double last_prog = st[6];
+    int flags = (int)st[7];
+    const bool act = action != nullptr;
+    const double ts = P.time_step;
+
+    // ---- obstacles' clock and the robot (environment.py:199-203, agent.py:97-139); every lane keeps the same copy
+    if (act) {
+        const int a = action[b];
+        clock += ts;
+        const int row = a / 3, col = a % 3;
+        if (row == 0) v += ts * P.acc_max;
+        if (row == 2) v += ts * P.acc_min;
+        if (col == 0) w += ts * P.angacc_max;
+        if (col == 2) w += ts * P.angacc_min;
+        if (v > P.speed_max) v = P.speed_max;
+        if (v < P.speed_min) v = P.speed_min;
+        if (w > P.angvel_max) w = P.angvel_max;
+        if (w < P.angvel_min) w = P.angvel_min;
+        th += ts * w;
+        x += ts * v * cos(th);
+        y += ts * v * sin(th);
+    }
+    const double cth = cos(th), sth = sin(th);
+
+    // ---- key-frame pose of obstacle `lane` (obstacle.py:71-88): (x, y, cos rot, sin rot) -> LDS
+    if (lane < n_obst) {
+        const double* an = rec + k.o_anim + lane * k.an;
+        const int kind = (int)an[0], nk = (int)an[2];
+        const double* tsv = an + 4;
+        const double* kf = an + 4 + (P.n_kf_max + 1);
+        const double tm = fmod(clock + an[1], an[3]);
+        double px = kf[3 * (nk - 1)], py = kf[3 * (nk - 1) + 1], rot = kf[3 * (nk - 1) + 2];
+        double t = 0.0;
+        bool found = false;
+        for (int i = 0; i < nk; ++i) {
+            t += tsv[i];
+            if (!found && t <= tm && tm < t + tsv[i + 1]) {
+                const double xx = (tm - t) / tsv[i + 1];
+                const double alpha = kind == 1 ? (1.0 - cos(xx * M_PI)) / 2.0 : xx;
+                const double* k0 = kf + 3 * i;
+                const double* k1 = kf + 3 * ((i + 1) % nk);
+                px = k0[0] * (1.0 - alpha) + k1[0] * alpha;
+                py = k0[1] * (1.0 - alpha) + k1[1] * alpha;
+                rot = k0[2] * (1.0 - alpha) + k1[2] * alpha;
+                found = true;
+            }
+        }
+        pose[lane][0] = px; pose[lane][1] = py; pose[lane][2] = cos(rot); pose[lane][3] = sin(rot);
+    }
+    __syncthreads();
+
+    // ---- the 16 directions theta + j pi/8: even j = ray / sector centre, odd j = sector borders
+    double dx[16], dy[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        dx[j] = cth * DIRC[j] - sth * DIRS[j];
+        dy[j] = sth * DIRC[j] + cth * DIRS[j];
+    }
+
+    // ---- edges: closest point of (edge within sector i), first hit of ray i, crossing parity per outline
+    double sec[NSEG], ray[NSEG];
+#pragma unroll
+    for (int i = 0; i < NSEG; ++i) { sec[i] = INFINITY; ray[i] = INFINITY; }
+    unsigned mask = 0u;  // bit 0: padded boundary, bit j+1: obstacle j -- set when the robot is inside that outline
+    for (int e = lane; e < n_edge; e += WAVE) {
+        const double* ed = rec + k.o_edge + 5 * e;
+        double x0 = ed[0], y0 = ed[1], x1 = ed[2], y1 = ed[3];
+        const int owner = (int)ed[4];
+        if (owner < -1) continue;
+        if (owner >= 0) {  // obstacle.py:174-188: position + R * nodes
+            const double ox = pose[owner][0], oy = pose[owner][1], c = pose[owner][2], s = pose[owner][3];
+            const double a0 = ox + c * x0 - s * y0, b0 = oy + s * x0 + c * y0;
+            const double a1 = ox + c * x1 - s * y1, b1 = oy + s * x1 + c * y1;
+            x0 = a0; y0 = b0; x1 = a1; y1 = b1;
+        }
+        const double Px = x0 - x, Py = y0 - y, Qx = x1 - x, Qy = y1 - y;
+        const double Ex = Qx - Px, Ey = Qy - Py;
+        if ((Py > 0.0) != (Qy > 0.0)) {  // even-odd rule along +x from the robot
+            const double xi = Ex * (-Py) / Ey + Px;
+            if (xi > 0.0) mask ^= 1u << (owner + 1);
+        }
+        const double ee = Ex * Ex + Ey * Ey, pe = Px * Ex + Py * Ey, pxe = Px * Ey - Py * Ex;
+        const double t_free = ee > 0.0 ? -pe / ee : 0.0;
+#pragma unroll
+        for (int i = 0; i < NSEG; ++i) {
+            const int jl = (2 * i + 15) & 15, ju = 2 * i + 1, jc = 2 * i;
+            // wedge = {cross(d_lower, X) >= 0} and {cross(X, d_upper) >= 0}: clip the edge's parameter range
+            double t0 = 0.0, t1 = 1.0;
+            bool empty = false;
+            {
+                const double f0 = dx[jl] * Py - dy[jl] * Px, f1 = dx[jl] * Ey - dy[jl] * Ex;
+                if (f1 > 0.0) t0 = fmax(t0, -f0 / f1);
+                else if (f1 < 0.0) t1 = fmin(t1, -f0 / f1);
+                else if (f0 < 0.0) empty = true;
+            }
+            {
+                const double f0 = Px * dy[ju] - Py * dx[ju], f1 = Ex * dy[ju] - Ey * dx[ju];
+                if (f1 > 0.0) t0 = fmax(t0, -f0 / f1);
+                else if (f1 < 0.0) t1 = fmin(t1, -f0 / f1);
+                else if (f0 < 0.0) empty = true;
+            }
+            if (!empty && t0 <= t1) {
+                const double tt = fmin(fmax(t_free, t0), t1);
+                const double cx = Px + tt * Ex, cy = Py + tt * Ey;
+                sec[i] = fmin(sec[i], sqrt(cx * cx + cy * cy));
+            }
+            const double den = dx[jc] * Ey - dy[jc] * Ex;
+            if (den != 0.0) {
+                const double s = pxe / den, t = (Px * dy[jc] - Py * dx[jc]) / den;
+                if (s >= 0.0 && t >= 0.0 && t <= 1.0 && s <= L_SECTOR) ray[i] = fmin(ray[i], s);
+            }
+        }
+    }
+    mask = wave_xor(mask);
+    const bool in_obstacle = (mask & ~1u) != 0u;
+#pragma unroll
+    for (int i = 0; i < NSEG; ++i) {
+        sec[i] = in_obstacle ? 0.0 : wave_min(sec[i]);  // the robot itself belongs to sector ∩ obstacle
+        ray[i] = in_obstacle ? 0.0 : wave_min(ray[i]);
+    }
+
+    // ---- path progress = LineString.project: first closest segment (environment.py:118)
+    const double* cum = rec + k.o_cum;
+    const double* len = rec + k.o_len;
+    const double* pxy = rec + k.o_xy;
+    double dist = INFINITY, tproj = 0.0, cpx = 0.0, cpy = 0.0;
+    if (lane < n_path - 1) {
+        const double ax = pxy[2 * lane], ay = pxy[2 * lane + 1];
+        const double ex = pxy[2 * lane + 2] - ax, ey = pxy[2 * lane + 3] - ay;
+        const double den = ex * ex + ey * ey;
+        double t = den == 0.0 ? 0.0 : ((x - ax) * ex + (y - ay) * ey) / den;
+        t = fmin(1.0, fmax(0.0, t));
+        cpx = ax + t * ex; cpy = ay + t * ey;
+        tproj = t;
+        dist = sqrt((x - cpx) * (x - cpx) + (y - cpy) * (y - cpy));
+    }
+    const double cte = wave_min(dist);
+    const int iseg = __ffsll((long long)__ballot(dist == cte)) - 1;
+    const double progress = cum[iseg] + lane_value(tproj, iseg) * len[iseg];
+    cpx = lane_value(cpx, iseg); cpy = lane_value(cpy, iseg);
+    // sample point at progress + offset (LineString.interpolate, clamped to the line)
+    double spx = cpx, spy = cpy;
+    if (P.sample_offset != 0.0) {
+        const double s = progress + P.sample_offset;
+        const double total = cum[n_path - 1];
+        if (s <= 0.0) { spx = pxy[0]; spy = pxy[1]; }
+        else if (s >= total) { spx = pxy[2 * (n_path - 1)]; spy = pxy[2 * (n_path - 1) + 1]; }
+        else {
+            const unsigned long long bal = __ballot(lane < n_path - 1 && s < cum[lane < n_path - 1 ? lane + 1 : 0]);
+            const int i = bal ? __ffsll((long long)bal) - 1 : n_path - 2;
+            const double t = (s - cum[i]) / len[i];
+            spx = pxy[2 * i] + t * (pxy[2 * i + 2] - pxy[2 * i]);
+            spy = pxy[2 * i + 1] + t * (pxy[2 * i + 3] - pxy[2 * i + 1]);
+        }
+    }
+    // first node whose cumulative length reaches the progress (int_obsv_reference_path_corner.py:29-33)
+    const unsigned long long reach = __ballot(lane < n_path && cum[lane < n_path ? lane : 0] >= progress);
+    int icorner = reach ? __ffsll((long long)reach) - 1 : n_path - 1;
+
+    if (lane != 0) return;
+    // ---- status flags, sticky (environment.py:113-116)
+    if (in_obstacle) flags |= 1;
+    if (!(mask & 1u)) flags |= 2;
+    if (sqrt((gx - x) * (gx - x) + (gy - y) * (gy - y)) < P.radius) flags |= 4;
+    const bool collided = (flags & 3) != 0, reached = (flags & 4) != 0;
+
+    // ---- internal observation (components/int_obsv_*.py)
+    float* oi = obs_int + (size_t)b * MPCGPU_ENV_INTERNAL_OBS;
+    oi[0] = (float)(2.0 * (v - P.speed_min) / (P.speed_max - P.speed_min) - 1.0);
+    // the reference normalises the angular velocity with the angular ACCELERATION limits (int_obsv_angular_velocity.py:13-19)
+    oi[1] = (float)(2.0 * (w - P.angacc_min) / (P.angacc_max - P.angacc_min) - 1.0);
+    auto relative = [&](double qx, double qy, float* o) {  // cos / sin of (bearing - theta), normalised distance
+        const double ddx = qx - x, ddy = qy - y;
+        const double d = sqrt(ddx * ddx + ddy * ddy);
+        double cr = cth, sr = -sth;  // atan2(0, 0) = 0
+        if (d > 0.0) { cr = (ddx * cth + ddy * sth) / d; sr = (ddy * cth - ddx * sth) / d; }
+        o[0] = (float)cr; o[1] = (float)sr; o[2] = (float)normalize_distance(d);
+    };
+    relative(spx, spy, oi + 2);
+    for (int j = 0; j < NCORNER; ++j) {
+        if (icorner > n_path - 1) icorner = n_path - 1;
+        relative(pxy[2 * icorner], pxy[2 * icorner + 1], oi + 5 + 3 * j);
+        ++icorner;
+    }
+
+    // ---- external observation with one-step memory (ext_obsv_sector_and_ray.py:66-74)
+    float* oe = obs_ext + (size_t)b * MPCGPU_ENV_EXTERNAL_OBS;
+#pragma unroll
+    for (int i = 0; i < NSEG; ++i) {
+        const float a = (float)normalize_distance(sec[i]), r = (float)normalize_distance(ray[i]);
+        oe[i] = a; oe[NSEG + i] = r;
+        oe[2 * NSEG + i] = (float)st[8 + i];
+        oe[3 * NSEG + i] = (float)st[8 + NSEG + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * NSEG; ++i) st[8 + i] = (double)oe[i];
+
+    // ---- reward R1 (rays_reward1.py:26-39; summed in component order)
+    if (act) {
+        double r = collided ? -P.collision_factor : 0.0;
+        r += -ts * P.cross_track_factor * cte * cte;
+        r += reached ? P.reach_goal_factor : 0.0;
+        const double err = copysign(1.0, P.reference_speed) * (v - P.reference_speed);
+        r += -ts * P.excessive_speed_factor * fmax(0.0, err);
+        r += P.path_progress_factor * (progress - last_prog);
+        if (reward) reward[b] = r;
+        st[6] = progress;
+        st[25] += 1.0;
+    } else if (reward) {
+        reward[b] = 0.0;
+    }
+    if (terminated) terminated[b] = (collided || reached) ? 1 : 0;
+    st[0] = x; st[1] = y; st[2] = th; st[3] = v; st[4] = w; st[5] = clock;
+    st[7] = (double)flags;
+    st[24] = progress;
+}
+
+thread_local std::string g_err;
+static int fail(const char* what, hipError_t e = hipSuccess) {
+    char buf[256];
+    if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    else snprintf(buf, sizeof buf, "%s", what);
+    g_err = buf;
+    return -1;
+}
+
+}  // namespace envgpu
+
+extern "C" {
+
+int32_t mpcgpu_env_record_doubles(const mpcgpu_env_params* params) {
+    envgpu::EnvK k;
+    if (!params || !envgpu::layout(*params, k)) return envgpu::fail("invalid mpcgpu_env_params (P 2..64, M 0..31, K 1..4, E >= 1)");
+    return k.rec;
+}
+
+int32_t mpcgpu_env_step_dev(int32_t device, const mpcgpu_env_params* params, int32_t B, const double* records,
+                            double* state, const int32_t* action, float* obs_internal, float* obs_external,
+                            double* reward, uint8_t* terminated, void* stream) {
+    using namespace envgpu;
+    EnvK k;
+    if (!params || !layout(*params, k)) return fail("invalid mpcgpu_env_params (P 2..64, M 0..31, K 1..4, E >= 1)");
+    if (params->num_segments != NSEG || params->corner_samples != NCORNER)
+        return fail("only num_segments = 8 and corner_samples = 3 are built (rays_reward1.py:18-20)");
+    if (B < 0 || !records || !state || !obs_internal || !obs_external) return fail("null pointer / negative batch");
+    if (B == 0) return 0;
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) return fail("hipSetDevice", e);
+    hipLaunchKernelGGL(env_step_kernel, dim3(B), dim3(WAVE), 0, (hipStream_t)stream, k, records, state, action,
+                       obs_internal, obs_external, reward, terminated, (int)B);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail("env_step_kernel launch", e);
+    return 0;
+}
+
+const char* mpcgpu_env_last_error(void) { return envgpu::g_err.c_str(); }
+
+}  // extern "C"
