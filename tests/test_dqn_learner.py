@@ -1,0 +1,113 @@
+"""DQN collection / learning loop (SB3 semantics of src/test_block_rl.py:68-86).
+CPU: a counting fake environment with the BatchedRaysEnv contract.  GPU: the real HIP environment."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+dqn_train = importlib.import_module("trajtrack_mpcndqn_rlboost_amd.dqn_train")
+
+
+class CountingEnv:
+    """B environments; the observation encodes (env id, step in episode); env b terminates after 3 + b % 3 steps,
+    every 7th step limit truncates.  Deterministic, so buffer contents can be checked exactly."""
+
+    def __init__(self, B=6, device="cpu"):
+        self.B, self.device = B, torch.device(device)
+        self.t = torch.zeros(B, dtype=torch.int64)
+        self.limit = 3 + torch.arange(B) % 3
+
+    def _obs(self):
+        ext = torch.zeros(self.B, 32)
+        ext[:, 0] = torch.arange(self.B)
+        ext[:, 1] = self.t.float()
+        return {"external": ext, "internal": torch.full((self.B, 14), 0.5)}
+
+    def reset(self, mask=None):
+        if mask is None:
+            mask = torch.ones(self.B, dtype=torch.bool)
+        self.t = torch.where(mask, torch.zeros_like(self.t), self.t)
+        return self._obs()
+
+    def step(self, actions, auto_reset=False):
+        self.t = self.t + 1
+        obs = self._obs()
+        terminated = (self.t >= self.limit) & (torch.arange(self.B) % 2 == 0)
+        truncated = (self.t >= self.limit) & ~terminated
+        info = {"success": terminated.clone()}
+        reward = torch.ones(self.B, dtype=torch.float64)
+        done = terminated | truncated
+        if auto_reset and bool(done.any()):
+            info["terminal_observation"] = obs
+            new = self.reset(done)
+            obs = {k: torch.where(done[:, None], new[k], obs[k]) for k in obs}
+        return obs, reward, terminated, truncated, info
+
+
+def test_exploration_schedule_is_sb3_linear():
+    f = dqn_train.exploration_rate
+    assert f(0, 1000) == 1.0 and abs(f(100, 1000) - 0.525) < 1e-12 and abs(f(200, 1000) - 0.05) < 1e-12 and f(900, 1000) == 0.05
+
+
+def test_replay_buffer_wraps_and_samples_stored_rows():
+    buf = dqn_train.ReplayBuffer(10, 46, torch.device("cpu"))
+    for k in range(4):
+        o = torch.full((4, 46), float(k))
+        buf.add(o, o + 0.5, torch.full((4,), k), torch.full((4,), -float(k)), torch.zeros(4))
+    assert buf.size == 10 and buf.pos == 6
+    assert sorted(buf.obs[:, 0].tolist()) == [1.0, 1.0, 2.0, 2.0, 2.0, 2.0, 3.0, 3.0, 3.0, 3.0]
+    s = buf.sample(64, torch.Generator().manual_seed(1))
+    assert torch.equal(s["next_obs"][:, 0], s["obs"][:, 0] + 0.5) and torch.equal(s["rewards"], -s["obs"][:, 0])
+    assert torch.equal(s["actions"].float(), s["obs"][:, 0])
+
+
+def test_learner_stores_terminal_observations_and_follows_the_sb3_counters():
+    torch.manual_seed(0)
+    env = CountingEnv(B=6)
+    learner = dqn_train.DqnLearner(env, buffer_size=4096, learning_starts=24, batch_size=8, train_freq=4,
+                                   gradient_steps=-1, target_update_interval=60)
+    w0 = torch.cat([p.detach().reshape(-1).clone() for p in learner.trainer.q_net.parameters()])
+    stats = learner.learn(total_timesteps=6 * 40)
+    assert stats["timesteps"] == 240 and learner.n_calls == 40
+    # gradient_steps = -1: one update per collected transition once learning has started (after 24 timesteps)
+    assert stats["updates"] == 240 - 24 and learner.trainer.num_updates == 216
+    # hard target sync every 60 env steps = every 10 calls with 6 environments
+    assert learner.trainer.num_target_syncs == 4
+    assert not torch.equal(w0, torch.cat([p.detach().reshape(-1) for p in learner.trainer.q_net.parameters()]))
+    buf = learner.buffer
+    n = buf.size
+    assert n == 240
+    env_id, t_obs, t_next = buf.obs[:n, 0].long(), buf.obs[:n, 1].long(), buf.next_obs[:n, 1].long()
+    # next_obs is always the successor inside the same episode, also on the last step (not the reset observation)
+    assert torch.equal(t_next, t_obs + 1) and torch.equal(buf.next_obs[:n, 0].long(), env_id)
+    limit = 3 + env_id % 3
+    ended = t_next >= limit
+    # terminated rows carry done = 1, time-limit truncations do not (bootstrap continues)
+    assert torch.equal(buf.dones[:n].bool(), ended & (env_id % 2 == 0))
+    assert stats["episodes"] == len(learner.episode_returns) > 10
+    assert set(np.round(learner.episode_returns).astype(int)) == {3, 4, 5}
+
+
+@pytest.mark.gpu
+def test_learner_runs_on_the_hip_environment():
+    import json
+    import os
+    rl_env = importlib.import_module("trajtrack_mpcndqn_rlboost_amd.rl_env")
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "env_rays_traces.npz"))
+    specs = json.loads(bytes(fx["specs_json"]).decode())
+    maps = [rl_env.make_map(sp["boundary"], sp["static"], sp["dynamic"], sp["start"], sp["goal"], sp["path"])
+            for sp in specs.values()]
+    torch.manual_seed(0)
+    env = rl_env.BatchedRaysEnv([maps[i % 2] for i in range(256)], max_episode_steps=60)
+    learner = dqn_train.DqnLearner(env, buffer_size=65536, learning_starts=2048, batch_size=32, train_freq=4,
+                                   gradient_steps=8, target_update_interval=4096)
+    stats = learner.learn(total_timesteps=256 * 120)
+    assert stats["timesteps"] == 256 * 120 and stats["updates"] > 100 and np.isfinite(stats["loss"])
+    assert stats["episodes"] >= 256 and np.isfinite(stats["mean_return"])
+    buf = learner.buffer
+    assert buf.size == 256 * 120 and buf.obs.device.type == "cuda"
+    assert float(buf.obs.min()) >= -1.0 - 1e-6 and float(buf.obs.max()) <= 1.0 + 1e-6   # observation-space bounds
+    assert 0.0 < float(buf.dones.mean()) < 0.2
+    # the memory half of a stored observation is the sector / ray half of the previous one in the same environment
+    assert torch.equal(buf.next_obs[:256, 16:32], buf.obs[:256, 0:16])

@@ -73,6 +73,11 @@ __device__ __forceinline__ unsigned wave_xor(unsigned m) {
     for (int off = 32; off >= 1; off >>= 1) m ^= (unsigned)__shfl_xor((int)m, off, WAVE);
     return m;
 }
+// 1 / x: hardware estimate + one Newton step (~1e-15 relative; the observations are rounded to float32 afterwards)
+__device__ __forceinline__ double fast_rcp(double x) {
+    const double r = __builtin_amdgcn_rcp(x);
+    return r * (2.0 - x * r);
+}
 __device__ __forceinline__ double normalize_distance(double d) {  // components/utils.py:10-15
     return 2.0 / (1.0 + exp(-2.0 * d / 10.0)) - 1.0;
 }
@@ -178,47 +183,85 @@ __global__ __launch_bounds__(WAVE) void env_step_kernel(EnvK k, const double* __
         const double Px = x0 - x, Py = y0 - y, Qx = x1 - x, Qy = y1 - y;
         const double Ex = Qx - Px, Ey = Qy - Py;
         if ((Py > 0.0) != (Qy > 0.0)) {  // even-odd rule along +x from the robot
-            const double xi = Ex * (-Py) / Ey + Px;
+            const double xi = Ex * (-Py) * fast_rcp(Ey) + Px;
             if (xi > 0.0) mask ^= 1u << (owner + 1);
         }
         const double ee = Ex * Ex + Ey * Ey, pe = Px * Ex + Py * Ey, pxe = Px * Ey - Py * Ex;
-        const double t_free = ee > 0.0 ? -pe / ee : 0.0;
+        const double t_free = ee > 0.0 ? -pe * fast_rcp(ee) : 0.0;
+        // Line j through the robot with direction d_j meets the edge's carrier at parameter tc[j]; g0/g1 are the
+        // signed distances (x |d| = 1) of P and of the edge direction from that line.  Odd lines are sector borders
+        // (each shared by two neighbouring sectors), even lines carry the rays -- 16 reciprocals per edge in all.
+        double g0[16], g1[16], tc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            g0[j] = dx[j] * Py - dy[j] * Px;
+            g1[j] = dx[j] * Ey - dy[j] * Ex;
+            tc[j] = -g0[j] * fast_rcp(g1[j]);   // inf / nan when the edge is parallel to the line: handled below
+        }
 #pragma unroll
         for (int i = 0; i < NSEG; ++i) {
             const int jl = (2 * i + 15) & 15, ju = 2 * i + 1, jc = 2 * i;
-            // wedge = {cross(d_lower, X) >= 0} and {cross(X, d_upper) >= 0}: clip the edge's parameter range
+            // wedge = {cross(d_lower, X) >= 0} and {cross(d_upper, X) <= 0}: clip the edge's parameter range [0, 1]
             double t0 = 0.0, t1 = 1.0;
             bool empty = false;
-            {
-                const double f0 = dx[jl] * Py - dy[jl] * Px, f1 = dx[jl] * Ey - dy[jl] * Ex;
-                if (f1 > 0.0) t0 = fmax(t0, -f0 / f1);
-                else if (f1 < 0.0) t1 = fmin(t1, -f0 / f1);
-                else if (f0 < 0.0) empty = true;
-            }
-            {
-                const double f0 = Px * dy[ju] - Py * dx[ju], f1 = Ex * dy[ju] - Ey * dx[ju];
-                if (f1 > 0.0) t0 = fmax(t0, -f0 / f1);
-                else if (f1 < 0.0) t1 = fmin(t1, -f0 / f1);
-                else if (f0 < 0.0) empty = true;
-            }
+            if (g1[jl] > 0.0) t0 = fmax(t0, tc[jl]);
+            else if (g1[jl] < 0.0) t1 = fmin(t1, tc[jl]);
+            else if (g0[jl] < 0.0) empty = true;
+            if (g1[ju] < 0.0) t0 = fmax(t0, tc[ju]);
+            else if (g1[ju] > 0.0) t1 = fmin(t1, tc[ju]);
+            else if (g0[ju] > 0.0) empty = true;
             if (!empty && t0 <= t1) {
                 const double tt = fmin(fmax(t_free, t0), t1);
                 const double cx = Px + tt * Ex, cy = Py + tt * Ey;
-                sec[i] = fmin(sec[i], sqrt(cx * cx + cy * cy));
+                sec[i] = fmin(sec[i], cx * cx + cy * cy);  // squared; the root is taken once, after the reduction
             }
-            const double den = dx[jc] * Ey - dy[jc] * Ex;
-            if (den != 0.0) {
-                const double s = pxe / den, t = (Px * dy[jc] - Py * dx[jc]) / den;
+            // ray i: P + t E = s d_jc with t = tc[jc]; s follows from the projection on d (|d| = 1)
+            if (g1[jc] != 0.0) {
+                const double t = tc[jc];
+                const double s = (Px + t * Ex) * dx[jc] + (Py + t * Ey) * dy[jc];
                 if (s >= 0.0 && t >= 0.0 && t <= 1.0 && s <= L_SECTOR) ray[i] = fmin(ray[i], s);
             }
         }
     }
     mask = wave_xor(mask);
     const bool in_obstacle = (mask & ~1u) != 0u;
+    // 16 minima over 64 lanes as ONE butterfly: every exchange halves the number of values a lane still carries
+    // (8 + 4 + 2 + 1 + 1 + 1 = 17 exchanges instead of 16 x 6).  Afterwards lane l holds value number
+    // 8 b5 + 4 b4 + 2 b3 + b2 (b_k = bit k of l); values 0..7 = squared sector distances, 8..15 = ray distances.
+    double red;
+    {
+        double v8[8], v4[4], v2[2];
+        const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8, h2 = lane & 4;
 #pragma unroll
-    for (int i = 0; i < NSEG; ++i) {
-        sec[i] = in_obstacle ? 0.0 : wave_min(sec[i]);  // the robot itself belongs to sector ∩ obstacle
-        ray[i] = in_obstacle ? 0.0 : wave_min(ray[i]);
+        for (int i = 0; i < 8; ++i) {
+            const double keep = h5 ? ray[i] : sec[i], send = h5 ? sec[i] : ray[i];
+            v8[i] = fmin(keep, __shfl_xor(send, 32, WAVE));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const double keep = h4 ? v8[4 + i] : v8[i], send = h4 ? v8[i] : v8[4 + i];
+            v4[i] = fmin(keep, __shfl_xor(send, 16, WAVE));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const double keep = h3 ? v4[2 + i] : v4[i], send = h3 ? v4[i] : v4[2 + i];
+            v2[i] = fmin(keep, __shfl_xor(send, 8, WAVE));
+        }
+        const double keep = h2 ? v2[1] : v2[0], send = h2 ? v2[0] : v2[1];
+        red = fmin(keep, __shfl_xor(send, 4, WAVE));
+        red = fmin(red, __shfl_xor(red, 2, WAVE));
+        red = fmin(red, __shfl_xor(red, 1, WAVE));
+    }
+    // ---- external observation with one-step memory (ext_obsv_sector_and_ray.py:66-74): 16 lanes, one entry each
+    if ((lane & 3) == 0) {
+        const int idx = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+        // inside a padded obstacle the robot itself belongs to sector ∩ obstacle: every distance is 0
+        const double d = in_obstacle ? 0.0 : (idx < NSEG ? sqrt(red) : red);
+        const float o = (float)normalize_distance(d);
+        float* oe = obs_ext + (size_t)b * MPCGPU_ENV_EXTERNAL_OBS;
+        oe[idx] = o;
+        oe[2 * NSEG + idx] = (float)st[8 + idx];
+        st[8 + idx] = (double)o;
     }
 
     // ---- path progress = LineString.project: first closest segment (environment.py:118)
@@ -259,6 +302,23 @@ __global__ __launch_bounds__(WAVE) void env_step_kernel(EnvK k, const double* __
     const unsigned long long reach = __ballot(lane < n_path && cum[lane < n_path ? lane : 0] >= progress);
     int icorner = reach ? __ffsll((long long)reach) - 1 : n_path - 1;
 
+    // ---- path observations (components/int_obsv_reference_path_{sample,corner}.py): lanes 0..3, one point each
+    float* oi = obs_int + (size_t)b * MPCGPU_ENV_INTERNAL_OBS;
+    if (lane < 1 + NCORNER) {
+        double qx = spx, qy = spy;
+        if (lane > 0) {
+            int ic = icorner + lane - 1;
+            if (ic > n_path - 1) ic = n_path - 1;
+            qx = pxy[2 * ic]; qy = pxy[2 * ic + 1];
+        }
+        // cos / sin of (bearing - theta) and the normalised distance; atan2(0, 0) = 0 for a coincident point
+        const double ddx = qx - x, ddy = qy - y;
+        const double d = sqrt(ddx * ddx + ddy * ddy);
+        double cr = cth, sr = -sth;
+        if (d > 0.0) { cr = (ddx * cth + ddy * sth) / d; sr = (ddy * cth - ddx * sth) / d; }
+        float* o = oi + 2 + 3 * lane;
+        o[0] = (float)cr; o[1] = (float)sr; o[2] = (float)normalize_distance(d);
+    }
     if (lane != 0) return;
     // ---- status flags, sticky (environment.py:113-116)
     if (in_obstacle) flags |= 1;
@@ -266,36 +326,10 @@ __global__ __launch_bounds__(WAVE) void env_step_kernel(EnvK k, const double* __
     if (sqrt((gx - x) * (gx - x) + (gy - y) * (gy - y)) < P.radius) flags |= 4;
     const bool collided = (flags & 3) != 0, reached = (flags & 4) != 0;
 
-    // ---- internal observation (components/int_obsv_*.py)
-    float* oi = obs_int + (size_t)b * MPCGPU_ENV_INTERNAL_OBS;
+    // ---- speed and angular velocity (components/int_obsv_speed.py, int_obsv_angular_velocity.py)
     oi[0] = (float)(2.0 * (v - P.speed_min) / (P.speed_max - P.speed_min) - 1.0);
     // the reference normalises the angular velocity with the angular ACCELERATION limits (int_obsv_angular_velocity.py:13-19)
     oi[1] = (float)(2.0 * (w - P.angacc_min) / (P.angacc_max - P.angacc_min) - 1.0);
-    auto relative = [&](double qx, double qy, float* o) {  // cos / sin of (bearing - theta), normalised distance
-        const double ddx = qx - x, ddy = qy - y;
-        const double d = sqrt(ddx * ddx + ddy * ddy);
-        double cr = cth, sr = -sth;  // atan2(0, 0) = 0
-        if (d > 0.0) { cr = (ddx * cth + ddy * sth) / d; sr = (ddy * cth - ddx * sth) / d; }
-        o[0] = (float)cr; o[1] = (float)sr; o[2] = (float)normalize_distance(d);
-    };
-    relative(spx, spy, oi + 2);
-    for (int j = 0; j < NCORNER; ++j) {
-        if (icorner > n_path - 1) icorner = n_path - 1;
-        relative(pxy[2 * icorner], pxy[2 * icorner + 1], oi + 5 + 3 * j);
-        ++icorner;
-    }
-
-    // ---- external observation with one-step memory (ext_obsv_sector_and_ray.py:66-74)
-    float* oe = obs_ext + (size_t)b * MPCGPU_ENV_EXTERNAL_OBS;
-#pragma unroll
-    for (int i = 0; i < NSEG; ++i) {
-        const float a = (float)normalize_distance(sec[i]), r = (float)normalize_distance(ray[i]);
-        oe[i] = a; oe[NSEG + i] = r;
-        oe[2 * NSEG + i] = (float)st[8 + i];
-        oe[3 * NSEG + i] = (float)st[8 + NSEG + i];
-    }
-#pragma unroll
-    for (int i = 0; i < 2 * NSEG; ++i) st[8 + i] = (double)oe[i];
 
     // ---- reward R1 (rays_reward1.py:26-39; summed in component order)
     if (act) {

@@ -10,7 +10,7 @@ gradient of its shard of the batch, ONE all-reduce of a single flat bucket of 1 
 from __future__ import annotations
 
 import copy
-from typing import Dict, Optional
+from typing import Callable, Dict, Optional
 
 import torch
 import torch.distributed as dist
@@ -71,6 +71,135 @@ class DqnTrainer:
         nn.utils.clip_grad_norm_(self._params, self.max_grad_norm)
         self.optimizer.step()
         self.num_updates += 1
-        if self.num_updates % self.target_update_interval == 0:
-            self.q_net_target.load_state_dict(self.q_net.state_dict())
-        return float(loss.detach())
+        if self.target_update_interval and self.num_updates % self.target_update_interval == 0:
+            self.sync_target()
+        return loss.detach()
+
+    def sync_target(self) -> None:
+        """Hard target update (SB3 ``polyak_update`` with tau = 1)."""
+        self.q_net_target.load_state_dict(self.q_net.state_dict())
+        self.num_target_syncs = getattr(self, "num_target_syncs", 0) + 1
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# collection + learning loop over the batched environment (SB3 ``DQN.learn`` semantics of the reference's training
+# script: src/test_block_rl.py:68-86 -- n_envs vectorised environments, learning_starts 50 000, train_freq 4 steps,
+# gradient_steps -1 (one gradient step per collected transition), batch 32, buffer 1e6, epsilon 1.0 -> 0.05 over the
+# first 20 % of the run, hard target update every 10 000 environment steps)
+# ----------------------------------------------------------------------------------------------------------------------
+def flatten_observation(obs: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """SB3's CombinedExtractor concatenates the dict entries in sorted key order: ``external`` (32) then ``internal``
+    (14) -- the input layout of the reference's trained network (see dqn.py)."""
+    return torch.cat([obs["external"], obs["internal"]], dim=1)
+
+
+class ReplayBuffer:
+    """Uniform ring buffer, resident on the environment's device (transitions never visit the host)."""
+
+    def __init__(self, capacity: int, obs_dim: int, device):
+        self.capacity, self.device = int(capacity), device
+        self.obs = torch.zeros(self.capacity, obs_dim, dtype=torch.float32, device=device)
+        self.next_obs = torch.zeros_like(self.obs)
+        self.actions = torch.zeros(self.capacity, dtype=torch.int64, device=device)
+        self.rewards = torch.zeros(self.capacity, dtype=torch.float32, device=device)
+        self.dones = torch.zeros(self.capacity, dtype=torch.float32, device=device)
+        self.pos, self.size = 0, 0
+
+    def add(self, obs, next_obs, actions, rewards, dones) -> None:
+        n = obs.shape[0]
+        idx = (self.pos + torch.arange(n, device=self.device)) % self.capacity
+        self.obs[idx], self.next_obs[idx] = obs, next_obs
+        self.actions[idx] = actions.to(torch.int64)
+        self.rewards[idx] = rewards.to(torch.float32)
+        self.dones[idx] = dones.to(torch.float32)
+        self.pos = (self.pos + n) % self.capacity
+        self.size = min(self.size + n, self.capacity)
+
+    def sample(self, n: int, generator: Optional[torch.Generator] = None) -> Dict[str, torch.Tensor]:
+        idx = torch.randint(0, self.size, (n,), device=self.device, generator=generator)
+        return dict(obs=self.obs[idx], actions=self.actions[idx], rewards=self.rewards[idx],
+                    next_obs=self.next_obs[idx], dones=self.dones[idx])
+
+
+def exploration_rate(step: int, total: int, fraction: float = 0.2, initial: float = 1.0, final: float = 0.05) -> float:
+    """SB3 ``get_linear_fn``: linear from ``initial`` to ``final`` over the first ``fraction`` of the run."""
+    progress = step / float(total)
+    if progress > fraction:
+        return final
+    return initial + progress * (final - initial) / fraction
+
+
+class DqnLearner:
+    """Collect with an epsilon-greedy policy on a batched environment and update the Q-network.
+
+    ``env`` needs ``B``, ``device``, ``reset()`` and ``step(actions, auto_reset=True)`` with the contract of
+    :class:`rl_env.BatchedRaysEnv`.  With ``torch.distributed`` initialised every rank drives its own shard of
+    environments and its own buffer; gradients are summed by :class:`DqnTrainer`'s single flat all-reduce."""
+
+    def __init__(self, env, trainer: Optional[DqnTrainer] = None, buffer_size: int = 1_000_000,
+                 learning_starts: int = 50_000, batch_size: int = 32, train_freq: int = 4, gradient_steps: int = -1,
+                 target_update_interval: int = 10_000, exploration_fraction: float = 0.2,
+                 exploration_initial_eps: float = 1.0, exploration_final_eps: float = 0.05, seed: int = 0):
+        self.env = env
+        self.device = env.device
+        self.trainer = trainer if trainer is not None else DqnTrainer(device=str(self.device))
+        self.trainer.target_update_interval = 0   # the learner syncs on environment steps, as SB3 does
+        self.buffer = ReplayBuffer(buffer_size, 46, self.device)
+        self.learning_starts, self.batch_size, self.train_freq = learning_starts, batch_size, train_freq
+        self.gradient_steps, self.target_update_interval = gradient_steps, target_update_interval
+        self.eps = (exploration_fraction, exploration_initial_eps, exploration_final_eps)
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(seed + (dist.get_rank() if dist.is_available() and dist.is_initialized() else 0))
+        self.num_timesteps, self.n_calls = 0, 0
+        self.episode_returns, self.episode_successes = [], []
+
+    def act(self, obs_flat: torch.Tensor, epsilon: float) -> torch.Tensor:
+        greedy = self.trainer.q_net.greedy_actions(obs_flat)
+        B = obs_flat.shape[0]
+        explore = torch.rand(B, device=self.device, generator=self.gen) < epsilon
+        rand = torch.randint(0, 9, (B,), device=self.device, generator=self.gen)
+        return torch.where(explore, rand, greedy)
+
+    def learn(self, total_timesteps: int, callback: Optional[Callable[["DqnLearner"], None]] = None) -> Dict[str, float]:
+        env, B = self.env, self.env.B
+        obs = flatten_observation(env.reset())
+        ep_return = torch.zeros(B, dtype=torch.float64, device=self.device)
+        last_loss = torch.zeros((), device=self.device)
+        n_updates = 0
+        while self.num_timesteps < total_timesteps:
+            collected = 0
+            for _ in range(self.train_freq):
+                eps = exploration_rate(self.num_timesteps, total_timesteps, *self.eps)
+                actions = self.act(obs, eps)
+                nxt, reward, terminated, truncated, info = env.step(actions, auto_reset=True)
+                done = terminated | truncated
+                nxt_flat = flatten_observation(nxt)
+                # the transition stores the observation the episode ended in, not the first one of the next episode;
+                # a time-limit truncation is not a terminal state for the bootstrap (SB3 handle_timeout_termination)
+                stored_next = flatten_observation(info["terminal_observation"]) if "terminal_observation" in info else nxt_flat
+                self.buffer.add(obs, stored_next, actions, reward, terminated)
+                ep_return += reward
+                if bool(done.any()):
+                    self.episode_returns += ep_return[done].tolist()
+                    self.episode_successes += info["success"][done].tolist()
+                    ep_return = torch.where(done, torch.zeros_like(ep_return), ep_return)
+                obs = nxt_flat
+                self.num_timesteps += B
+                self.n_calls += 1
+                collected += B
+                if self.n_calls % max(self.target_update_interval // B, 1) == 0:
+                    self.trainer.sync_target()
+                if self.num_timesteps >= total_timesteps:
+                    break
+            if self.num_timesteps > self.learning_starts and self.buffer.size >= self.batch_size:
+                steps = self.gradient_steps if self.gradient_steps >= 0 else collected
+                for _ in range(steps):
+                    last_loss = self.trainer.update(self.buffer.sample(self.batch_size, self.gen))
+                n_updates += steps
+            if callback is not None:
+                callback(self)
+        recent = self.episode_returns[-100:]
+        return dict(timesteps=self.num_timesteps, updates=n_updates, loss=float(last_loss),
+                    episodes=len(self.episode_returns),
+                    mean_return=float(sum(recent) / len(recent)) if recent else float("nan"),
+                    success_rate=float(sum(self.episode_successes[-100:]) / max(1, len(self.episode_successes[-100:]))))
