@@ -1,0 +1,51 @@
+"""Closed loop of the DQN-boosted MPC on the GPU (reference: src/main.py decision modes): environment kernel +
+the reference's trained Q-network weights + batched MPC solve.  No reference numbers exist for a closed loop (OpEn
+cannot be built here), so this is an end-to-end behaviour test: the robots get past the unexpected box and the crossing
+obstacle to the goal, the hybrid mode does use the DQN's proposal, and a wrong observation pipeline would show up as
+the pure-DQN policy (trained on the reference's environment) failing."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _setup(B):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    loop = importlib.import_module("hybrid_loop")
+    from trajtrack_mpcndqn_rlboost_amd import MpcConfig
+    from trajtrack_mpcndqn_rlboost_amd.dqn import QNetwork
+    w = np.load(os.path.join(ROOT, "tests", "golden", "dqn_ray.npz"))
+    q = QNetwork().load_arrays({k: w[k] for k in w.files if k.startswith("w")})
+    cfg = MpcConfig(os.path.join(ROOT, "config", "mpc_longiter.yaml"))
+    rng = np.random.default_rng(3)
+    return loop, cfg, q, [loop.scene(rng) for _ in range(B)]
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_mpc_and_hybrid_reach_the_goal_without_collision(mode):
+    hybrid = importlib.import_module("trajtrack_mpcndqn_rlboost_amd.hybrid")
+    loop, cfg, q, scenes = _setup(8)
+    run = hybrid.BatchedHybrid(cfg, scenes, q, decision_mode=mode)
+    out = run.run(200)
+    assert out["done"].all()
+    assert not out["collided"].any()
+    assert out["success"].mean() >= 0.75
+    assert np.hypot(out["states"][:, 0] - 15.4, out["states"][:, 1] - 3.5).max() < 1.0
+    if mode == 2:
+        assert (out["switch_ticks"] > 0).any()          # the DQN proposal was tracked at some point
+    else:
+        assert (out["switch_ticks"] == 0).all()
+
+
+def test_pure_dqn_policy_of_the_reference_works_in_this_environment():
+    hybrid = importlib.import_module("trajtrack_mpcndqn_rlboost_amd.hybrid")
+    loop, cfg, q, scenes = _setup(16)
+    run = hybrid.BatchedHybrid(cfg, scenes, q, decision_mode=0)
+    out = run.run(200)
+    assert out["success"].mean() >= 0.5
+    assert out["progress"].mean() > 10.0                  # of a 14.8 m path

@@ -74,27 +74,39 @@ class BatchedTracker:
                 self.other_robot_states[i] = block.reshape(-1).tolist()
 
     # -- one control tick for all robots ---------------------------------------------------------------------------
-    def assemble(self, mode: str = "work") -> np.ndarray:
+    def local_refs(self) -> np.ndarray:
+        """``get_local_ref_traj`` for every robot ([B, N, 3]); advances the nearest-sample indices like the reference's
+        call does (``interface_mpc.py:73-80``).  Pass a (modified) copy to :meth:`step` as ``refs``."""
+        cfg = self.config
+        out = np.empty((self.B, cfg.N_hor, 3))
+        for i in range(self.B):
+            out[i], self.idx_ref[i] = local_reference_window(self.idx_ref[i], self.ref_trajs[i], self.states[i],
+                                                             cfg.action_steps, cfg.N_hor)
+        return out
+
+    def assemble(self, mode: str = "work", refs: Optional[np.ndarray] = None) -> np.ndarray:
         cfg = self.config
         base_speed, tuning = work_mode(cfg, mode)
         P = np.zeros((self.B, cfg.num_params))
+        if refs is None:
+            refs = self.local_refs()
         for i in range(self.B):
-            ref, idx = local_reference_window(self.idx_ref[i], self.ref_trajs[i], self.states[i], cfg.action_steps,
-                                              cfg.N_hor)
-            self.idx_ref[i] = idx
+            ref = np.asarray(refs[i], dtype=float)
             P[i] = assemble_parameters(self.states[i], ref[-1], self.last_actions[i], tuning,
                                        ref.reshape(-1), speed_references(cfg, base_speed, self.states[i], self.goals[i]),
                                        self.other_robot_states[i], self.stc_constraints[i], self.dyn_constraints[i],
                                        self.stc_weights, self.dyn_weights)
         return P
 
-    def step(self, mode: str = "work", initial_guess: Optional[np.ndarray] = None):
+    def step(self, mode: str = "work", initial_guess: Optional[np.ndarray] = None, refs: Optional[np.ndarray] = None):
         """Solve all robots, apply the first ``action_steps`` inputs.  Returns (actions [B, nu], pred_states
-        [B, N, ns], cost [B]); robots that already reached their goal keep their state (action 0)."""
+        [B, N, ns], cost [B]); robots that already reached their goal keep their state (action 0).
+        ``refs`` [B, N, 3]: the reference each robot tracks this tick (``get_action(current_ref_traj)``,
+        ``interface_mpc.py:82-88``); default: the local window of its global reference."""
         cfg = self.config
         near = np.all(np.abs(self.states[:, :2] - self.goals[:, :2]) <= 0.05, axis=1)
         self.active &= ~(near & (np.abs(self.last_actions[:, 0]) < 0.05))     # check_termination_condition
-        P = self.assemble(mode)
+        P = self.assemble(mode, refs)
         res = self.solver.solve(P, initial_guess)
         self.last_result = res
         u = res.solution.reshape(self.B, cfg.N_hor, cfg.nu)

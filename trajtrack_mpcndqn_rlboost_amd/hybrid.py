@@ -1,0 +1,253 @@
+"""DQN-boosted MPC, batched: the decision loop of the reference's ``src/main.py:93-243`` for B robots per tick.
+
+Pieces (each mirrors one reference item):
+
+* :class:`HintSwitcher`   -- ``src/main_pre.py:27-52``: when does the MPC track the DQN's proposal instead of the
+  original reference?  Same state machine, polygon distance / containment written out (shapely is not a dependency).
+* :func:`ref_traj_filter` -- ``src/main.py:34-41``.
+* :func:`circle_to_rect`  -- ``src/main.py:86-90``.
+* :func:`inflate_polygon` -- ``Inflator`` / ``geometry_tools.polygon_inflate`` (``src/main_pre.py:18-24``,
+  ``src/pkg_obstacle/geometry_tools.py:21-23``): mitre-join offset, the obstacle list the MPC and the switcher see.
+* :class:`BatchedHybrid`  -- the loop: environment status / observation (``rl_env.BatchedRaysEnv``, one HIP kernel),
+  Q-network action, 20-step RL reference (``dqn.rl_reference``), constant-velocity obstacle predictions
+  (``feeders``), reference switch, one batched MPC solve (``BatchedTracker`` -> ``libmpcgpu.so``).
+  ``decision_mode``: 0 pure DQN, 1 pure MPC, 2 hybrid -- as in ``main.py:96-98``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import rl_env, rl_geometry as rg
+from .batched_tracker import BatchedTracker
+from .config import MpcConfig
+from .dqn import QNetwork, merge_reference, rl_reference
+from .feeders import DYN_OBS_SIZE, constant_velocity_prediction
+
+MAX_RUN_STEP = 200  # main.py:30
+
+
+# ---- geometry the switcher needs -----------------------------------------------------------------------------------
+def polygon_distance(polygon: np.ndarray, point) -> float:
+    """shapely ``Polygon.distance(Point)``: 0 inside, else the distance to the outline."""
+    ring = np.asarray(polygon, dtype=float).reshape(-1, 2)
+    if rg.point_in_ring(point, ring):
+        return 0.0
+    px, py = float(point[0]), float(point[1])
+    best = math.inf
+    for i in range(len(ring)):
+        ax, ay = ring[i]
+        bx, by = ring[(i + 1) % len(ring)]
+        dx, dy = bx - ax, by - ay
+        den = dx * dx + dy * dy
+        t = 0.0 if den == 0.0 else min(1.0, max(0.0, ((px - ax) * dx + (py - ay) * dy) / den))
+        best = min(best, math.hypot(px - (ax + t * dx), py - (ay + t * dy)))
+    return best
+
+
+def inflate_polygon(polygon: Sequence[Sequence[float]], margin: float, mitre_limit: float = 5.0) -> List[List[float]]:
+    """Mitre-join offset of a simple polygon (GEOS ``buffer(margin, join_style=mitre)`` with the default limit 5):
+    every vertex moves to the intersection of its two offset edges; a corner sharper than the limit is bevelled at
+    ``mitre_limit * margin`` from the vertex.  Local construction, valid while the offset ring stays simple (true for
+    the reference's obstacle sets)."""
+    ring = rg.orient(polygon, ccw=True)
+    n = len(ring)
+    out: List[List[float]] = []
+    for i in range(n):
+        v = ring[i]
+        d0 = v - ring[i - 1]
+        d1 = ring[(i + 1) % n] - v
+        d0, d1 = d0 / np.hypot(*d0), d1 / np.hypot(*d1)
+        n0 = np.array([d0[1], -d0[0]])
+        n1 = np.array([d1[1], -d1[0]])
+        cosang = float(n0 @ n1)
+        if 1.0 + cosang < 1e-12:                       # a spike: 180 degree turn
+            out += [(v + margin * n0).tolist(), (v + margin * n1).tolist()]
+            continue
+        mitre = (n0 + n1) / (1.0 + cosang)             # |mitre| = 1 / cos(half turning angle)
+        ratio = float(np.hypot(*mitre))
+        turn = d0[0] * d1[1] - d0[1] * d1[0]
+        if ratio <= mitre_limit or turn * margin < 0:  # inside turns always collapse to the intersection
+            out.append((v + margin * mitre).tolist())
+        else:                                          # limited mitre: bevel at mitre_limit * |margin| on the bisector
+            bis = mitre / ratio
+            mid = v + margin * mitre_limit * bis
+            perp = np.array([-bis[1], bis[0]])
+            # the bevel's end points lie on the two offset edges
+            h0 = ((v + margin * n0 - mid) @ n0) / (perp @ n0) if abs(perp @ n0) > 1e-15 else 0.0
+            out += [(mid + h0 * perp).tolist(), (mid - h0 * perp).tolist()]
+    return out
+
+
+def circle_to_rect(pos, radius: float = DYN_OBS_SIZE) -> List[List[float]]:
+    return [[pos[0] - radius, pos[1] - radius], [pos[0] + radius, pos[1] - radius],
+            [pos[0] + radius, pos[1] + radius], [pos[0] - radius, pos[1] + radius]]
+
+
+def ref_traj_filter(original: np.ndarray, new: np.ndarray, decay: float = 1.0) -> np.ndarray:
+    """Blend of the two references with a weight that is squared after every row (1 stays 1: the proposal is taken
+    as it is) and cut to 0 below 1e-2."""
+    filtered = np.array(original, dtype=float, copy=True)
+    for i in range(filtered.shape[0]):
+        filtered[i, :] = (1 - decay) * filtered[i, :] + decay * new[i, :]
+        decay *= decay
+        if decay < 1e-2:
+            decay = 0.0
+    return filtered
+
+
+class HintSwitcher:
+    """Switch to the DQN's proposal when the original reference runs through an obstacle that is closer than
+    ``max_switch_distance``; switch back after the robot has been farther than ``min_detach_distance`` from an
+    obstacle for more than ``min_detach_steps`` calls.  The loop order and the early return are the reference's."""
+
+    def __init__(self, max_switch_distance: float, min_detach_distance: float, min_detach_steps: float = 5):
+        self.switch_distance = max_switch_distance
+        self.detach_distance = min_detach_distance
+        self.detach_steps = min_detach_steps
+        self.detach_cnt = 0
+        self.switch_on = False
+
+    def switch(self, current_position, original_traj, new_traj, obstacle_list) -> bool:
+        counted = False
+        rings = [np.asarray(ob, dtype=float).reshape(-1, 2) for ob in obstacle_list]
+        dists = [polygon_distance(r, current_position) for r in rings]   # does not depend on the trajectory row
+        for old_pos, _new_pos in zip(original_traj, new_traj):
+            for ring, dist in zip(rings, dists):
+                if rg.point_in_ring(old_pos[:2], ring):
+                    if dist < self.switch_distance and not self.switch_on:
+                        self.switch_on = True
+                        return self.switch_on
+                elif dist > self.detach_distance and self.switch_on:
+                    if self.detach_cnt > self.detach_steps:
+                        self.switch_on = False
+                        self.detach_cnt = 0
+                    elif not counted:
+                        self.detach_cnt += 1
+                        counted = True
+        return self.switch_on
+
+
+# ---- the batched decision loop ----------------------------------------------------------------------------------------
+class BatchedHybrid:
+    """B robots, each in its own copy of a scene.  ``scenes[i]``: dict with ``boundary``, ``static`` (polygons),
+    ``dynamic`` (``rl_env.periodic_obstacle`` arguments), ``start`` (x, y, theta, v, w), ``goal`` (x, y), ``path``.
+
+    One tick = one environment kernel launch + one Q-network forward + one batched MPC solve."""
+
+    def __init__(self, config: MpcConfig, scenes: Sequence[Dict], q_net: QNetwork, decision_mode: int = 2,
+                 device: int = 0, inflate_margin: float = 0.8, switcher=(10, 2, 10), tracker: Optional[BatchedTracker] = None):
+        import torch
+        if decision_mode not in (0, 1, 2):
+            raise ValueError("decision_mode: 0 pure DQN, 1 pure MPC, 2 hybrid")
+        self._torch = torch
+        self.config, self.mode, self.B = config, decision_mode, len(scenes)
+        self.scenes = list(scenes)
+        self.maps = [rl_env.make_map(s["boundary"], s["static"], s["dynamic"], s["start"], s["goal"], s["path"])
+                     for s in scenes]
+        self.env = rl_env.BatchedRaysEnv(self.maps, device=device, time_step=0.2)   # gym.make default (environment.py:53)
+        self.q_net = q_net.to(self.env.device)
+        self.tracker = tracker if tracker is not None else BatchedTracker(config, self.B, device=device)
+        self.inflated = [[inflate_polygon(poly, inflate_margin) for poly in s["static"]] for s in scenes]
+        self.switchers = [HintSwitcher(*switcher) for _ in scenes]
+        self.reset()
+
+    def reset(self):
+        cfg = self.config
+        self.obs = self.env.reset()
+        for i, s in enumerate(self.scenes):
+            start = np.asarray(s["start"], dtype=float)
+            self.tracker.initialization(i, start[:3], np.array([s["goal"][0], s["goal"][1], 0.0]), s["path"])
+            self.tracker.update_static_constraints(i, self.inflated[i])
+            self.switchers[i].__init__(self.switchers[i].switch_distance, self.switchers[i].detach_distance,
+                                       self.switchers[i].detach_steps)
+        self.last_dyn = None
+        self.done = np.zeros(self.B, dtype=bool)
+        self.success = np.zeros(self.B, dtype=bool)
+        self.collided = np.zeros(self.B, dtype=bool)
+        self.steps = np.zeros(self.B, dtype=int)
+        self.switch_on = np.zeros(self.B, dtype=bool)
+        self.switch_ticks = np.zeros(self.B, dtype=int)   # ticks on which the MPC tracked the DQN's proposal
+        self.t = 0
+
+    def dynamic_positions(self) -> List[np.ndarray]:
+        """Current key-frame positions of every environment's dynamic obstacles (main.py:127)."""
+        clock = self.env.state[:, 5].cpu().numpy()
+        out = []
+        for b, m in enumerate(self.maps):
+            n_static = len(self.scenes[b]["static"])
+            out.append(np.array([rl_env.keyframe_pose(ob, clock[b])[:2] for ob in m["obstacles"][n_static:]]).reshape(-1, 2))
+        return out
+
+    def _flat(self, obs):
+        return self._torch.cat([obs["external"], obs["internal"]], dim=1)
+
+    def tick(self) -> Dict[str, np.ndarray]:
+        torch, cfg, env, trk = self._torch, self.config, self.env, self.tracker
+        dyn_now = self.dynamic_positions()
+        if self.last_dyn is None:
+            self.last_dyn = dyn_now
+        preds = [constant_velocity_prediction(self.last_dyn[b], dyn_now[b], steps=cfg.N_hor) if len(dyn_now[b]) else None
+                 for b in range(self.B)]
+        self.last_dyn = dyn_now
+        live = ~self.done
+
+        if self.mode == 0:                                   # pure DQN: main.py:139-152
+            actions = self.q_net.greedy_actions(self._flat(self.obs))
+            self.obs, _, term, trunc, info = env.step(actions)
+            trk.states[:] = env.agent_state[:, :3].cpu().numpy()
+            chosen = None
+        else:
+            # the environment follows the tracker: position / heading from the MPC state, speeds from its last action
+            st = np.concatenate([trk.states, trk.last_actions], axis=1)
+            env.set_agent_state(st)
+            if self.mode == 1:                               # main.py:154-157: env.step(0) "just for ... status"
+                self.obs, _, term, trunc, info = env.step(torch.zeros(self.B, dtype=torch.int32))
+                chosen = trk.local_refs()
+            else:                                            # main.py:176-214
+                actions = self.q_net.greedy_actions(self._flat(self.obs)).cpu().numpy()
+                env.state[:, 5] += env.time_step             # step_obstacles()
+                self.obs = env.observe()                     # update_status() + get_observation()
+                term = env.terminated.bool()
+                info = {"success": env.flags[:, 2]}
+                rl_ref, _ = rl_reference(env.agent_state.cpu().numpy(), actions, cfg.ts, steps=20, ref_speed=1.0)
+                original = trk.local_refs()
+                proposal = merge_reference(rl_ref[:, :cfg.N_hor], original)
+                chosen = original.copy()
+                for b in range(self.B):
+                    if self.done[b]:
+                        continue
+                    filtered = ref_traj_filter(original[b], proposal[b], decay=1)
+                    obstacles = self.inflated[b] + [circle_to_rect(p) for p in dyn_now[b]]
+                    on = self.switchers[b].switch(trk.states[b, :2], original[b].tolist(), filtered.tolist(), obstacles)
+                    self.switch_on[b] = on
+                    self.switch_ticks[b] += int(on)
+                    if on:
+                        chosen[b] = filtered
+            for b in range(self.B):
+                if preds[b] is not None:
+                    trk.update_dynamic_constraints(b, preds[b])
+            trk.active &= live
+            trk.step(refs=chosen)
+            # get_action returns None once the tracker's own termination test fires (interface_mpc.py:83-85)
+            self.done |= live & ~trk.active
+        term = term.cpu().numpy().astype(bool)
+        flags = env.flags.cpu().numpy()
+        self.success |= live & flags[:, 2]
+        self.collided |= live & (flags[:, 0] | flags[:, 1])
+        self.done |= live & term
+        self.steps += live
+        self.t += 1
+        return dict(done=self.done.copy(), success=self.success.copy(), collided=self.collided.copy(),
+                    switch_on=self.switch_on.copy(), states=trk.states.copy())
+
+    def run(self, max_steps: int = MAX_RUN_STEP) -> Dict[str, np.ndarray]:
+        out = None
+        for _ in range(max_steps):
+            out = self.tick()
+            if out["done"].all():
+                break
+        return dict(out, steps=self.steps.copy(), switch_ticks=self.switch_ticks.copy(),
+                    progress=self.env.path_progress.cpu().numpy())

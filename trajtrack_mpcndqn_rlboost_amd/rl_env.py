@@ -57,6 +57,22 @@ def periodic_obstacle(p1, p2, freq: float, rx: float, ry: float, angle: float, c
                 keyframes=[(p1[0], p1[1], rot), (p2[0], p2[1], rot)], interp="cosine", offset=0.0)
 
 
+def keyframe_pose(obstacle: Dict, time: float):
+    """(x, y, rotation) of an obstacle at ``time``: the cyclic key-frame animation of ``obstacle.py:71-88`` (host-side
+    twin of what the kernel evaluates per step; used by callers that need obstacle positions, e.g. the MPC feeders)."""
+    steps, frames = obstacle["time_steps"], obstacle["keyframes"]
+    tm = (time + obstacle["offset"]) % float(sum(steps))
+    t = 0.0
+    for i in range(len(frames)):
+        t += steps[i]
+        if t <= tm < t + steps[i + 1]:
+            x = (tm - t) / steps[i + 1]
+            alpha = (1.0 - math.cos(x * math.pi)) / 2.0 if obstacle["interp"] == "cosine" else x
+            k0, k1 = frames[i], frames[(i + 1) % len(frames)]
+            return tuple(k0[j] * (1.0 - alpha) + k1[j] * alpha for j in range(3))
+    return tuple(frames[-1])
+
+
 def make_map(boundary, static: Sequence, dynamic: Sequence[Dict], start, goal, path,
              radius: float = ROBOT["radius"]) -> Dict:
     """Map description -> the spec both the record packer and ``oracle/rl_env_numpy.py`` consume."""
