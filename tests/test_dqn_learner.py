@@ -111,3 +111,39 @@ def test_learner_runs_on_the_hip_environment():
     assert 0.0 < float(buf.dones.mean()) < 0.2
     # the memory half of a stored observation is the sector / ray half of the previous one in the same environment
     assert torch.equal(buf.next_obs[:256, 16:32], buf.obs[:256, 0:16])
+
+
+def _learner_worker(rank, world, port, tmpdir):
+    import os
+    import sys
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mod = importlib.import_module("trajtrack_mpcndqn_rlboost_amd.dqn_train")
+    torch.manual_seed(0)                       # same initial network on every rank
+    env = CountingEnv(B=4 + 2 * rank)          # ranks own different environments (different data, different sizes)
+    learner = mod.DqnLearner(env, buffer_size=1024, learning_starts=0, batch_size=8, train_freq=2, gradient_steps=3,
+                             target_update_interval=10_000, seed=5)
+    stats = learner.learn(total_timesteps=env.B * 10)
+    flat = torch.cat([p.detach().reshape(-1) for p in learner.trainer.q_net.parameters()])
+    np.save(os.path.join(tmpdir, f"w_{rank}.npy"), flat.numpy())
+    np.save(os.path.join(tmpdir, f"u_{rank}.npy"), np.array([stats["updates"]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_learners_share_one_network(tmp_path):
+    """world_size 2 over gloo: each rank collects from its own environments into its own buffer; the gradient
+    all-reduce inside every update keeps the two Q-networks identical although the ranks see different data."""
+    import os
+    import torch.multiprocessing as mp
+    port = 29900 + os.getpid() % 500
+    mp.start_processes(_learner_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    w0, w1 = np.load(tmp_path / "w_0.npy"), np.load(tmp_path / "w_1.npy")
+    assert np.load(tmp_path / "u_0.npy")[0] == np.load(tmp_path / "u_1.npy")[0] == 15
+    assert np.array_equal(w0, w1)
+    torch.manual_seed(0)
+    init = torch.cat([p.detach().reshape(-1) for p in dqn_train.DqnTrainer().q_net.parameters()]).numpy()
+    assert not np.array_equal(w0, init)

@@ -67,6 +67,14 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch's ROCm wheel bundles its own libamdhip64 / libhsa-runtime64 (same SONAME as the system's).  If torch is
+    # imported first, our library binds to that already-loaded runtime and the process has ONE HIP runtime (torch
+    # tensors' pointers and stream handles are then first-class here).  The other order puts two runtimes in the
+    # process and torch no longer sees the GPU -- so torch, when installed, always goes first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(_LIB):
         raise MpcGpuError(f"{_LIB} not found: build it with `make -C {os.path.join(_PKG, 'csrc')}` "
                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")
