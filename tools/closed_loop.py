@@ -33,8 +33,7 @@ inside_box = np.zeros(B, bool); hit_disc = np.zeros(B, bool)
 t0 = time.time(); solve_ms = []
 for t in range(T):
     pred = constant_velocity_prediction(pos - vel, pos, steps=cfg.N_hor)         # [B, K, N, 6]
-    for i in range(B):
-        bt.update_dynamic_constraints(i, pred[i])
+    bt.set_dynamic_constraints(pred)
     actions, _, cost = bt.step("work")
     solve_ms.append(bt.solver.last_timing()["solve_ms"])
     pos = pos + vel

@@ -17,11 +17,13 @@ from .config import MpcConfig
 from .geometry import static_obstacle_params
 from .motion_model import unicycle_model
 from .solver import BatchSolver, BatchResult
-from .trajectory_generator import (assemble_parameters, global_reference_trajectory, local_reference_window,
-                                   speed_references, work_mode)
+from .trajectory_generator import global_reference_trajectory, work_mode
 
 
 class BatchedTracker:
+    """State of B robots as arrays; every per-tick step (window search, speed rule, parameter assembly, rollouts) is a
+    numpy array operation over the batch -- no Python loop over robots on the tick path."""
+
     def __init__(self, config: MpcConfig, n_robots: int, device: int = 0, solver: Optional[BatchSolver] = None):
         self.config = config
         self.B = int(n_robots)
@@ -30,16 +32,22 @@ class BatchedTracker:
         self.states = np.zeros((self.B, config.ns))
         self.goals = np.zeros((self.B, config.ns))
         self.last_actions = np.zeros((self.B, config.nu))
-        self.ref_trajs: List[np.ndarray] = [np.zeros((1, 3))] * self.B
-        self.idx_ref = [0] * self.B
-        self.stc_constraints = [[0.0] * (config.Nstcobs * config.nstcobs) for _ in range(self.B)]
-        self.dyn_constraints = [[0.0] * (config.Ndynobs * config.ndynobs * N) for _ in range(self.B)]
-        self.other_robot_states = [[0.0] * (config.ns * N * config.Nother) for _ in range(self.B)]
+        self._ref = np.zeros((self.B, 1, 3))            # global reference trajectories, padded to the longest
+        self._ref_len = np.ones(self.B, dtype=np.int64)
+        self.idx_ref = np.zeros(self.B, dtype=np.int64)
+        self.stc_constraints = np.zeros((self.B, config.Nstcobs * config.nstcobs))
+        self.dyn_constraints = np.zeros((self.B, config.Ndynobs * config.ndynobs * N))
+        self.other_robot_states = np.zeros((self.B, config.ns * N * config.Nother))
         self.stc_weights = [1e3] * N
         self.dyn_weights = [1e3] * N
         self.pred_states = np.zeros((self.B, N, config.ns))
         self.active = np.ones(self.B, dtype=bool)   # False once a robot's termination test has fired
         self.last_result: Optional[BatchResult] = None
+        self._P: Optional[np.ndarray] = None
+
+    @property
+    def ref_trajs(self) -> List[np.ndarray]:
+        return [self._ref[i, :self._ref_len[i]] for i in range(self.B)]
 
     # -- per-robot set-up (same meaning as InterfaceMpc.initialization / update_*_constraints) ---------------------
     def initialization(self, i: int, init_state, goal_state, ref_path_list: Sequence[Sequence[float]], mode: str = "work"):
@@ -47,7 +55,13 @@ class BatchedTracker:
         self.goals[i] = goal_state
         self.last_actions[i] = 0.0
         base_speed, _ = work_mode(self.config, mode)
-        self.ref_trajs[i] = global_reference_trajectory(self.config.ts, ref_path_list, self.states[i], base_speed)
+        traj = global_reference_trajectory(self.config.ts, ref_path_list, self.states[i], base_speed)
+        if len(traj) > self._ref.shape[1]:
+            grown = np.zeros((self.B, len(traj), 3))
+            grown[:, :self._ref.shape[1]] = self._ref
+            self._ref = grown
+        self._ref[i, :len(traj)] = traj
+        self._ref_len[i] = len(traj)
         self.idx_ref[i] = 0
         self.active[i] = True
 
@@ -55,10 +69,15 @@ class BatchedTracker:
         self.stc_constraints[i] = static_obstacle_params(obstacle_list, self.config.Nstcobs, self.config.nstcobs)
 
     def update_dynamic_constraints(self, i: int, full_dyn_obstacle_list):
-        per = self.config.ndynobs * self.config.N_hor
-        block = self.dyn_constraints[i]
-        for j, obstacle in enumerate(full_dyn_obstacle_list):
-            block[j * per:(j + 1) * per] = [float(x) for step in obstacle for x in step]
+        """``full_dyn_obstacle_list[j][k]`` = (x, y, rx, ry, angle, alpha) of obstacle j at step k; slots beyond the
+        list keep what they held (``interface_mpc.py:65-67``)."""
+        block = np.asarray(full_dyn_obstacle_list, dtype=float).reshape(-1)
+        self.dyn_constraints[i, :block.size] = block
+
+    def set_dynamic_constraints(self, predictions: np.ndarray):
+        """All robots at once: ``predictions`` [B, K, N, 6] (e.g. ``feeders.constant_velocity_prediction``)."""
+        block = np.asarray(predictions, dtype=float).reshape(self.B, -1)
+        self.dyn_constraints[:, :block.shape[1]] = block
 
     def share_predictions(self, groups: Optional[Sequence[Sequence[int]]] = None):
         """Fill every robot's other-robot block with the latest predictions of the robots in its group
@@ -71,31 +90,57 @@ class BatchedTracker:
                 block = np.zeros((cfg.Nother, cfg.N_hor, cfg.ns))
                 if others:
                     block[:len(others)] = self.pred_states[others]
-                self.other_robot_states[i] = block.reshape(-1).tolist()
+                self.other_robot_states[i] = block.reshape(-1)
 
     # -- one control tick for all robots ---------------------------------------------------------------------------
     def local_refs(self) -> np.ndarray:
-        """``get_local_ref_traj`` for every robot ([B, N, 3]); advances the nearest-sample indices like the reference's
-        call does (``interface_mpc.py:73-80``).  Pass a (modified) copy to :meth:`step` as ``refs``."""
+        """``get_local_ref_traj`` for every robot ([B, N, 3]): nearest sample inside the window [idx-1, idx+5) action
+        steps (first one on ties), then N rows from there, the tail padded with the last sample; advances the
+        indices like the reference's call does (``trajectory_generator.py:206-232``, ``interface_mpc.py:73-80``).
+        Pass a (modified) copy to :meth:`step` as ``refs``."""
         cfg = self.config
-        out = np.empty((self.B, cfg.N_hor, 3))
-        for i in range(self.B):
-            out[i], self.idx_ref[i] = local_reference_window(self.idx_ref[i], self.ref_trajs[i], self.states[i],
-                                                             cfg.action_steps, cfg.N_hor)
-        return out
+        a, rows = cfg.action_steps, np.arange(self.B)
+        lb = np.maximum(0, self.idx_ref - a)
+        ub = np.minimum(self._ref_len, self.idx_ref + 5 * a)
+        cand = lb[:, None] + np.arange(6 * a)[None, :]
+        valid = cand < ub[:, None]
+        pts = self._ref[rows[:, None], np.minimum(cand, self._ref_len[:, None] - 1)]
+        d = np.hypot(self.states[:, None, 0] - pts[..., 0], self.states[:, None, 1] - pts[..., 1])
+        d[~valid] = np.inf
+        self.idx_ref = lb + np.argmin(d, axis=1)
+        take = np.minimum(self.idx_ref[:, None] + np.arange(cfg.N_hor)[None, :], self._ref_len[:, None] - 1)
+        return self._ref[rows[:, None], take]
+
+    def speed_refs(self, base_speed: float) -> np.ndarray:
+        """[B] speed reference of this tick (``trajectory_generator.py:257-264``)."""
+        cfg = self.config
+        dist = np.hypot(self.states[:, 0] - self.goals[:, 0], self.states[:, 1] - self.goals[:, 1])
+        return np.where(dist >= base_speed * cfg.N_hor * cfg.ts, base_speed,
+                        np.maximum(dist / cfg.N_hor / cfg.ts, cfg.low_speed))
 
     def assemble(self, mode: str = "work", refs: Optional[np.ndarray] = None) -> np.ndarray:
+        """[B, np] parameter vectors in the order of ``mpc_generator.py:179-188`` (a view of the tracker's own buffer:
+        valid until the next call)."""
         cfg = self.config
         base_speed, tuning = work_mode(cfg, mode)
-        P = np.zeros((self.B, cfg.num_params))
         if refs is None:
             refs = self.local_refs()
-        for i in range(self.B):
-            ref = np.asarray(refs[i], dtype=float)
-            P[i] = assemble_parameters(self.states[i], ref[-1], self.last_actions[i], tuning,
-                                       ref.reshape(-1), speed_references(cfg, base_speed, self.states[i], self.goals[i]),
-                                       self.other_robot_states[i], self.stc_constraints[i], self.dyn_constraints[i],
-                                       self.stc_weights, self.dyn_weights)
+        refs = np.asarray(refs, dtype=float)
+        off, N = cfg.offsets(), cfg.N_hor
+        if self._P is None:                 # one buffer for the tracker's lifetime: every block is rewritten each tick
+            self._P = np.zeros((self.B, cfg.num_params))
+        P = self._P
+        P[:, 0:3] = self.states
+        P[:, 3:6] = refs[:, -1]
+        P[:, 6:8] = self.last_actions
+        P[:, off["q"]:off["q"] + len(tuning)] = tuning
+        P[:, off["r"]:off["r"] + 3 * N] = refs.reshape(self.B, -1)
+        P[:, off["vref"]:off["vref"] + N] = self.speed_refs(base_speed)[:, None]
+        P[:, off["c"]:off["c"] + self.other_robot_states.shape[1]] = self.other_robot_states
+        P[:, off["os"]:off["os"] + self.stc_constraints.shape[1]] = self.stc_constraints
+        P[:, off["od"]:off["od"] + self.dyn_constraints.shape[1]] = self.dyn_constraints
+        P[:, off["qstc"]:off["qstc"] + N] = self.stc_weights
+        P[:, off["qdyn"]:off["qdyn"] + N] = self.dyn_weights
         return P
 
     def step(self, mode: str = "work", initial_guess: Optional[np.ndarray] = None, refs: Optional[np.ndarray] = None):
