@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Closed-loop run of the batched tracker on the MI355X: B robots drive the reference's scene 1 (corridor, inflated
 box on the path, src/pkg_dqn/utils/map.py:292-305) while discs cross it; one GPU solve per control tick.
-usage: closed_loop.py [B] [ticks] [n_dyn]"""
+usage: closed_loop.py [B] [ticks] [n_dyn] [warm]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,7 +20,8 @@ inflate = lambda poly, m=0.8: [(min(x for x, _ in poly) - m, min(y for _, y in p
                                (max(x for x, _ in poly) + m, max(y for _, y in poly) + m), (min(x for x, _ in poly) - m, max(y for _, y in poly) + m)]
 box = [(7.5, 3.0), (7.5, 4.0), (8.5, 4.0), (8.5, 3.0)]
 static = [inflate(w) for w in walls] + [inflate(box)]
-bt = BatchedTracker(cfg, B)
+WARM = len(sys.argv) > 4 and sys.argv[4] == "warm"
+bt = BatchedTracker(cfg, B, warm_start=WARM)
 y0 = rng.uniform(3.0, 4.0, B)
 for i in range(B):
     bt.initialization(i, np.array([0.6, y0[i], 0.0]), np.array([15.4, 3.5, 0.0]),
@@ -42,7 +43,7 @@ for t in range(T):
     hit_disc |= (np.hypot(pos[..., 0] - x[:, None], pos[..., 1] - y[:, None]) < 0.8).any(axis=1)   # physical radius 0.8
 wall = time.time() - t0
 d_goal = np.hypot(bt.states[:, 0] - 15.4, bt.states[:, 1] - 3.5)
-print(f"B={B} ticks={T} discs={K}: wall {wall:.1f}s  kernel {np.mean(solve_ms):.1f} ms/tick  ({B * T / (np.sum(solve_ms) * 1e-3):.0f} solves/s in-kernel)")
+print(f"B={B} ticks={T} discs={K} {'warm' if WARM else 'cold'} start: wall {wall:.1f}s  kernel {np.mean(solve_ms):.1f} ms/tick  ({B * T / (np.sum(solve_ms) * 1e-3):.0f} solves/s in-kernel)")
 print(f"  progress: mean x {bt.states[:, 0].mean():.2f} m (start 0.6), within 0.5 m of goal: {(d_goal < 0.5).mean():.2f}, still active {bt.active.mean():.2f}")
 print(f"  safety  : entered the (un-inflated) box {inside_box.mean():.3f}, touched a disc (0.8 m) {hit_disc.mean():.3f}")
 print(f"  last tick status histogram {np.bincount(bt.last_result.status, minlength=4).tolist()} mean inner it {bt.last_result.num_inner_iterations.mean():.0f}")

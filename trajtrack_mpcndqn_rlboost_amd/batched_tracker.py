@@ -24,9 +24,11 @@ class BatchedTracker:
     """State of B robots as arrays; every per-tick step (window search, speed rule, parameter assembly, rollouts) is a
     numpy array operation over the batch -- no Python loop over robots on the tick path."""
 
-    def __init__(self, config: MpcConfig, n_robots: int, device: int = 0, solver: Optional[BatchSolver] = None):
+    def __init__(self, config: MpcConfig, n_robots: int, device: int = 0, solver: Optional[BatchSolver] = None,
+                 warm_start: bool = False):
         self.config = config
         self.B = int(n_robots)
+        self.warm_start = warm_start        # default False = the reference's call sites (initial_guess=None -> u0 = 0)
         self.solver = solver if solver is not None else BatchSolver(config, device=device)
         N = config.N_hor
         self.states = np.zeros((self.B, config.ns))
@@ -152,6 +154,12 @@ class BatchedTracker:
         near = np.all(np.abs(self.states[:, :2] - self.goals[:, :2]) <= 0.05, axis=1)
         self.active &= ~(near & (np.abs(self.last_actions[:, 0]) < 0.05))     # check_termination_condition
         P = self.assemble(mode, refs)
+        if initial_guess is None and self.warm_start and self.last_result is not None:
+            # receding-horizon warm start (what OpEn's TCP server does with its cached solution): previous plan
+            # shifted by the inputs already applied, last input repeated
+            prev = self.last_result.solution.reshape(self.B, cfg.N_hor, cfg.nu)
+            k = cfg.action_steps
+            initial_guess = np.concatenate([prev[:, k:], np.repeat(prev[:, -1:], k, axis=1)], axis=1).reshape(self.B, -1)
         res = self.solver.solve(P, initial_guess)
         self.last_result = res
         u = res.solution.reshape(self.B, cfg.N_hor, cfg.nu)
