@@ -135,3 +135,66 @@ def test_invalid_calls_fail_loudly():
     env.params.num_segments = 16
     with pytest.raises(rl_env.MpcGpuError, match="num_segments"):
         env.observe()
+
+
+def _random_map(rng):
+    """A random hall with random convex obstacles on general key-frame animations (1..4 key frames, linear or cosine
+    easing, time offsets) -- exercises what the two fixture scenes do not: n_kf_max = 4, linear interpolation, offsets,
+    different obstacle / edge / path-node counts per environment in one batch."""
+    import math
+    rg = importlib.import_module("trajtrack_mpcndqn_rlboost_amd.rl_geometry")
+    W, H = rng.uniform(12, 30), rng.uniform(10, 25)
+    boundary = [(0, 0), (W, 0), (W, H), (0, H)]
+    if rng.random() < 0.5:                      # notch: a reflex corner in the boundary
+        boundary = [(0, 0), (W, 0), (W, H * 0.6), (W * 0.7, H * 0.6), (W * 0.7, H), (0, H)]
+    obstacles = []
+    for _ in range(rng.integers(0, 7)):
+        n = rng.integers(3, 7)
+        ang = np.sort(rng.uniform(0, 2 * math.pi, n))
+        if np.min(np.diff(np.concatenate([ang, [ang[0] + 2 * math.pi]]))) < 0.4:
+            continue
+        rad = rng.uniform(0.5, 2.0)
+        nodes = np.stack([rad * np.cos(ang), rad * np.sin(ang)], axis=1)
+        if rg.signed_area(nodes) < 0.3:
+            continue
+        nk = int(rng.integers(1, 5))
+        frames = [(rng.uniform(1, W - 1), rng.uniform(1, H - 1), rng.uniform(-3, 3)) for _ in range(nk)]
+        steps = [0.0] + [float(rng.uniform(0.5, 6.0)) for _ in range(nk)]
+        obstacles.append(dict(padded_nodes=rg.buffer_polygon(nodes, 0.5), time_steps=steps, keyframes=frames,
+                              interp="cosine" if rng.random() < 0.5 else "linear", offset=float(rng.uniform(0, 5))))
+    npath = int(rng.integers(2, 9))
+    path = np.stack([np.sort(rng.uniform(0.5, W - 0.5, npath)), rng.uniform(0.5, H * 0.55, npath)], axis=1)
+    return dict(start=np.array([path[0, 0], path[0, 1], 0.0, 0.0, 0.0]), goal=np.asarray(path[-1], dtype=np.float32).astype(float),
+                path=path, boundary_padded=rg.buffer_polygon(boundary, -0.5), obstacles=obstacles)
+
+
+def test_random_maps_with_general_keyframe_animations_match_the_oracle():
+    import torch
+    rng = np.random.default_rng(99)
+    maps = [_random_map(rng) for _ in range(96)]
+    assert max(len(o["keyframes"]) for m in maps for o in m["obstacles"]) == 4
+    env = rl_env.BatchedRaysEnv(maps, time_step=0.15)
+    B = len(maps)
+    oracles = [orc.OracleRaysEnv(m, time_step=0.15) for m in maps]
+    env.reset()
+    for k in range(12):
+        acts = rng.integers(0, 9, B)
+        if k % 4 == 3:                              # teleport everybody, anywhere in (or slightly outside) the hall
+            st = np.zeros((B, 5))
+            for b, m in enumerate(maps):
+                ring = np.asarray(m["boundary_padded"])
+                st[b] = [rng.uniform(ring[:, 0].min() - 0.3, ring[:, 0].max() + 0.3),
+                         rng.uniform(ring[:, 1].min() - 0.3, ring[:, 1].max() + 0.3), rng.uniform(-4, 4),
+                         rng.uniform(-0.5, 1.5), rng.uniform(-0.5, 0.5)]
+                oracles[b].state[:] = st[b]
+            env.set_agent_state(st)
+        obs, rew, term, _, _ = env.step(torch.from_numpy(acts))
+        oi, oe = obs["internal"].cpu().numpy(), obs["external"].cpu().numpy()
+        st, fl = env.agent_state.cpu().numpy(), env.flags.cpu().numpy()
+        for b, o in enumerate(oracles):
+            ob, r, done, _ = o.step(int(acts[b]))
+            assert np.abs(st[b] - o.state).max() <= 1e-12, (k, b)
+            assert np.array_equal(fl[b], [o.collided_obstacle, o.collided_boundary, o.reached_goal]), (k, b)
+            assert np.abs(oi[b] - ob["internal"]).max() <= 1e-6, (k, b)
+            assert np.abs(oe[b] - ob["external"]).max() <= 2e-6, (k, b, oe[b], ob["external"])
+            assert abs(float(rew[b]) - r) <= 1e-9 and bool(term[b]) == done
