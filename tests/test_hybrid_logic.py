@@ -56,3 +56,59 @@ def test_polygon_distance_and_mitre_inflation():
     needle = [(0.0, 0.0), (10.0, 0.2), (10.0, -0.2)]
     out = np.array(hybrid.inflate_polygon(needle, 0.5))
     assert len(out) == 4 and np.isclose(np.min(out[:, 0]), -2.5, atol=1e-9)
+
+
+@pytest.mark.parametrize("args", [(10, 2, 10), (3.0, 1.0, 2), (1.5, 0.5, 0)])
+def test_batched_switcher_equals_the_scalar_one(args):
+    """BatchedHintSwitcher (array operations over robots) against one scalar HintSwitcher per robot -- which the
+    previous tests pin to the reference's class -- on random drives past random obstacle sets of different sizes."""
+    rng = np.random.default_rng(1)
+    B, R, T, O, V = 40, 20, 150, 5, 4
+    scal = [hybrid.HintSwitcher(*args) for _ in range(B)]
+    bat = hybrid.BatchedHintSwitcher(B, *args)
+    nst = rng.integers(0, 4, B)
+    base = np.array([[0.0, 0.0], [2.0, 0.0], [2.5, 1.5], [0.0, 2.0]])
+    static = [[(base[:(3 if rng.random() < 0.3 else 4)] + [rng.uniform(2, 30), rng.uniform(0, 2)]).tolist()
+               for _ in range(nst[b])] for b in range(B)]
+    x = np.zeros(B)
+    seen_on = seen_off = toggles = 0
+    prev = np.zeros(B, dtype=bool)
+    for t in range(T):
+        x += rng.uniform(0.05, 0.4, B)
+        pos = np.stack([x, 1.0 + rng.normal(0, 1.0, B)], axis=1)
+        orig = np.stack([pos[:, None, 0] + 0.24 * np.arange(1, R + 1)[None], np.repeat(rng.uniform(0, 3, B)[:, None], R, 1),
+                         np.zeros((B, R))], axis=2)
+        dyn = np.stack([x[:, None] + rng.uniform(-4, 8, (B, 2)), rng.uniform(-1, 5, (B, 2))], axis=2)
+        polygons, valid = np.zeros((B, O, V, 2)), np.zeros((B, O), dtype=bool)
+        live = rng.random(B) < 0.9
+        expect = []
+        for b in range(B):
+            rects = [hybrid.circle_to_rect(p, 0.8) for p in dyn[b]]
+            if static[b]:
+                polygons[b, :nst[b]] = hybrid.pad_polygons(static[b], V)
+            valid[b, :nst[b]] = True
+            polygons[b, 3:5], valid[b, 3:5] = np.array(rects), True
+            expect.append(scal[b].switch(pos[b], orig[b].tolist(), orig[b].tolist(), static[b] + rects) if live[b]
+                          else scal[b].switch_on)
+        got = bat.switch(pos, orig, polygons, valid, live)
+        assert np.array_equal(np.array(expect), got), t
+        assert np.array_equal(np.array([s.detach_cnt for s in scal]), bat.detach_cnt), t
+        seen_on += int(got.sum()); seen_off += int((~got).sum()); toggles += int((got != prev).sum()); prev = got
+    assert seen_on > 100 and seen_off > 100 and toggles > 20
+
+
+def test_batched_geometry_helpers_match_the_scalar_ones():
+    rng = np.random.default_rng(2)
+    polys = [[(0, 0), (3, 0), (3, 2), (0, 2)], [(5, 5), (7, 5), (6, 8)], [(1, 4), (2, 4), (2, 6), (1.5, 7), (1, 6)]]
+    P = hybrid.pad_polygons(polys, 6)[None].repeat(50, axis=0)
+    pts = rng.uniform(-1, 9, (50, 7, 2))
+    inside = hybrid.points_in_polygons(pts, P)
+    dist = hybrid.polygon_distances(pts[:, 0], P)
+    for b in range(50):
+        for o, poly in enumerate(polys):
+            assert abs(dist[b, o] - hybrid.polygon_distance(poly, pts[b, 0])) < 1e-12
+            for r in range(7):
+                assert inside[b, r, o] == hybrid.rg.point_in_ring(pts[b, r], np.asarray(poly, dtype=float))
+    w = hybrid.filter_weights(20, 0.9)
+    o, n = rng.normal(size=(20, 3)), rng.normal(size=(20, 3))
+    assert np.allclose((1 - w)[:, None] * o + w[:, None] * n, hybrid.ref_traj_filter(o, n, 0.9), rtol=0, atol=0)

@@ -130,6 +130,92 @@ class HintSwitcher:
         return self.switch_on
 
 
+def filter_weights(n_rows: int, decay: float = 1.0) -> np.ndarray:
+    """Row weights of :func:`ref_traj_filter` (they do not depend on the data)."""
+    w = np.empty(n_rows)
+    for i in range(n_rows):
+        w[i] = decay
+        decay *= decay
+        if decay < 1e-2:
+            decay = 0.0
+    return w
+
+
+def pad_polygons(polygons: Sequence[Sequence[Sequence[float]]], n_vertices: int) -> np.ndarray:
+    """[O, n_vertices, 2]: every ring padded by repeating its last vertex (zero-length edges change neither the
+    even-odd test nor the distance)."""
+    out = np.zeros((len(polygons), n_vertices, 2))
+    for i, poly in enumerate(polygons):
+        ring = np.asarray(poly, dtype=float).reshape(-1, 2)
+        out[i, :len(ring)] = ring
+        out[i, len(ring):] = ring[-1]
+    return out
+
+
+def points_in_polygons(points: np.ndarray, polygons: np.ndarray) -> np.ndarray:
+    """Even-odd rule, batched: points [B, R, 2], polygons [B, O, V, 2] -> [B, R, O] bool."""
+    a = polygons[:, None]                               # [B, 1, O, V, 2]
+    b = np.roll(polygons, -1, axis=2)[:, None]
+    px, py = points[:, :, None, None, 0], points[:, :, None, None, 1]
+    straddle = (a[..., 1] > py) != (b[..., 1] > py)
+    dy = np.where(straddle, b[..., 1] - a[..., 1], 1.0)
+    cross = px < (b[..., 0] - a[..., 0]) * (py - a[..., 1]) / dy + a[..., 0]
+    return (np.sum(straddle & cross, axis=-1) & 1).astype(bool)
+
+
+def polygon_distances(points: np.ndarray, polygons: np.ndarray) -> np.ndarray:
+    """shapely ``Polygon.distance(Point)``, batched: points [B, 2], polygons [B, O, V, 2] -> [B, O]."""
+    a = polygons
+    d = np.roll(polygons, -1, axis=2) - a
+    rel = points[:, None, None, :] - a
+    den = np.sum(d * d, axis=-1)
+    t = np.clip(np.where(den > 0.0, np.sum(rel * d, axis=-1) / np.where(den > 0.0, den, 1.0), 0.0), 0.0, 1.0)
+    gap = rel - t[..., None] * d
+    dist = np.sqrt(np.sum(gap * gap, axis=-1)).min(axis=-1)
+    inside = points_in_polygons(points[:, None, :], polygons)[:, 0]
+    return np.where(inside, 0.0, dist)
+
+
+class BatchedHintSwitcher:
+    """:class:`HintSwitcher` for B robots at once: the same sequential scan over (trajectory row, obstacle) pairs, each
+    step applied to all robots as array operations (early return = a per-robot mask)."""
+
+    def __init__(self, n_robots: int, max_switch_distance: float, min_detach_distance: float, min_detach_steps: float = 5):
+        self.B = n_robots
+        self.switch_distance, self.detach_distance, self.detach_steps = max_switch_distance, min_detach_distance, min_detach_steps
+        self.reset()
+
+    def reset(self):
+        self.detach_cnt = np.zeros(self.B, dtype=np.int64)
+        self.switch_on = np.zeros(self.B, dtype=bool)
+
+    def switch(self, positions: np.ndarray, original: np.ndarray, polygons: np.ndarray, valid: np.ndarray,
+               live: Optional[np.ndarray] = None) -> np.ndarray:
+        """positions [B, 2]; original [B, R, >= 2] (rows of the original reference); polygons [B, O, V, 2] with
+        ``valid`` [B, O] marking real obstacles; ``live`` [B]: robots whose switcher is consulted this tick."""
+        contains = points_in_polygons(np.asarray(original)[..., :2], polygons)      # [B, R, O]
+        dist = polygon_distances(np.asarray(positions, dtype=float), polygons)      # [B, O]
+        on, cnt = self.switch_on, self.detach_cnt
+        returned = np.zeros(self.B, dtype=bool) if live is None else ~np.asarray(live, dtype=bool)
+        counted = np.zeros(self.B, dtype=bool)
+        near, far = dist < self.switch_distance, dist > self.detach_distance
+        for r in range(contains.shape[1]):
+            for o in range(contains.shape[2]):
+                act = valid[:, o] & ~returned
+                c = contains[:, r, o]
+                trig = act & c & near[:, o] & ~on
+                on = on | trig
+                returned = returned | trig
+                e = act & ~c & far[:, o] & on & ~trig
+                reset = e & (cnt > self.detach_steps)
+                inc = e & ~reset & ~counted
+                on = on & ~reset
+                cnt = np.where(reset, 0, cnt + inc)
+                counted = counted | inc
+        self.switch_on, self.detach_cnt = on, cnt
+        return on.copy()
+
+
 # ---- the batched decision loop ----------------------------------------------------------------------------------------
 class BatchedHybrid:
     """B robots, each in its own copy of a scene.  ``scenes[i]``: dict with ``boundary``, ``static`` (polygons),
@@ -151,7 +237,19 @@ class BatchedHybrid:
         self.q_net = q_net.to(self.env.device)
         self.tracker = tracker if tracker is not None else BatchedTracker(config, self.B, device=device)
         self.inflated = [[inflate_polygon(poly, inflate_margin) for poly in s["static"]] for s in scenes]
-        self.switchers = [HintSwitcher(*switcher) for _ in scenes]
+        self.switcher = BatchedHintSwitcher(self.B, *switcher)
+        n_dyn = max(len(s["dynamic"]) for s in scenes)
+        self._n_static = np.array([len(s["static"]) for s in scenes])
+        self._n_dynamic = np.array([len(s["dynamic"]) for s in scenes])
+        vmax = max([4] + [len(p) for polys in self.inflated for p in polys])
+        omax = int(self._n_static.max()) + n_dyn
+        self._polygons = np.zeros((self.B, omax, vmax, 2))        # static (inflated) first, this tick's discs after them
+        self._poly_valid = np.zeros((self.B, omax), dtype=bool)
+        for b, polys in enumerate(self.inflated):
+            if polys:
+                self._polygons[b, :len(polys)] = pad_polygons(polys, vmax)
+            self._poly_valid[b, :len(polys)] = True
+            self._poly_valid[b, self._n_static.max():self._n_static.max() + self._n_dynamic[b]] = True
         self.reset()
 
     def reset(self):
@@ -161,8 +259,7 @@ class BatchedHybrid:
             start = np.asarray(s["start"], dtype=float)
             self.tracker.initialization(i, start[:3], np.array([s["goal"][0], s["goal"][1], 0.0]), s["path"])
             self.tracker.update_static_constraints(i, self.inflated[i])
-            self.switchers[i].__init__(self.switchers[i].switch_distance, self.switchers[i].detach_distance,
-                                       self.switchers[i].detach_steps)
+        self.switcher.reset()
         self.last_dyn = None
         self.done = np.zeros(self.B, dtype=bool)
         self.success = np.zeros(self.B, dtype=bool)
@@ -172,13 +269,14 @@ class BatchedHybrid:
         self.switch_ticks = np.zeros(self.B, dtype=int)   # ticks on which the MPC tracked the DQN's proposal
         self.t = 0
 
-    def dynamic_positions(self) -> List[np.ndarray]:
-        """Current key-frame positions of every environment's dynamic obstacles (main.py:127)."""
+    def dynamic_positions(self) -> np.ndarray:
+        """[B, Kmax, 2]: current key-frame positions of every environment's dynamic obstacles (main.py:127); rows
+        beyond an environment's own count stay 0."""
         clock = self.env.state[:, 5].cpu().numpy()
-        out = []
+        out = np.zeros((self.B, int(self._n_dynamic.max()) if self.B else 0, 2))
         for b, m in enumerate(self.maps):
-            n_static = len(self.scenes[b]["static"])
-            out.append(np.array([rl_env.keyframe_pose(ob, clock[b])[:2] for ob in m["obstacles"][n_static:]]).reshape(-1, 2))
+            for j, ob in enumerate(m["obstacles"][self._n_static[b]:]):
+                out[b, j] = rl_env.keyframe_pose(ob, clock[b])[:2]
         return out
 
     def _flat(self, obs):
@@ -189,8 +287,10 @@ class BatchedHybrid:
         dyn_now = self.dynamic_positions()
         if self.last_dyn is None:
             self.last_dyn = dyn_now
-        preds = [constant_velocity_prediction(self.last_dyn[b], dyn_now[b], steps=cfg.N_hor) if len(dyn_now[b]) else None
-                 for b in range(self.B)]
+        kmax = dyn_now.shape[1]
+        if kmax:                                             # est_dyn_obs_positions (main.py:77-85) for every robot
+            has = (np.arange(kmax)[None, :] < self._n_dynamic[:, None])[:, :, None, None]
+            preds = np.where(has, constant_velocity_prediction(self.last_dyn, dyn_now, steps=cfg.N_hor), 0.0)
         self.last_dyn = dyn_now
         live = ~self.done
 
@@ -215,20 +315,21 @@ class BatchedHybrid:
                 rl_ref, _ = rl_reference(env.agent_state.cpu().numpy(), actions, cfg.ts, steps=20, ref_speed=1.0)
                 original = trk.local_refs()
                 proposal = merge_reference(rl_ref[:, :cfg.N_hor], original)
-                chosen = original.copy()
-                for b in range(self.B):
-                    if self.done[b]:
-                        continue
-                    filtered = ref_traj_filter(original[b], proposal[b], decay=1)
-                    obstacles = self.inflated[b] + [circle_to_rect(p) for p in dyn_now[b]]
-                    on = self.switchers[b].switch(trk.states[b, :2], original[b].tolist(), filtered.tolist(), obstacles)
-                    self.switch_on[b] = on
-                    self.switch_ticks[b] += int(on)
-                    if on:
-                        chosen[b] = filtered
-            for b in range(self.B):
-                if preds[b] is not None:
-                    trk.update_dynamic_constraints(b, preds[b])
+                w = filter_weights(cfg.N_hor, 1.0)[None, :, None]      # ref_traj_filter(decay=1): the proposal as it is
+                filtered = (1.0 - w) * original + w * proposal
+                if kmax:                                             # circle_to_rect of every disc (main.py:129)
+                    r = DYN_OBS_SIZE
+                    corners = np.array([[-r, -r], [r, -r], [r, r], [-r, r]])
+                    s0 = int(self._n_static.max())
+                    rects = dyn_now[:, :, None, :] + corners[None, None]
+                    self._polygons[:, s0:s0 + kmax, :4] = rects
+                    self._polygons[:, s0:s0 + kmax, 4:] = rects[:, :, 3:4]
+                on = self.switcher.switch(trk.states[:, :2], original, self._polygons, self._poly_valid, live)
+                self.switch_on = on & live
+                self.switch_ticks += self.switch_on
+                chosen = np.where(self.switch_on[:, None, None], filtered, original)
+            if kmax:
+                trk.set_dynamic_constraints(preds)
             trk.active &= live
             trk.step(refs=chosen)
             # get_action returns None once the tracker's own termination test fires (interface_mpc.py:83-85)
