@@ -147,3 +147,25 @@ def test_two_rank_learners_share_one_network(tmp_path):
     torch.manual_seed(0)
     init = torch.cat([p.detach().reshape(-1) for p in dqn_train.DqnTrainer().q_net.parameters()]).numpy()
     assert not np.array_equal(w0, init)
+
+
+@pytest.mark.gpu
+def test_graph_replayed_update_equals_the_eager_update():
+    """The hipGraph replay of the DQN update gives the same parameters as the eager update on the same batches."""
+    dev = "cuda:0"
+    def batch(seed, n=64):
+        g = torch.Generator().manual_seed(seed)
+        return {k: v.to(dev) for k, v in dict(obs=torch.rand(n, 46, generator=g) * 2 - 1, actions=torch.randint(0, 9, (n,), generator=g),
+                                               rewards=torch.randn(n, generator=g), next_obs=torch.rand(n, 46, generator=g) * 2 - 1,
+                                               dones=(torch.rand(n, generator=g) < 0.1).float()).items()}
+    outs = []
+    for graphed in (False, True):
+        torch.manual_seed(0)
+        tr = dqn_train.DqnTrainer(device=dev, target_update_interval=3)
+        if graphed:
+            tr.enable_graph(64)
+        losses = [float((tr.update_graphed if graphed else tr.update)(batch(10 + i))) for i in range(8)]
+        outs.append((torch.cat([p.detach().reshape(-1) for p in tr.q_net.parameters()]).cpu(), losses, tr.num_target_syncs))
+    assert outs[0][2] == outs[1][2] == 2
+    assert np.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-7)
+    assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-7)

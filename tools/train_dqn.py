@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""DQN training on the batched HIP environment (BASELINE.json config 5 in miniature, one GPU per process).
+
+    python tools/train_dqn.py [--envs 4096] [--timesteps 4000000] [--gradient-steps 16] [--batch-size 256]
+
+Every environment is scene 1 of the reference (src/pkg_dqn/utils/map.py:292-305) with the 'medium' box and a periodic
+obstacle, start pose jittered per environment; the reference path is the straight line start -> goal (an input; the
+reference gets it from A*).  Under torch.distributed (torchrun, backend nccl = RCCL) every rank trains on its own
+environments and the gradients are summed by one flat all-reduce per update.  Prints throughput and the return curve."""
+import argparse
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+rl_env = importlib.import_module("trajtrack_mpcndqn_rlboost_amd.rl_env")
+dqn_train = importlib.import_module("trajtrack_mpcndqn_rlboost_amd.dqn_train")
+
+
+def scene(rng):
+    y0 = 3.5 + rng.uniform(-1.0, 1.0)
+    th = rng.uniform(-0.5, 0.5)
+    return rl_env.make_map(
+        boundary=[(0.0, 0.0), (16.0, 0.0), (16.0, 10.0), (0.0, 10.0)],
+        static=[[(0.0, 1.5), (0.0, 1.6), (9.0, 1.6), (9.0, 1.5)], [(0.0, 8.4), (0.0, 8.5), (9.0, 8.5), (9.0, 8.4)],
+                [(11.0, 1.5), (11.0, 1.6), (16.0, 1.6), (16.0, 1.5)], [(11.0, 8.4), (11.0, 8.5), (16.0, 8.5), (16.0, 8.4)],
+                [(7.2, 2.8), (7.2, 4.2), (8.8, 4.2), (8.8, 2.8)]],
+        dynamic=[dict(p1=(10.0, 1.0), p2=(10.0, 9.0), freq=0.2, rx=0.8, ry=0.8, angle=0.0, corners=20)],
+        start=[0.6, y0, th, 0.0, 0.0], goal=[15.4, 3.5], path=[(0.6, y0), (6.4, 5.4), (9.6, 5.4), (15.4, 3.5)])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--envs", type=int, default=4096)
+    ap.add_argument("--timesteps", type=int, default=4_000_000)
+    ap.add_argument("--gradient-steps", type=int, default=16)
+    ap.add_argument("--batch-size", type=int, default=256)
+    ap.add_argument("--double-q", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the update from a captured HIP graph (single process)")
+    args = ap.parse_args()
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    rng = np.random.default_rng(100 + rank)
+    torch.manual_seed(0)
+    env = rl_env.BatchedRaysEnv([scene(rng) for _ in range(args.envs)], device=local, max_episode_steps=400)
+    trainer = dqn_train.DqnTrainer(device=f"cuda:{local}", double_q=args.double_q, lr=1e-3)
+    learner = dqn_train.DqnLearner(env, trainer, buffer_size=2_000_000, learning_starts=4 * args.envs,
+                                   batch_size=args.batch_size, train_freq=4, gradient_steps=args.gradient_steps,
+                                   target_update_interval=200_000, exploration_fraction=0.3, use_graph=args.graph)
+    marks, t0 = [], time.perf_counter()
+
+    def progress(lr):
+        if lr.num_timesteps // (args.timesteps // 10) > len(marks):
+            recent, succ = lr.episode_returns[-2000:], lr.episode_successes[-2000:]
+            marks.append((lr.num_timesteps, float(np.mean(recent)) if recent else float("nan"),
+                          float(np.mean(succ)) if succ else float("nan"), time.perf_counter() - t0))
+            if rank == 0:
+                print(f"  {marks[-1][0]:>9d} steps  mean return {marks[-1][1]:8.2f}  success {marks[-1][2]:.2f}  {marks[-1][3]:6.1f} s", flush=True)
+
+    stats = learner.learn(args.timesteps, callback=progress)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        print(f"envs/rank {args.envs} x ranks {world}: {world * stats['timesteps'] / dt:.3e} environment steps/s incl. "
+              f"{stats['updates']} updates of batch {args.batch_size} ({stats['updates'] / dt:.0f} updates/s), "
+              f"episodes {stats['episodes']}, final mean return {stats['mean_return']:.2f}, success rate {stats['success_rate']:.2f}")
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

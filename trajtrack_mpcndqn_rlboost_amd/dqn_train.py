@@ -75,6 +75,61 @@ class DqnTrainer:
             self.sync_target()
         return loss.detach()
 
+    # ---- hipGraph path: the update is ~40 tiny kernels (MLP forward / backward, Huber loss, clip, Adam) on 1 177
+    # parameters, i.e. pure launch latency; captured once, it replays as ONE graph launch
+    def enable_graph(self, batch_size: int, obs_dim: int = 46) -> None:
+        """Capture ``update`` for a fixed batch size into a HIP graph (``torch.cuda.CUDAGraph`` is hipGraph on ROCm).
+        Single-process only: the gradient all-reduce of the multi-rank path stays outside graphs."""
+        if self.world > 1:
+            raise RuntimeError("graph capture is built for the single-process update; multi-rank keeps the eager path")
+        dev = self._bucket.device
+        if dev.type != "cuda":
+            raise RuntimeError("enable_graph needs the GPU")
+        lr = self.optimizer.param_groups[0]["lr"]
+        self.optimizer = torch.optim.Adam(self.q_net.parameters(), lr=lr, capturable=True)
+        self._g_batch = dict(obs=torch.zeros(batch_size, obs_dim, device=dev), actions=torch.zeros(batch_size, dtype=torch.int64, device=dev),
+                             rewards=torch.zeros(batch_size, device=dev), next_obs=torch.zeros(batch_size, obs_dim, device=dev),
+                             dones=torch.zeros(batch_size, device=dev))
+        self._g_loss = torch.zeros((), device=dev)
+        keep_interval, self.target_update_interval = self.target_update_interval, 0
+        state = ([p.detach().clone() for p in self._params], self.num_updates)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # warm-up off the capture (allocations, Adam state)
+            for _ in range(3):
+                self._eager_step(self._g_batch)
+        torch.cuda.current_stream().wait_stream(side)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._g_loss.copy_(self._eager_step(self._g_batch))
+        with torch.no_grad():                              # undo the warm-up / capture steps on the zero batch
+            for p, p0 in zip(self._params, state[0]):
+                p.copy_(p0)
+            for st in self.optimizer.state.values():
+                st["exp_avg"].zero_(); st["exp_avg_sq"].zero_(); st["step"].zero_()
+        self.num_updates = state[1]
+        self.target_update_interval = keep_interval
+
+    def _eager_step(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        target = self.td_target(batch["rewards"], batch["next_obs"], batch["dones"])
+        q = self.q_net(batch["obs"]).gather(1, batch["actions"].view(-1, 1)).squeeze(1)
+        loss = F.smooth_l1_loss(q, target)
+        self.optimizer.zero_grad(set_to_none=False)
+        loss.backward()
+        nn.utils.clip_grad_norm_(self._params, self.max_grad_norm)
+        self.optimizer.step()
+        return loss.detach()
+
+    def update_graphed(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """Same arithmetic as :meth:`update`, replayed from the captured graph (batch size fixed by enable_graph)."""
+        for k, v in self._g_batch.items():
+            v.copy_(batch[k])
+        self._graph.replay()
+        self.num_updates += 1
+        if self.target_update_interval and self.num_updates % self.target_update_interval == 0:
+            self.sync_target()
+        return self._g_loss
+
     def sync_target(self) -> None:
         """Hard target update (SB3 ``polyak_update`` with tau = 1)."""
         self.q_net_target.load_state_dict(self.q_net.state_dict())
@@ -139,7 +194,8 @@ class DqnLearner:
     def __init__(self, env, trainer: Optional[DqnTrainer] = None, buffer_size: int = 1_000_000,
                  learning_starts: int = 50_000, batch_size: int = 32, train_freq: int = 4, gradient_steps: int = -1,
                  target_update_interval: int = 10_000, exploration_fraction: float = 0.2,
-                 exploration_initial_eps: float = 1.0, exploration_final_eps: float = 0.05, seed: int = 0):
+                 exploration_initial_eps: float = 1.0, exploration_final_eps: float = 0.05, seed: int = 0,
+                 use_graph: bool = False):
         self.env = env
         self.device = env.device
         self.trainer = trainer if trainer is not None else DqnTrainer(device=str(self.device))
@@ -152,6 +208,9 @@ class DqnLearner:
         self.gen.manual_seed(seed + (dist.get_rank() if dist.is_available() and dist.is_initialized() else 0))
         self.num_timesteps, self.n_calls = 0, 0
         self.episode_returns, self.episode_successes = [], []
+        self.use_graph = use_graph
+        if use_graph:
+            self.trainer.enable_graph(batch_size)
 
     def act(self, obs_flat: torch.Tensor, epsilon: float) -> torch.Tensor:
         greedy = self.trainer.q_net.greedy_actions(obs_flat)
@@ -194,7 +253,8 @@ class DqnLearner:
             if self.num_timesteps > self.learning_starts and self.buffer.size >= self.batch_size:
                 steps = self.gradient_steps if self.gradient_steps >= 0 else collected
                 for _ in range(steps):
-                    last_loss = self.trainer.update(self.buffer.sample(self.batch_size, self.gen))
+                    step = self.trainer.update_graphed if self.use_graph else self.trainer.update
+                    last_loss = step(self.buffer.sample(self.batch_size, self.gen))
                 n_updates += steps
             if callback is not None:
                 callback(self)
