@@ -49,7 +49,9 @@ struct Prof {
 
 constexpr int WAVE = 64;
 constexpr int HDR = 64;        // header doubles per problem in the workspace
-constexpr int SEGW = 12;       // doubles per reference segment: s1x, s1y, dx, dy, 1/(|d|^2+1e-16), midx, midy, half length,
+constexpr int SEGW = 13;       // doubles per reference segment (12 used + 1 pad: an odd stride spreads the records of
+                               // neighbouring steps over all LDS banks; 12 gave 3-way conflicts, -1.8 % kernel time):
+                               // s1x, s1y, dx, dy, 1/(|d|^2+1e-16), midx, midy, half length,
                                // then the bounding circle (cx, cy, R, -) of ALL segments from this one to the last
 constexpr int STCW = 12;       // doubles per static obstacle    (b[4], a0[4], a1[4])
 constexpr int DYNW = 9;        // workspace record per (dyn row, step): cx, cy, cosA, sinA, ihx, ihy, isx, isy, wgt
