@@ -144,3 +144,29 @@ def test_record_layout_matches_the_library_and_env_symbols_are_exported():
     header = open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "include", "mpcgpu_env.h")).read()
     for name in rl_env.ENV_EXPORTS:
         assert name + "(" in header
+
+
+def test_round_buffer_properties_on_random_convex_polygons():
+    """Every vertex of the grown ring lies at distance r from the polygon (arc points and offset-edge end points), the
+    ring is simple and counter-clockwise, contains the polygon, and its area is between the mitred-free lower bound
+    (area + r * perimeter) and the exact Minkowski sum (+ pi r^2)."""
+    rng = np.random.default_rng(3)
+    for _ in range(60):
+        n = int(rng.integers(3, 9))
+        ang = np.sort(rng.uniform(0, 2 * math.pi, n))
+        if np.min(np.diff(np.concatenate([ang, [ang[0] + 2 * math.pi]]))) < 0.25:
+            continue
+        rad = rng.uniform(0.5, 3.0)
+        poly = np.stack([rad * np.cos(ang), rad * np.sin(ang)], axis=1) + rng.uniform(-5, 5, 2)
+        if rg.signed_area(poly) < 0.2:
+            continue
+        r = float(rng.uniform(0.1, 1.0))
+        ring = rg.buffer_polygon(poly, r, quad_segs=int(rng.integers(1, 9)))
+        assert rg.signed_area(ring) > 0 and rg.ring_is_simple(ring)
+        for p in ring:
+            d = min(orc.point_segment_distance(p, poly[k], poly[(k + 1) % n]) for k in range(n))
+            assert abs(d - r) < 1e-9 and not rg.point_in_ring(p, poly)
+        assert all(rg.point_in_ring(v, ring) for v in poly)
+        per = sum(math.hypot(*(poly[(k + 1) % n] - poly[k])) for k in range(n))
+        area = rg.signed_area(poly)
+        assert area + r * per - 1e-9 <= rg.signed_area(ring) <= area + r * per + math.pi * r * r + 1e-9
