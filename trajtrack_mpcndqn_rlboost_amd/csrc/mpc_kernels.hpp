@@ -49,14 +49,17 @@ struct Prof {
 
 constexpr int WAVE = 64;
 constexpr int HDR = 64;        // header doubles per problem in the workspace
-constexpr int SEGW = 13;       // doubles per reference segment (12 used + 1 pad: an odd stride spreads the records of
-                               // neighbouring steps over all LDS banks; 12 gave 3-way conflicts, -1.8 % kernel time):
-                               // s1x, s1y, dx, dy, 1/(|d|^2+1e-16), midx, midy, half length,
-                               // then the bounding circle (cx, cy, R, -) of ALL segments from this one to the last
+constexpr int SEGW = 9;        // LDS / workspace doubles per reference segment: s1x, s1y, dx, dy, 1/(|d|^2+1e-16), then the
+                               // bounding circle (cx, cy, R) of ALL segments from this one to the last, + 1 pad: the odd
+                               // stride spreads the records of neighbouring steps over all LDS banks (an even stride
+                               // gave 3-way conflicts on every segment read: -1.8 % kernel time)
+constexpr int SEGC = 3;        // "cold" per-segment fields (midpoint x, y, half length), only read by the rare per-segment
+                               // pruning pass: they stay in the workspace (L2) and cost no LDS
 constexpr int STCW = 12;       // doubles per static obstacle    (b[4], a0[4], a1[4])
 constexpr int DYNW = 9;        // workspace record per (dyn row, step): cx, cy, cosA, sinA, ihx, ihy, isx, isy, wgt
-constexpr int DYNP = 3;        // shape-constant LDS record per (row, step): cx, cy, wgt
-constexpr int DYNC = 6;        // shape-constant LDS record per row: cosA, sinA, ihx, ihy, isx, isy
+constexpr int DYNP = 2;        // shape-constant LDS record per (row, step): cx, cy
+constexpr int DYNC = 7;        // shape-constant LDS record per row: cosA, sinA, ihx, ihy, isx, isy, alpha
+                               // (the item weight q_dyn[k] * alpha is formed where it is used: q_dyn is one value per step)
 constexpr int PARTW = 5;       // doubles per item-lane partial  (gx, gy, best, bgx, bgy)
 constexpr int MAX_MEM = 16;
 constexpr int SEG_WIN = 2;     // reference segments per item lane that are evaluated unconditionally
@@ -79,10 +82,10 @@ struct KParams {
     // parameter-vector offsets (mpc_generator.py:179-188)
     int r0, c0, os0, od0, qs0, qd0;
     // workspace (global) layout per problem, doubles
-    int ws_stride, ws_vref, ws_seg, ws_stc, ws_fxy, ws_dyn, ws_lbs, ws_lby;
+    int ws_stride, ws_vref, ws_seg, ws_segc, ws_stc, ws_fxy, ws_dyn, ws_qd, ws_alpha, ws_lbs, ws_lby, ws_lold;
     // LDS layout (doubles), strides use the batch maxima mKs/mKf/mKd
     int mKs, mKf, mKd;
-    int l_seg, l_stc, l_fxy, l_dyn, l_dync, l_pos, l_H, l_W, l_part, l_stash, l_hd, l_S, l_Y, l_rho, l_alpha, l_old, l_total;
+    int l_seg, l_stc, l_fxy, l_dyn, l_dync, l_qd, l_pos, l_H, l_W, l_part, l_stash, l_hd, l_S, l_Y, l_rho, l_alpha, l_old, l_total;
 };
 
 // compile-time horizon NT (0 = runtime horizon from KParams; DPP row counts then cover the whole wave)
@@ -276,8 +279,9 @@ __global__ __launch_bounds__(WAVE) void prep_kernel(KParams kp, BatchPtrs io, in
         double* sg = ws + kp.ws_seg + SEGW * i;
         sg[0] = s1x; sg[1] = s1y; sg[2] = dx; sg[3] = dy;
         sg[4] = 1.0 / (dx * dx + dy * dy + 1e-16);
-        sg[5] = s1x + 0.5 * dx; sg[6] = s1y + 0.5 * dy;
-        sg[7] = 0.5 * sqrt(dx * dx + dy * dy) * (1.0 + 1e-12);
+        double* sc = ws + kp.ws_segc + SEGC * i;
+        sc[0] = s1x + 0.5 * dx; sc[1] = s1y + 0.5 * dy;
+        sc[2] = 0.5 * sqrt(dx * dx + dy * dy) * (1.0 + 1e-12);
         // bounding circle of the reference points i..N-1 (every remaining segment lies inside it)
         double xlo = s1x, xhi = s1x, ylo = s1y, yhi = s1y;
         for (int j = i + 1; j < N; ++j) {
@@ -290,8 +294,9 @@ __global__ __launch_bounds__(WAVE) void prep_kernel(KParams kp, BatchPtrs io, in
             const double ex = p[kp.r0 + 3 * j] - bcx, ey = p[kp.r0 + 3 * j + 1] - bcy;
             r2 = fmax(r2, ex * ex + ey * ey);
         }
-        sg[8] = bcx; sg[9] = bcy; sg[10] = sqrt(r2) * (1.0 + 1e-12) + 1e-300; sg[11] = 0.0;
+        sg[5] = bcx; sg[6] = bcy; sg[7] = sqrt(r2) * (1.0 + 1e-12) + 1e-300; sg[8] = 0.0;
         ws[kp.ws_vref + i] = p[kp.r0 + 3 * N + i];
+        ws[kp.ws_qd + i] = p[kp.qd0 + i];
     }
     // ---- static obstacles: lane o checks obstacle o
     int Ks;
@@ -336,8 +341,8 @@ __global__ __launch_bounds__(WAVE) void prep_kernel(KParams kp, BatchPtrs io, in
         if (lane < kp.Ndynobs) {
             const double* q = p + kp.od0 + lane * 6 * N;
             for (int t = 0; t < 6 * N; ++t) nz |= (q[t] != 0.0);
-            for (int k = 1; k < N; ++k)  // semi-axes and angle constant over the horizon?
-                varshape |= (q[6 * k + 2] != q[2]) | (q[6 * k + 3] != q[3]) | (q[6 * k + 4] != q[4]);
+            for (int k = 1; k < N; ++k)  // semi-axes, angle and alpha constant over the horizon?
+                varshape |= (q[6 * k + 2] != q[2]) | (q[6 * k + 3] != q[3]) | (q[6 * k + 4] != q[4]) | (q[6 * k + 5] != q[5]);
         }
         const unsigned long long m = __ballot(nz);
         Kd = __popcll(m);
@@ -364,6 +369,7 @@ __global__ __launch_bounds__(WAVE) void prep_kernel(KParams kp, BatchPtrs io, in
             d[6] = 1.0 / ((rx + kp.social + 1e-6) * (rx + kp.social + 1e-6));
             d[7] = 1.0 / ((ry + kp.social + 1e-6) * (ry + kp.social + 1e-6));
             d[8] = p[kp.qd0 + k] * q[5];  // q_dyn[k] * alpha
+            if (k == 0) ws[kp.ws_alpha + e] = q[5];
         }
     }
     const bool any_var = __ballot(varshape) != 0ull;
@@ -391,7 +397,8 @@ struct Ctx {
     bool vl, il;
     double vref;  // vector lane k: speed reference of step k
     // LDS tables
-    double *seg, *stc, *fxy, *dyn, *dync, *pos, *H, *W, *part, *stash;
+    double *seg, *stc, *fxy, *dyn, *dync, *qd, *pos, *H, *W, *part, *stash;
+    const double* segc;  // cold segment fields, in the workspace (global memory)
 };
 constexpr int KC_BASE = 32;
 #define KC(i) (cx.hd[KC_BASE + (i)])
@@ -425,22 +432,24 @@ __device__ __forceinline__ void load_problem(const KParams& kp, const double* __
     cx.terminal = U(H_QN) != 0.0 || U(H_QTHN) != 0.0;
     cx.vref = cx.vl ? ws[kp.ws_vref + lane] : 0.0;
     cx.seg = lds + kp.l_seg; cx.stc = lds + kp.l_stc; cx.fxy = lds + kp.l_fxy;
-    cx.dyn = lds + kp.l_dyn; cx.dync = lds + kp.l_dync; cx.pos = lds + kp.l_pos; cx.H = lds + kp.l_H;
+    cx.segc = ws + kp.ws_segc;
+    cx.dyn = lds + kp.l_dyn; cx.dync = lds + kp.l_dync; cx.qd = lds + kp.l_qd; cx.pos = lds + kp.l_pos; cx.H = lds + kp.l_H;
     cx.W = lds + kp.l_W; cx.part = lds + kp.l_part; cx.stash = lds + kp.l_stash;
     // coalesced table copies HBM -> LDS (only the active entries of this problem)
     for (int i = lane; i < N * SEGW; i += WAVE) cx.seg[i] = ws[kp.ws_seg + i];
     for (int i = lane; i < cx.Ks * STCW; i += WAVE) cx.stc[i] = ws[kp.ws_stc + i];
     for (int i = lane; i < cx.Kf * N * 2; i += WAVE) cx.fxy[i] = ws[kp.ws_fxy + i];
     if (SC) {
-        // shape-constant rows: per-row constants from the step-0 record, per-step (cx, cy, wgt)
+        // shape-constant rows: per-row constants from the step-0 record (+ alpha), per-step centre, per-step q_dyn
         for (int i = lane; i < cx.Kd * DYNC; i += WAVE) {
             const int r = i / DYNC, f = i - r * DYNC;
-            cx.dync[i] = ws[kp.ws_dyn + (r * N) * DYNW + 2 + f];
+            cx.dync[i] = f < 6 ? ws[kp.ws_dyn + (r * N) * DYNW + 2 + f] : ws[kp.ws_alpha + r];
         }
         for (int i = lane; i < cx.Kd * N; i += WAVE) {
             const double* d = ws + kp.ws_dyn + i * DYNW;
-            cx.dyn[i * DYNP] = d[0]; cx.dyn[i * DYNP + 1] = d[1]; cx.dyn[i * DYNP + 2] = d[8];
+            cx.dyn[i * DYNP] = d[0]; cx.dyn[i * DYNP + 1] = d[1];
         }
+        for (int i = lane; i < N; i += WAVE) cx.qd[i] = ws[kp.ws_qd + i];
     } else {
         for (int i = lane; i < cx.Kd * N * DYNW; i += WAVE) cx.dyn[i] = ws[kp.ws_dyn + i];
     }
@@ -458,7 +467,7 @@ __device__ __forceinline__ DynItem dyn_item(const Ctx& cx, int i, int k, int N, 
     if (SC) {
         const double* e = cx.dyn + (i * N + k) * DYNP;
         const double* s = cx.dync + i * DYNC;
-        ex = px - e[0]; ey = py - e[1]; d.wgt = e[2];
+        ex = px - e[0]; ey = py - e[1]; d.wgt = cx.qd[k] * s[6];  // the same product prep_kernel forms for the general table
         d.ca = s[0]; d.sa = s[1]; d.ihx = s[2]; d.ihy = s[3]; d.isx = s[4]; d.isy = s[5];
     } else {
         const double* e = cx.dyn + (i * N + k) * DYNW;
@@ -572,7 +581,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         if (i < N) {
             sb = sqrt(best) * KC(K_SQRT);
             const double* sg = cx.seg + SEGW * (k + SEG_WIN * LPS);
-            const double bx = px - sg[8], by = py - sg[9], reach = (sb + sg[10]) * KC(K_REACH);
+            const double bx = px - sg[5], by = py - sg[6], reach = (sb + sg[7]) * KC(K_REACH);
             more = bx * bx + by * by < reach * reach;
         }
         if (__ballot(more) != 0ull) {
@@ -580,7 +589,8 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
             MPC_ITEM_LOOP
             for (; i < N; i += LPS) {
                 const double* sg = cx.seg + SEGW * i;
-                const double mx = px - sg[5], my = py - sg[6], reach = (sb + sg[7]) * KC(K_REACH);
+                const double* sc = cx.segc + SEGC * i;
+                const double mx = px - sc[0], my = py - sc[1], reach = (sb + sc[2]) * KC(K_REACH);
                 if (mx * mx + my * my < reach * reach) {
                     const double s1x = sg[0], s1y = sg[1], dx = sg[2], dy = sg[3], inv = sg[4];
                     const double th = ((px - s1x) * dx + (py - s1y) * dy) * inv;
@@ -854,8 +864,8 @@ __device__ __forceinline__ double dot2r(double a0, double a1, double b0, double 
 #ifndef MPC_MIN_WAVES
 #define MPC_MIN_WAVES 3  // waves per SIMD the register allocator must leave room for (512 / MPC_MIN_WAVES VGPRs)
 #endif
-template <int NT, bool SC, bool LBG>
-__global__ __launch_bounds__(WAVE, MPC_MIN_WAVES) void solve_kernel_pair(KParams kp, BatchPtrs io, int B) {
+template <int NT, bool SC, bool LBG, int MINW>
+__global__ __launch_bounds__(WAVE, MINW) void solve_kernel_pair(KParams kp, BatchPtrs io, int B) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int b = blockIdx.x;
     if (b >= B) return;
@@ -872,7 +882,10 @@ __global__ __launch_bounds__(WAVE, MPC_MIN_WAVES) void solve_kernel_pair(KParams
     double* LY = LBG ? io.ws + (size_t)b * kp.ws_stride + kp.ws_lby : lds + kp.l_Y;
     double* LRHO = lds + kp.l_rho;  // [mem]
     double* LALPHA = lds + kp.l_alpha;
-    double* LOLD = lds + kp.l_old;  // [N][4]: L-BFGS old state (u) and old g (gamma*fpr)
+    // [N][4]: L-BFGS old state (u) and old g (gamma*fpr); read and written once per PANOC iteration by its own lane.
+    // It follows S and Y into the workspace record (measured: keeping it in LDS when it still fits is no faster for the
+    // benchmark batch and slower for small batches and for N = 40).
+    double* LOLD = LBG ? io.ws + (size_t)b * kp.ws_stride + kp.ws_lold : lds + kp.l_old;
     const bool vl = cx.vl;
 
     // PANOC constants [OpEn]

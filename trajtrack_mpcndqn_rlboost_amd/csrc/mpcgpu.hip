@@ -38,6 +38,8 @@ struct Handle {
     int last_shape[4] = {0, 0, 0, 0};
     int last_B = 0;  // batch size of the last solve (for mpcgpu_last_eval_counts)
     bool shape_const = true;  // of the batch prepared last
+    int last_min_waves = 0;   // launch-bounds variant of the last solve (3 or 4 wavefronts per SIMD)
+    int num_cus = 256;
 };
 
 int fail(Handle* h, int code, const char* fmt, ...) {
@@ -73,6 +75,9 @@ inline int even(int x) { return (x + 1) & ~1; }
 #define MPC_LBFGS_IN_WORKSPACE 1
 #endif
 constexpr bool LBFGS_IN_WORKSPACE = MPC_LBFGS_IN_WORKSPACE != 0;
+#ifndef MPC_TRY_FOUR_WAVES
+#define MPC_TRY_FOUR_WAVES 1
+#endif
 
 void fill_static_params(Handle* h) {
     const mpcgpu_config& c = h->cfg;
@@ -99,31 +104,36 @@ void fill_static_params(Handle* h) {
     // workspace layout (worst-case strides)
     int o = HDR;
     k.ws_vref = o; o += even(N);
-    k.ws_seg = o; o += N * SEGW;
+    k.ws_seg = o; o += even(N * SEGW);
+    k.ws_segc = o; o += even(N * SEGC);
     k.ws_stc = o; o += c.Nstcobs * STCW;
     k.ws_fxy = o; o += c.Nother * N * 2;
     k.ws_dyn = o; o += even(c.Ndynobs * N * DYNW);
+    k.ws_qd = o; o += even(N);
+    k.ws_alpha = o; o += even(c.Ndynobs);
     k.ws_lbs = o; o += c.lbfgs_mem * N * 2;   // L-BFGS memory when it is kept in the workspace (see LBFGS_IN_WORKSPACE)
     k.ws_lby = o; o += c.lbfgs_mem * N * 2;
+    k.ws_lold = o; o += N * 4;
     k.ws_stride = (o + 15) & ~15;
 }
 
 // LDS carve for the batch maxima (doubles; every offset even => 16-byte aligned).
-// shape_const: every active dynamic row of the batch keeps (rx, ry, angle) over the horizon -> 3 doubles per
+// shape_const: every active dynamic row of the batch keeps (rx, ry, angle, alpha) over the horizon -> 2 doubles per
 // (row, step) + 6 per row instead of 9 per (row, step).
 void fill_lds_layout(KParams& k, int mKs, int mKf, int mKd, bool shape_const, bool lbfgs_in_lds) {
     const int N = k.N;
     k.mKs = mKs; k.mKf = mKf; k.mKd = mKd;
     int o = 0;
-    k.l_seg = o; o += N * SEGW;
+    k.l_seg = o; o += even(N * SEGW);
     k.l_stc = o; o += mKs * STCW;
     k.l_fxy = o; o += mKf * N * 2;
     if (shape_const) {
         k.l_dyn = o; o += even(mKd * N * DYNP);
         k.l_dync = o; o += even(mKd * DYNC);
+        k.l_qd = o; o += even(N);
     } else {
         k.l_dyn = o; o += even(mKd * N * DYNW);
-        k.l_dync = k.l_dyn;
+        k.l_dync = k.l_dyn; k.l_qd = k.l_dyn;
     }
     k.l_pos = o; o += N * 2;
     k.l_stash = o; o += N * 6;
@@ -140,7 +150,8 @@ void fill_lds_layout(KParams& k, int mKs, int mKf, int mKd, bool shape_const, bo
     }
     k.l_rho = o; o += even(k.mem);
     k.l_alpha = o; o += even(k.mem);
-    k.l_old = o; o += N * 4;
+    k.l_old = o;
+    if (lbfgs_in_lds) o += N * 4;
     k.l_total = o;
 }
 
@@ -216,6 +227,7 @@ int32_t mpcgpu_create(const mpcgpu_config* cfg, void** handle) {
         }                                                                                               \
     } while (0)
     CREATE_OK(hipSetDevice(h->device));
+    CREATE_OK(hipDeviceGetAttribute(&h->num_cus, hipDeviceAttributeMultiprocessorCount, h->device));
     CREATE_OK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     for (auto& ev : h->ev) CREATE_OK(hipEventCreate(&ev));
     CREATE_OK(hipHostMalloc((void**)&h->h_counts, 4 * sizeof(int), hipHostMallocDefault));
@@ -271,22 +283,33 @@ int32_t mpcgpu_solve_batch_dev(void* handle, int32_t B, const double* p, const d
     HIP_OK(h, hipEventRecord(h->ev[2], s));
     const size_t lds = h->kp.l_total * sizeof(double);
     // more than 64 KiB of dynamic LDS (long horizons with many time-varying obstacles) must be opted into per kernel
-#define LAUNCH_PAIR(NT, SC)                                                                                        \
+#define LAUNCH_PAIR_W(NT, SC, MINW)                                                                                \
     do {                                                                                                             \
-        auto kern = solve_kernel_pair<NT, SC, LBFGS_IN_WORKSPACE>;                                                   \
+        auto kern = solve_kernel_pair<NT, SC, LBFGS_IN_WORKSPACE, MINW>;                                             \
         if (lds > 64 * 1024)                                                                                         \
             HIP_OK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
         hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE), lds, s, h->kp, io, B);                                         \
     } while (0)
     // compile-time horizons for the configurations the reference uses (generic kernel otherwise) x
     // {shape-constant, general} dynamic-obstacle tables
+    // Residency: 160 KiB of LDS and 4 x 512 VGPRs per CU.  When a wavefront's LDS carve fits 16 times (<= 10 KiB) AND
+    // the batch has more problems than the 148-VGPR build can keep resident (12 per CU), the 128-VGPR build (4
+    // wavefronts per SIMD, ~20 spilled registers) wins by 9-12 %; a batch that fits anyway, or a bigger carve, runs
+    // the build without spills (it is 13 % faster per wavefront).
+#define LAUNCH_PAIR(NT, SC) LAUNCH_PAIR_W(NT, SC, MPC_MIN_WAVES)
     const bool sc = h->shape_const;
+    const bool four = MPC_TRY_FOUR_WAVES && lds <= 10 * 1024 && B > 4 * MPC_MIN_WAVES * h->num_cus;
+    h->last_min_waves = four && h->kp.N == 20 ? 4 : MPC_MIN_WAVES;
     switch (h->kp.N) {
-        case 20: if (sc) LAUNCH_PAIR(20, true); else LAUNCH_PAIR(20, false); break;
+        case 20:
+            if (four) { if (sc) LAUNCH_PAIR_W(20, true, 4); else LAUNCH_PAIR_W(20, false, 4); }
+            else if (sc) LAUNCH_PAIR(20, true); else LAUNCH_PAIR(20, false);
+            break;
         case 40: if (sc) LAUNCH_PAIR(40, true); else LAUNCH_PAIR(40, false); break;
         default: if (sc) LAUNCH_PAIR(0, true); else LAUNCH_PAIR(0, false); break;
     }
 #undef LAUNCH_PAIR
+#undef LAUNCH_PAIR_W
     HIP_OK(h, hipGetLastError());
     HIP_OK(h, hipEventRecord(h->ev[3], s));
     h->timing_valid = true;
