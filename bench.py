@@ -144,7 +144,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "solve_kernel", "kernel_ms": k_ms, "prep_kernel_ms": float(np.mean(prep_ms)),
                          "algorithmic_bytes_per_solve": algo_bytes // B,
-                         "note": "state is register/LDS/L2 resident: the kernel is VALU-f64 issue bound, see valu_f64",
+                         "note": "state is register/LDS/L2 resident: the kernel is VALU-f64 issue bound, see valu_f64; traffic = L2<->fabric bytes of the kernel's own cold state (L-BFGS ring, spill slots), see DESIGN.md section 2",
                          "valu_f64": valu_profile()},
         }
         if args.cpu_seconds > 0 and world == 1:
