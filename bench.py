@@ -139,7 +139,9 @@ def main():
                        "batch_per_gpu": B, "N_hor": N, "n_dyn": args.n_dyn, "parallelism": f"shard{world}",
                        "mean_inner_iterations": float(inner.mean()),
                        "mean_psi_evaluations": float(n_psi.mean()), "mean_grad_evaluations": float(n_grad.mean()),
-                       "status_histogram": np.bincount(status, minlength=3).tolist()},
+                       "status_histogram": np.bincount(status, minlength=3).tolist(),
+                       "lds_bytes_per_wavefront": solver.last_shape()["lds_bytes"],
+                       "wavefronts_per_simd": solver.last_shape()["waves_per_simd"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "solve_kernel", "kernel_ms": k_ms, "prep_kernel_ms": float(np.mean(prep_ms)),

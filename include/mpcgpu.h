@@ -124,6 +124,11 @@ int32_t mpcgpu_last_eval_counts(void* handle, int32_t B, int32_t* n_psi, int32_t
 int32_t mpcgpu_last_shape(void* handle, int32_t* max_static, int32_t* max_fleet, int32_t* max_dyn,
                           int32_t* lds_bytes);
 
+/* Register-allocation variant the last solve call was launched with: 3 (148 VGPRs, no spills) or 4 wavefronts per SIMD
+ * (128 VGPRs; chosen when the LDS carve fits 16 times into a CU and the batch exceeds 12 problems per CU).  Both give
+ * bitwise identical results. */
+int32_t mpcgpu_last_waves_per_simd(void* handle);
+
 #ifdef __cplusplus
 }
 #endif

@@ -505,3 +505,24 @@ def test_large_lds_carve_long_horizon_with_time_varying_obstacles():
     with pytest.raises(MpcGpuError, match="LDS carve"):
         bs.solve(pb)
     bs.close()
+
+
+def test_both_register_allocation_variants_give_bitwise_identical_solutions():
+    """The launcher runs the 148-VGPR build (3 wavefronts/SIMD) for batches that fit 12 problems per CU or whose LDS
+    carve exceeds 10 KiB, and the 128-VGPR build (4 wavefronts/SIMD, a few spilled registers) otherwise.  Same
+    arithmetic: the same problems must come out bitwise equal from both."""
+    cfg = make_cfg(20)
+    bs = BatchSolver(cfg)
+    big = scenes.make_batch(cfg, 4096, n_dyn=8, seed=77)
+    res_big = bs.solve(big["p"])
+    shape = bs.last_shape()
+    assert shape["lds_bytes"] <= 10 * 1024 and shape["waves_per_simd"] == 4
+    small = bs.solve(big["p"][:256])
+    assert bs.last_shape()["waves_per_simd"] == 3
+    assert np.array_equal(small.solution, res_big.solution[:256])
+    assert np.array_equal(small.cost, res_big.cost[:256])
+    assert np.array_equal(small.num_inner_iterations, res_big.num_inner_iterations[:256])
+    # many time-varying obstacles: the carve is beyond 10 KiB, the batch size no longer matters
+    dense = scenes.make_batch(cfg, 4096, n_dyn=15, seed=78)
+    bs.solve(dense["p"])
+    assert bs.last_shape()["lds_bytes"] > 10 * 1024 and bs.last_shape()["waves_per_simd"] == 3

@@ -460,6 +460,11 @@ int32_t mpcgpu_last_shape(void* handle, int32_t* max_static, int32_t* max_fleet,
     return 0;
 }
 
+int32_t mpcgpu_last_waves_per_simd(void* handle) {
+    Handle* h = (Handle*)handle;
+    return h ? h->last_min_waves : -1;
+}
+
 #ifdef MPC_PROFILE
 // profiling builds only: read and clear the phase-cycle table (24 counters)
 int32_t mpcgpu_debug_read_prof(double* out24) {

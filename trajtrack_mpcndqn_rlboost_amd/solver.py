@@ -44,7 +44,7 @@ class _CConfig(C.Structure):
 
 EXPORTS = ("mpcgpu_abi_version", "mpcgpu_create", "mpcgpu_destroy", "mpcgpu_last_error", "mpcgpu_num_params",
            "mpcgpu_solve_batch", "mpcgpu_solve_batch_dev", "mpcgpu_cost_grad_batch", "mpcgpu_last_timing",
-           "mpcgpu_last_eval_counts", "mpcgpu_last_shape")
+           "mpcgpu_last_eval_counts", "mpcgpu_last_shape", "mpcgpu_last_waves_per_simd")
 
 
 def library_path() -> str:
@@ -101,6 +101,8 @@ def load_library():
     L.mpcgpu_last_eval_counts.restype = C.c_int32
     L.mpcgpu_last_shape.argtypes = [vp, ip, ip, ip, ip]
     L.mpcgpu_last_shape.restype = C.c_int32
+    L.mpcgpu_last_waves_per_simd.argtypes = [vp]
+    L.mpcgpu_last_waves_per_simd.restype = C.c_int32
     _lib = L
     return L
 
@@ -254,4 +256,5 @@ class BatchSolver:
     def last_shape(self):
         v = [C.c_int32() for _ in range(4)]
         self._check(self._L.mpcgpu_last_shape(self._h, *[C.byref(x) for x in v]), "mpcgpu_last_shape")
-        return dict(max_static=v[0].value, max_fleet=v[1].value, max_dyn=v[2].value, lds_bytes=v[3].value)
+        return dict(max_static=v[0].value, max_fleet=v[1].value, max_dyn=v[2].value, lds_bytes=v[3].value,
+                    waves_per_simd=int(self._L.mpcgpu_last_waves_per_simd(self._h)))
