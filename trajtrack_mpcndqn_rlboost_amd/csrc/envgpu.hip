@@ -92,10 +92,11 @@ __constant__ double DIRS[16] = {0.0, 0.38268343236508978178, 0.70710678118654757
                                 0.0, -0.38268343236508978178, -0.70710678118654757274, -0.92387953251128673848,
                                 -1.0, -0.92387953251128673848, -0.70710678118654757274, -0.38268343236508978178};
 
-__global__ __launch_bounds__(WAVE) void env_step_kernel(EnvK k, const double* __restrict__ rec_all, double* state_all,
+__global__ __launch_bounds__(WAVE, 4) void env_step_kernel(EnvK k, const double* __restrict__ rec_all, double* state_all,
                                                         const int32_t* __restrict__ action, float* obs_int,
                                                         float* obs_ext, double* reward, uint8_t* terminated, int B) {
     __shared__ double pose[MAX_OBST + 1][4];
+    __shared__ __attribute__((aligned(16))) double dirs[16][2];
     const int b = blockIdx.x;
     if (b >= B) return;
     const int lane = threadIdx.x;
@@ -156,13 +157,13 @@ __global__ __launch_bounds__(WAVE) void env_step_kernel(EnvK k, const double* __
     }
     __syncthreads();
 
-    // ---- the 16 directions theta + j pi/8: even j = ray / sector centre, odd j = sector borders
-    double dx[16], dy[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        dx[j] = cth * DIRC[j] - sth * DIRS[j];
-        dy[j] = sth * DIRC[j] + cth * DIRS[j];
+    // ---- the 16 directions theta + j pi/8 (even j = ray / sector centre, odd j = sector borders) live in LDS: every
+    //      lane reads the same entry (a broadcast), which keeps 64 VGPRs free for a fourth resident wavefront per SIMD
+    if (lane < 16) {
+        dirs[lane][0] = cth * DIRC[lane] - sth * DIRS[lane];
+        dirs[lane][1] = sth * DIRC[lane] + cth * DIRS[lane];
     }
+    __syncthreads();
 
     // ---- edges: closest point of (edge within sector i), first hit of ray i, crossing parity per outline
     double sec[NSEG], ray[NSEG];
@@ -186,41 +187,49 @@ __global__ __launch_bounds__(WAVE) void env_step_kernel(EnvK k, const double* __
             const double xi = Ex * (-Py) * fast_rcp(Ey) + Px;
             if (xi > 0.0) mask ^= 1u << (owner + 1);
         }
-        const double ee = Ex * Ex + Ey * Ey, pe = Px * Ex + Py * Ey, pxe = Px * Ey - Py * Ex;
+        const double ee = Ex * Ex + Ey * Ey, pe = Px * Ex + Py * Ey;
         const double t_free = ee > 0.0 ? -pe * fast_rcp(ee) : 0.0;
-        // Line j through the robot with direction d_j meets the edge's carrier at parameter tc[j]; g0/g1 are the
-        // signed distances (x |d| = 1) of P and of the edge direction from that line.  Odd lines are sector borders
-        // (each shared by two neighbouring sectors), even lines carry the rays -- 16 reciprocals per edge in all.
-        double g0[16], g1[16], tc[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            g0[j] = dx[j] * Py - dy[j] * Px;
-            g1[j] = dx[j] * Ey - dy[j] * Ex;
-            tc[j] = -g0[j] * fast_rcp(g1[j]);   // inf / nan when the edge is parallel to the line: handled below
-        }
+        // Line j through the robot with direction d_j meets the edge's carrier at parameter tc; g0 / g1 are the signed
+        // distances (x |d| = 1) of P and of the edge direction from that line.  Odd lines are sector borders (each
+        // shared by two neighbouring sectors), even lines carry the rays -- 16 reciprocals per edge in all.  The lines
+        // are walked in order and only the previous border is kept (registers: residency, see __launch_bounds__).
+        struct Line { double g0, g1, tc, dx, dy; };
+        asm volatile("" ::: "memory");  // keep the direction reads inside the loop (hoisted, they pin 64 VGPRs again)
+        auto line = [&](int j) {
+            Line l;
+            l.dx = dirs[j][0]; l.dy = dirs[j][1];
+            l.g0 = l.dx * Py - l.dy * Px;
+            l.g1 = l.dx * Ey - l.dy * Ex;
+            l.tc = -l.g0 * fast_rcp(l.g1);   // inf / nan when the edge is parallel to the line: handled below
+            return l;
+        };
+        const Line first = line(15);
+        Line lower = first;
 #pragma unroll
         for (int i = 0; i < NSEG; ++i) {
-            const int jl = (2 * i + 15) & 15, ju = 2 * i + 1, jc = 2 * i;
+            const Line centre = line(2 * i);
+            const Line upper = i == NSEG - 1 ? first : line(2 * i + 1);
             // wedge = {cross(d_lower, X) >= 0} and {cross(d_upper, X) <= 0}: clip the edge's parameter range [0, 1]
             double t0 = 0.0, t1 = 1.0;
             bool empty = false;
-            if (g1[jl] > 0.0) t0 = fmax(t0, tc[jl]);
-            else if (g1[jl] < 0.0) t1 = fmin(t1, tc[jl]);
-            else if (g0[jl] < 0.0) empty = true;
-            if (g1[ju] < 0.0) t0 = fmax(t0, tc[ju]);
-            else if (g1[ju] > 0.0) t1 = fmin(t1, tc[ju]);
-            else if (g0[ju] > 0.0) empty = true;
+            if (lower.g1 > 0.0) t0 = fmax(t0, lower.tc);
+            else if (lower.g1 < 0.0) t1 = fmin(t1, lower.tc);
+            else if (lower.g0 < 0.0) empty = true;
+            if (upper.g1 < 0.0) t0 = fmax(t0, upper.tc);
+            else if (upper.g1 > 0.0) t1 = fmin(t1, upper.tc);
+            else if (upper.g0 > 0.0) empty = true;
             if (!empty && t0 <= t1) {
                 const double tt = fmin(fmax(t_free, t0), t1);
                 const double cx = Px + tt * Ex, cy = Py + tt * Ey;
                 sec[i] = fmin(sec[i], cx * cx + cy * cy);  // squared; the root is taken once, after the reduction
             }
-            // ray i: P + t E = s d_jc with t = tc[jc]; s follows from the projection on d (|d| = 1)
-            if (g1[jc] != 0.0) {
-                const double t = tc[jc];
-                const double s = (Px + t * Ex) * dx[jc] + (Py + t * Ey) * dy[jc];
-                if (s >= 0.0 && t >= 0.0 && t <= 1.0 && s <= L_SECTOR) ray[i] = fmin(ray[i], s);
+            // ray i: P + t E = s d with t = tc of the centre line; s follows from the projection on d (|d| = 1)
+            if (centre.g1 != 0.0) {
+                const double t = centre.tc;
+                const double sd = (Px + t * Ex) * centre.dx + (Py + t * Ey) * centre.dy;
+                if (sd >= 0.0 && t >= 0.0 && t <= 1.0 && sd <= L_SECTOR) ray[i] = fmin(ray[i], sd);
             }
+            lower = upper;
         }
     }
     mask = wave_xor(mask);
