@@ -80,3 +80,35 @@ if __name__ == "__main__":
     out["rect"] = np.array(ns["circle_to_rect"]([3.0, -2.0]))
     np.savez_compressed(os.path.join(HERE, "hybrid_switch.npz"), **out)
     print("wrote hybrid_switch.npz")
+
+
+def make_metrics_fixture():
+    """The reference's own Metrics class (src/main_pre.py:55-144) on seeded random trials -> hybrid_metrics.npz."""
+    import statistics
+    from typing import List, Tuple
+    ns = {"Polygon": Polygon, "Point": shim.Point, "List": List, "Tuple": Tuple, "np": np, "math": math, "statistics": statistics}
+    extract(os.path.join(REF, "src/main_pre.py"), ["Metrics"], ns)
+    rng = np.random.default_rng(21)
+    m = ns["Metrics"]("hyb")
+    out = {}
+    obstacles = [[(4.0, 3.1), (4.0, 5.0), (6.0, 5.0), (6.0, 3.1)], [(10.0, 0.9), (10.0, -1.5), (12.5, -1.5), (11.0, 1.0)]]
+    for t in range(7):
+        n = int(rng.integers(20, 60))
+        times = rng.uniform(1.0, 30.0, n)
+        acts = np.stack([np.clip(np.cumsum(rng.normal(0, 0.1, n + 1)) + 1.0, -0.5, 1.5), rng.normal(0, 0.2, n + 1)], axis=1)
+        ref = np.stack([np.linspace(0, 15, 63), np.full(63, 2.0), np.zeros(63)], axis=1)
+        traj = np.stack([np.linspace(0, 15 * rng.uniform(0.5, 1.0), n + 2), 2.0 + rng.normal(0, 0.4, n + 2)], axis=1)
+        ok = bool(rng.random() < 0.6)
+        m.add_trial_result(times.tolist(), ok, [tuple(a) for a in acts], [tuple(r) for r in ref], [tuple(p) for p in traj], obstacles)
+        out[f"t{t}_times"], out[f"t{t}_acts"], out[f"t{t}_ref"], out[f"t{t}_traj"], out[f"t{t}_ok"] = times, acts, ref, traj, np.array(ok)
+        tr = m.trial_list[-1]
+        out[f"t{t}_expect"] = np.array(tr["computation_time"] + tr["deviation_distance"] + tr["smoothness"] + [tr["clearance"], tr["finish_time"]], dtype=float)
+    avg = m.get_average(4)
+    out["average"] = np.array(avg["computation_time"] + avg["deviation_distance"] + avg["smoothness"] + [avg["clearance"], avg["finish_time"], avg["success_rate"]], dtype=float)
+    out["obstacles_json"] = np.frombuffer(json.dumps(obstacles).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, "hybrid_metrics.npz"), **out)
+    print("wrote hybrid_metrics.npz", avg)
+
+
+if __name__ == "__main__":
+    make_metrics_fixture()

@@ -112,3 +112,24 @@ def test_batched_geometry_helpers_match_the_scalar_ones():
     w = hybrid.filter_weights(20, 0.9)
     o, n = rng.normal(size=(20, 3)), rng.normal(size=(20, 3))
     assert np.allclose((1 - w)[:, None] * o + w[:, None] * n, hybrid.ref_traj_filter(o, n, 0.9), rtol=0, atol=0)
+
+
+def test_metrics_match_the_reference_class():
+    """Metrics (main_pre.py:55-144) on the trials recorded from the reference's own class."""
+    metrics = importlib.import_module("trajtrack_mpcndqn_rlboost_amd.metrics")
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "hybrid_metrics.npz"))
+    obstacles = json.loads(bytes(fx["obstacles_json"]).decode())
+    m = metrics.Metrics("hyb")
+    for t in range(7):
+        m.add_trial_result(fx[f"t{t}_times"].tolist(), bool(fx[f"t{t}_ok"]), [tuple(a) for a in fx[f"t{t}_acts"]],
+                           [tuple(r) for r in fx[f"t{t}_ref"]], [tuple(p) for p in fx[f"t{t}_traj"]], obstacles)
+        tr = m.trial_list[-1]
+        got = np.array(tr["computation_time"] + tr["deviation_distance"] + tr["smoothness"] + [tr["clearance"], tr["finish_time"]])
+        assert np.allclose(got, fx[f"t{t}_expect"], rtol=1e-12, atol=1e-12), t
+    avg = m.get_average(4)
+    got = np.array(avg["computation_time"] + avg["deviation_distance"] + avg["smoothness"] +
+                   [avg["clearance"], avg["finish_time"], avg["success_rate"]])
+    assert np.allclose(got, fx["average"], rtol=0, atol=1e-12)
+    assert fx["average"][7] > 0.0                    # a positive clearance: the distance branch is exercised
+    with pytest.raises(ValueError):
+        metrics.Metrics("rl")

@@ -7,6 +7,7 @@ sys.path.insert(0, ROOT)
 from trajtrack_mpcndqn_rlboost_amd import MpcConfig
 from trajtrack_mpcndqn_rlboost_amd.dqn import QNetwork
 hybrid = importlib.import_module("trajtrack_mpcndqn_rlboost_amd.hybrid")
+metrics = importlib.import_module("trajtrack_mpcndqn_rlboost_amd.metrics")
 
 
 def scene(rng, dynamic=True):
@@ -30,9 +31,12 @@ if __name__ == "__main__":
         rng = np.random.default_rng(3)
         run = hybrid.BatchedHybrid(cfg, [scene(rng) for _ in range(B)], q, decision_mode=mode)
         t0 = time.perf_counter()
-        out = run.run(steps)
+        out = run.run(steps, record=True)
         dt = time.perf_counter() - t0
         goal_dist = np.hypot(out["states"][:, 0] - 15.4, out["states"][:, 1] - 3.5)
         print(f"{name:9s} B={B}: ticks {run.t}, {1e3 * dt / run.t:.1f} ms/tick, success {out['success'].mean():.2f}, "
               f"collided {out['collided'].mean():.2f}, mean steps {out['steps'].mean():.0f}, "
               f"mean goal distance {goal_dist.mean():.2f}, ticks tracking the DQN proposal {out['switch_ticks'].mean():.1f}", flush=True)
+        m = metrics.Metrics({0: "dqn", 1: "mpc", 2: "hyb"}[mode])
+        m.add_batch(out["record"], [s["static"] for s in run.scenes])
+        print("          metrics (main_pre.py Metrics):", m.get_average(), flush=True)

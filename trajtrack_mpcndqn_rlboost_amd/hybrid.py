@@ -344,11 +344,31 @@ class BatchedHybrid:
         return dict(done=self.done.copy(), success=self.success.copy(), collided=self.collided.copy(),
                     switch_on=self.switch_on.copy(), states=trk.states.copy())
 
-    def run(self, max_steps: int = MAX_RUN_STEP) -> Dict[str, np.ndarray]:
+    def run(self, max_steps: int = MAX_RUN_STEP, record: bool = False) -> Dict[str, np.ndarray]:
+        """Run until every robot is done (or ``max_steps``).  ``record=True`` also returns what the reference's
+        ``Metrics.add_trial_result`` consumes per robot (``main_evaluation.py:255-266``): tick times [ms], (v, w) history,
+        traversed positions and the global reference trajectory (see ``metrics.Metrics.add_batch``)."""
+        import time
         out = None
+        tick_ms = [[] for _ in range(self.B)]
+        actions = [[(float(s["start"][3]), float(s["start"][4]))] for s in self.scenes]
+        positions = [[(float(s["start"][0]), float(s["start"][1]))] * 2 for s in self.scenes]   # update_status appends twice at reset
         for _ in range(max_steps):
+            live = ~self.done
+            t0 = time.perf_counter()
             out = self.tick()
+            dt = 1e3 * (time.perf_counter() - t0)
+            if record:
+                st = self.env.agent_state.cpu().numpy()
+                for b in np.nonzero(live)[0]:
+                    tick_ms[b].append(dt)
+                    actions[b].append((float(st[b, 3]), float(st[b, 4])))
+                    positions[b].append((float(st[b, 0]), float(st[b, 1])))
             if out["done"].all():
                 break
-        return dict(out, steps=self.steps.copy(), switch_ticks=self.switch_ticks.copy(),
-                    progress=self.env.path_progress.cpu().numpy())
+        res = dict(out, steps=self.steps.copy(), switch_ticks=self.switch_ticks.copy(),
+                   progress=self.env.path_progress.cpu().numpy())
+        if record:
+            res["record"] = dict(tick_ms=tick_ms, success=self.success.copy(), actions=actions, positions=positions,
+                                 ref_traj=[np.array(t) for t in self.tracker.ref_trajs])
+        return res
