@@ -158,3 +158,31 @@ def test_batched_tracker_assembly_is_bitwise_the_per_robot_assembly():
     pred = rng.normal(size=(B, 3, cfg.N_hor, 6))
     bt.set_dynamic_constraints(pred)
     assert np.array_equal(bt.dyn_constraints[5, :3 * cfg.N_hor * 6], pred[5].reshape(-1))
+
+
+def test_share_predictions_builds_the_reference_other_robot_block():
+    """``get_other_robot_states`` (scenario_simulator.py:154-163): the other robots' predictions in fleet order,
+    N x (x, y, theta) each, zero padded to Nother robots; more than Nother others are cut."""
+    import importlib
+    from trajtrack_mpcndqn_rlboost_amd.config import MpcConfig
+    btm = importlib.import_module("trajtrack_mpcndqn_rlboost_amd.batched_tracker")
+    cfg = MpcConfig()
+    B = 17
+    bt = btm.BatchedTracker(cfg, B, solver=object())
+    rng = np.random.default_rng(0)
+    bt.pred_states[:] = rng.normal(size=bt.pred_states.shape)
+    groups = [[0, 1, 2], [3], list(range(4, 17))]           # 3 robots, a loner, 13 robots (> Nother + 1 = 11)
+    bt.share_predictions(groups)
+    per = cfg.N_hor * cfg.ns
+    for g in groups:
+        for i in g:
+            expect, pos = [0.0] * (cfg.ns * cfg.N_hor * cfg.Nother), 0     # the reference's loop, verbatim semantics
+            for j in g:
+                if j != i and pos + per <= len(expect):
+                    expect[pos:pos + per] = bt.pred_states[j].reshape(-1).tolist()
+                    pos += per
+            assert np.array_equal(bt.other_robot_states[i], np.asarray(expect)), (g, i)
+    assert not bt.other_robot_states[3].any()
+    P = bt.assemble("work")
+    off = cfg.offsets()
+    assert np.array_equal(P[1, off["c"]:off["c"] + per], bt.pred_states[0].reshape(-1))

@@ -82,17 +82,25 @@ class BatchedTracker:
         self.dyn_constraints[:, :block.shape[1]] = block
 
     def share_predictions(self, groups: Optional[Sequence[Sequence[int]]] = None):
-        """Fill every robot's other-robot block with the latest predictions of the robots in its group
-        (layout of ``scenario_simulator.py:154-163``: robot after robot, N x (x, y, theta) each, zero padded)."""
+        """Fill every robot's other-robot block with the latest predictions of the other robots of its group, in group
+        order, N x (x, y, theta) each, zero padded -- ``get_other_robot_states`` (``scenario_simulator.py:154-163``).
+        Before the first solve the predictions are zeros, which is what the reference's block holds then too."""
         cfg = self.config
         groups = groups if groups is not None else [list(range(self.B))]
+        per = cfg.N_hor * cfg.ns
         for g in groups:
-            for i in g:
-                others = [j for j in g if j != i][:cfg.Nother]
-                block = np.zeros((cfg.Nother, cfg.N_hor, cfg.ns))
-                if others:
-                    block[:len(others)] = self.pred_states[others]
-                self.other_robot_states[i] = block.reshape(-1)
+            idx = np.asarray(g, dtype=np.int64)
+            n = len(idx)
+            if n == 0:
+                continue
+            keep = min(n - 1, cfg.Nother)
+            block = np.zeros((n, cfg.Nother * per))
+            if keep > 0:
+                # others[i] = the group without robot i, order preserved
+                others = np.stack([np.delete(idx, i)[:keep] for i in range(n)]) if n <= 64 else \
+                    np.array([np.delete(idx, i)[:keep] for i in range(n)])
+                block[:, :keep * per] = self.pred_states[others].reshape(n, keep * per)
+            self.other_robot_states[idx] = block
 
     # -- one control tick for all robots ---------------------------------------------------------------------------
     def local_refs(self) -> np.ndarray:
