@@ -18,7 +18,8 @@
  * 0 = ok, < 0 = error (text via mpcgpu_env_last_error, thread-local).  There is no CPU fallback.
  *
  * Record of environment b (doubles), R = mpcgpu_env_record_doubles(params):
- *     [0] n_path  [1] n_obstacles  [2] n_edges  [3] goal_x  [4] goal_y  [5..15] reserved
+ *     [0] n_path  [1] n_obstacles  [2] n_edges  [3] goal_x  [4] goal_y  [5..9] start state x, y, theta, v, w (used by the
+ *     in-kernel auto-reset)  [10..15] reserved
  *     path_cum [P]      cumulative length at node i (sequential float64 sum, path_cum[i+1] = path_cum[i] + path_len[i])
  *     path_len [P]      length of segment i -> i+1
  *     path_xy  [P][2]
@@ -32,7 +33,8 @@
  *     [0..4] x, y, theta, v, w   [5] obstacle clock   [6] last path progress (reward_path_progress.py)
  *     [7] flags: 1 collided with obstacle | 2 collided with boundary | 4 reached goal  (sticky, environment.py:113-116)
  *     [8..23] first 16 entries of the previous external observation (the observation's one-step memory)
- *     [24] path progress (output)   [25] step counter   [26..31] reserved
+ *     [24] path progress (output)   [25] step counter   [26] flags of the last step (kept across an in-kernel reset)
+ *     [27..31] reserved
  */
 #ifndef MPCGPU_ENV_H
 #define MPCGPU_ENV_H
@@ -77,6 +79,19 @@ int32_t mpcgpu_env_record_doubles(const mpcgpu_env_params* params);
 int32_t mpcgpu_env_step_dev(int32_t device, const mpcgpu_env_params* params, int32_t B, const double* records,
                             double* state, const int32_t* action, float* obs_internal, float* obs_external,
                             double* reward, uint8_t* terminated, void* stream);
+
+/*
+ * The same step with the episode bookkeeping of a vectorised environment done INSIDE the kernel (what SB3's VecEnv +
+ * gym's TimeLimit do around env.step for the reference's training, src/test_block_rl.py:68-69, environment/__init__.py:
+ * 15-25): an environment that terminated (collision / goal) or reached max_episode_steps is put back to the start
+ * state of its record, observed again, and that observation is what obs_internal / obs_external hold on return; the
+ * observation the episode ended in goes to terminal_obs_* (rows of environments that did not end are left untouched).
+ *   truncated [B]: 1 = ended by the step limit (not a terminal state for the bootstrap).  terminal_obs_* may be NULL.
+ */
+int32_t mpcgpu_env_step_autoreset_dev(int32_t device, const mpcgpu_env_params* params, int32_t B, const double* records,
+                                      double* state, const int32_t* action, float* obs_internal, float* obs_external,
+                                      double* reward, uint8_t* terminated, uint8_t* truncated, float* terminal_obs_internal,
+                                      float* terminal_obs_external, int32_t max_episode_steps, void* stream);
 
 const char* mpcgpu_env_last_error(void);
 

@@ -55,14 +55,16 @@ def main():
     trainer = dqn_train.DqnTrainer(device=f"cuda:{local}", double_q=args.double_q, lr=1e-3)
     learner = dqn_train.DqnLearner(env, trainer, buffer_size=2_000_000, learning_starts=4 * args.envs,
                                    batch_size=args.batch_size, train_freq=4, gradient_steps=args.gradient_steps,
-                                   target_update_interval=200_000, exploration_fraction=0.3, use_graph=args.graph)
+                                   target_update_interval=200_000, exploration_fraction=0.3, use_graph=args.graph,
+                                   track_episodes=False)
     marks, t0 = [], time.perf_counter()
 
     def progress(lr):
         if lr.num_timesteps // (args.timesteps // 10) > len(marks):
-            recent, succ = lr.episode_returns[-2000:], lr.episode_successes[-2000:]
-            marks.append((lr.num_timesteps, float(np.mean(recent)) if recent else float("nan"),
-                          float(np.mean(succ)) if succ else float("nan"), time.perf_counter() - t0))
+            n, r, ok = float(lr.ep_count), float(lr.ep_return_sum), float(lr.ep_success_sum)      # one sync per mark
+            pn, pr, pok = marks[-1][4:] if marks else (0.0, 0.0, 0.0)
+            dn = max(n - pn, 1.0)
+            marks.append((lr.num_timesteps, (r - pr) / dn, (ok - pok) / dn, time.perf_counter() - t0, n, r, ok))
             if rank == 0:
                 print(f"  {marks[-1][0]:>9d} steps  mean return {marks[-1][1]:8.2f}  success {marks[-1][2]:.2f}  {marks[-1][3]:6.1f} s", flush=True)
 

@@ -92,9 +92,18 @@ __constant__ double DIRS[16] = {0.0, 0.38268343236508978178, 0.70710678118654757
                                 0.0, -0.38268343236508978178, -0.70710678118654757274, -0.92387953251128673848,
                                 -1.0, -0.92387953251128673848, -0.70710678118654757274, -0.38268343236508978178};
 
+struct EnvOut {
+    float* obs_int; float* obs_ext; double* reward; uint8_t* terminated;
+    // in-kernel auto-reset (max_steps > 0): time-limit flag, and where the observation an episode ENDED in is kept
+    uint8_t* truncated; float* term_int; float* term_ext; int max_steps;
+};
+
 __global__ __launch_bounds__(WAVE, 4) void env_step_kernel(EnvK k, const double* __restrict__ rec_all, double* state_all,
-                                                        const int32_t* __restrict__ action, float* obs_int,
-                                                        float* obs_ext, double* reward, uint8_t* terminated, int B) {
+                                                        const int32_t* __restrict__ action, EnvOut out, int B) {
+    float* const obs_int = out.obs_int;
+    float* const obs_ext = out.obs_ext;
+    double* const reward = out.reward;
+    uint8_t* const terminated = out.terminated;
     __shared__ double pose[MAX_OBST + 1][4];
     __shared__ __attribute__((aligned(16))) double dirs[16][2];
     const int b = blockIdx.x;
@@ -106,9 +115,9 @@ __global__ __launch_bounds__(WAVE, 4) void env_step_kernel(EnvK k, const double*
     const int n_path = (int)rec[0], n_obst = (int)rec[1], n_edge = (int)rec[2];
     const double gx = rec[3], gy = rec[4];
     double x = st[0], y = st[1], th = st[2], v = st[3], w = st[4], clock = st[5];
-    const double last_prog = st[6];
+    double last_prog = st[6], steps = st[25];
     int flags = (int)st[7];
-    const bool act = action != nullptr;
+    bool act = action != nullptr;
     const double ts = P.time_step;
 
     // ---- obstacles' clock and the robot (environment.py:199-203, agent.py:97-139); every lane keeps the same copy
@@ -128,6 +137,9 @@ __global__ __launch_bounds__(WAVE, 4) void env_step_kernel(EnvK k, const double*
         x += ts * v * cos(th);
         y += ts * v * sin(th);
     }
+    // Pass 0 is the step itself.  With in-kernel auto-reset (out.max_steps > 0) an environment whose episode ended is
+    // put back to its start state and observed again in pass 1 -- no host round trip, no second launch.
+    auto run_pass = [&](const int pass) -> bool {   // returns true when the episode ended and pass 1 is wanted
     const double cth = cos(th), sth = sin(th);
 
     // ---- key-frame pose of obstacle `lane` (obstacle.py:71-88): (x, y, cos rot, sin rot) -> LDS
@@ -328,36 +340,59 @@ __global__ __launch_bounds__(WAVE, 4) void env_step_kernel(EnvK k, const double*
         float* o = oi + 2 + 3 * lane;
         o[0] = (float)cr; o[1] = (float)sr; o[2] = (float)normalize_distance(d);
     }
-    if (lane != 0) return;
-    // ---- status flags, sticky (environment.py:113-116)
+    // ---- status flags, sticky (environment.py:113-116); uniform, every lane keeps a copy
     if (in_obstacle) flags |= 1;
     if (!(mask & 1u)) flags |= 2;
     if (sqrt((gx - x) * (gx - x) + (gy - y) * (gy - y)) < P.radius) flags |= 4;
     const bool collided = (flags & 3) != 0, reached = (flags & 4) != 0;
+    if (act) { steps += 1.0; }
+    const bool timeout = out.max_steps > 0 && steps >= (double)out.max_steps && !(collided || reached);
 
-    // ---- speed and angular velocity (components/int_obsv_speed.py, int_obsv_angular_velocity.py)
-    oi[0] = (float)(2.0 * (v - P.speed_min) / (P.speed_max - P.speed_min) - 1.0);
-    // the reference normalises the angular velocity with the angular ACCELERATION limits (int_obsv_angular_velocity.py:13-19)
-    oi[1] = (float)(2.0 * (w - P.angacc_min) / (P.angacc_max - P.angacc_min) - 1.0);
-
-    // ---- reward R1 (rays_reward1.py:26-39; summed in component order)
-    if (act) {
-        double r = collided ? -P.collision_factor : 0.0;
-        r += -ts * P.cross_track_factor * cte * cte;
-        r += reached ? P.reach_goal_factor : 0.0;
-        const double err = copysign(1.0, P.reference_speed) * (v - P.reference_speed);
-        r += -ts * P.excessive_speed_factor * fmax(0.0, err);
-        r += P.path_progress_factor * (progress - last_prog);
-        if (reward) reward[b] = r;
-        st[6] = progress;
-        st[25] += 1.0;
-    } else if (reward) {
-        reward[b] = 0.0;
+    if (lane == 0) {
+        // ---- speed and angular velocity (components/int_obsv_speed.py, int_obsv_angular_velocity.py)
+        oi[0] = (float)(2.0 * (v - P.speed_min) / (P.speed_max - P.speed_min) - 1.0);
+        // the reference normalises the angular velocity with the angular ACCELERATION limits (int_obsv_angular_velocity.py:13-19)
+        oi[1] = (float)(2.0 * (w - P.angacc_min) / (P.angacc_max - P.angacc_min) - 1.0);
+        if (pass == 0) {
+            // ---- reward R1 (rays_reward1.py:26-39; summed in component order)
+            if (act) {
+                double r = collided ? -P.collision_factor : 0.0;
+                r += -ts * P.cross_track_factor * cte * cte;
+                r += reached ? P.reach_goal_factor : 0.0;
+                const double err = copysign(1.0, P.reference_speed) * (v - P.reference_speed);
+                r += -ts * P.excessive_speed_factor * fmax(0.0, err);
+                r += P.path_progress_factor * (progress - last_prog);
+                if (reward) reward[b] = r;
+            } else if (reward) {
+                reward[b] = 0.0;
+            }
+            if (terminated) terminated[b] = (collided || reached) ? 1 : 0;
+            if (out.truncated) out.truncated[b] = timeout ? 1 : 0;
+            st[26] = (double)flags;   // flags of this step, still readable after an in-kernel reset
+        }
+        st[0] = x; st[1] = y; st[2] = th; st[3] = v; st[4] = w; st[5] = clock;
+        st[6] = (act || pass == 1) ? (pass == 1 ? 0.0 : progress) : last_prog;
+        st[7] = (double)flags;
+        st[24] = progress;
+        st[25] = steps;
     }
-    if (terminated) terminated[b] = (collided || reached) ? 1 : 0;
-    st[0] = x; st[1] = y; st[2] = th; st[3] = v; st[4] = w; st[5] = clock;
-    st[7] = (double)flags;
-    st[24] = progress;
+    return pass == 0 && out.max_steps > 0 && act && (collided || reached || timeout);
+    };  // run_pass
+
+    if (!run_pass(0)) return;
+
+    // ---- the episode ended: keep its last observation, go back to the start state (environment.py:166-186) and
+    //      observe once more.  The observation memory (st[8..23]) is not cleared -- the reference's component keeps it.
+    __threadfence();
+    __syncthreads();
+    if (out.term_int && lane < MPCGPU_ENV_INTERNAL_OBS)
+        out.term_int[(size_t)b * MPCGPU_ENV_INTERNAL_OBS + lane] = obs_int[(size_t)b * MPCGPU_ENV_INTERNAL_OBS + lane];
+    if (out.term_ext && lane < MPCGPU_ENV_EXTERNAL_OBS)
+        out.term_ext[(size_t)b * MPCGPU_ENV_EXTERNAL_OBS + lane] = obs_ext[(size_t)b * MPCGPU_ENV_EXTERNAL_OBS + lane];
+    __syncthreads();
+    x = rec[5]; y = rec[6]; th = rec[7]; v = rec[8]; w = rec[9];
+    clock = 0.0; flags = 0; steps = 0.0; last_prog = 0.0; act = false;
+    run_pass(1);
 }
 
 thread_local std::string g_err;
@@ -379,23 +414,39 @@ int32_t mpcgpu_env_record_doubles(const mpcgpu_env_params* params) {
     return k.rec;
 }
 
-int32_t mpcgpu_env_step_dev(int32_t device, const mpcgpu_env_params* params, int32_t B, const double* records,
-                            double* state, const int32_t* action, float* obs_internal, float* obs_external,
-                            double* reward, uint8_t* terminated, void* stream) {
+static int32_t launch_env(int32_t device, const mpcgpu_env_params* params, int32_t B, const double* records, double* state,
+                          const int32_t* action, envgpu::EnvOut out, void* stream) {
     using namespace envgpu;
     EnvK k;
     if (!params || !layout(*params, k)) return fail("invalid mpcgpu_env_params (P 2..64, M 0..31, K 1..4, E >= 1)");
     if (params->num_segments != NSEG || params->corner_samples != NCORNER)
         return fail("only num_segments = 8 and corner_samples = 3 are built (rays_reward1.py:18-20)");
-    if (B < 0 || !records || !state || !obs_internal || !obs_external) return fail("null pointer / negative batch");
+    if (B < 0 || !records || !state || !out.obs_int || !out.obs_ext) return fail("null pointer / negative batch");
     if (B == 0) return 0;
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) return fail("hipSetDevice", e);
-    hipLaunchKernelGGL(env_step_kernel, dim3(B), dim3(WAVE), 0, (hipStream_t)stream, k, records, state, action,
-                       obs_internal, obs_external, reward, terminated, (int)B);
+    hipLaunchKernelGGL(env_step_kernel, dim3(B), dim3(WAVE), 0, (hipStream_t)stream, k, records, state, action, out, (int)B);
     e = hipGetLastError();
     if (e != hipSuccess) return fail("env_step_kernel launch", e);
     return 0;
+}
+
+int32_t mpcgpu_env_step_dev(int32_t device, const mpcgpu_env_params* params, int32_t B, const double* records,
+                            double* state, const int32_t* action, float* obs_internal, float* obs_external,
+                            double* reward, uint8_t* terminated, void* stream) {
+    envgpu::EnvOut out{obs_internal, obs_external, reward, terminated, nullptr, nullptr, nullptr, 0};
+    return launch_env(device, params, B, records, state, action, out, stream);
+}
+
+int32_t mpcgpu_env_step_autoreset_dev(int32_t device, const mpcgpu_env_params* params, int32_t B, const double* records,
+                                      double* state, const int32_t* action, float* obs_internal, float* obs_external,
+                                      double* reward, uint8_t* terminated, uint8_t* truncated, float* terminal_obs_internal,
+                                      float* terminal_obs_external, int32_t max_episode_steps, void* stream) {
+    if (!action) return envgpu::fail("auto-reset needs actions (use mpcgpu_env_step_dev to observe)");
+    if (max_episode_steps <= 0) return envgpu::fail("max_episode_steps must be positive");
+    envgpu::EnvOut out{obs_internal, obs_external, reward, terminated, truncated, terminal_obs_internal,
+                       terminal_obs_external, max_episode_steps};
+    return launch_env(device, params, B, records, state, action, out, stream);
 }
 
 const char* mpcgpu_env_last_error(void) { return envgpu::g_err.c_str(); }

@@ -195,7 +195,7 @@ class DqnLearner:
                  learning_starts: int = 50_000, batch_size: int = 32, train_freq: int = 4, gradient_steps: int = -1,
                  target_update_interval: int = 10_000, exploration_fraction: float = 0.2,
                  exploration_initial_eps: float = 1.0, exploration_final_eps: float = 0.05, seed: int = 0,
-                 use_graph: bool = False):
+                 use_graph: bool = False, track_episodes: bool = True):
         self.env = env
         self.device = env.device
         self.trainer = trainer if trainer is not None else DqnTrainer(device=str(self.device))
@@ -208,6 +208,11 @@ class DqnLearner:
         self.gen.manual_seed(seed + (dist.get_rank() if dist.is_available() and dist.is_initialized() else 0))
         self.num_timesteps, self.n_calls = 0, 0
         self.episode_returns, self.episode_successes = [], []
+        # track_episodes=False keeps the episode statistics as device counters (no host synchronisation in the loop)
+        self.track_episodes = track_episodes
+        self.ep_count = torch.zeros((), dtype=torch.float64, device=self.device)
+        self.ep_return_sum = torch.zeros((), dtype=torch.float64, device=self.device)
+        self.ep_success_sum = torch.zeros((), dtype=torch.float64, device=self.device)
         self.use_graph = use_graph
         if use_graph:
             self.trainer.enable_graph(batch_size)
@@ -238,10 +243,15 @@ class DqnLearner:
                 stored_next = flatten_observation(info["terminal_observation"]) if "terminal_observation" in info else nxt_flat
                 self.buffer.add(obs, stored_next, actions, reward, terminated)
                 ep_return += reward
-                if bool(done.any()):
-                    self.episode_returns += ep_return[done].tolist()
-                    self.episode_successes += info["success"][done].tolist()
-                    ep_return = torch.where(done, torch.zeros_like(ep_return), ep_return)
+                if self.track_episodes:
+                    if bool(done.any()):
+                        self.episode_returns += ep_return[done].tolist()
+                        self.episode_successes += info["success"][done].tolist()
+                else:
+                    self.ep_count += done.sum()
+                    self.ep_return_sum += (ep_return * done).sum()
+                    self.ep_success_sum += (info["success"] & done).sum()
+                ep_return = torch.where(done, torch.zeros_like(ep_return), ep_return)
                 obs = nxt_flat
                 self.num_timesteps += B
                 self.n_calls += 1
@@ -258,6 +268,11 @@ class DqnLearner:
                 n_updates += steps
             if callback is not None:
                 callback(self)
+        if not self.track_episodes:       # whole-run averages from the device counters
+            n = float(self.ep_count)
+            return dict(timesteps=self.num_timesteps, updates=n_updates, loss=float(last_loss), episodes=int(n),
+                        mean_return=float(self.ep_return_sum) / n if n else float("nan"),
+                        success_rate=float(self.ep_success_sum) / n if n else float("nan"))
         recent = self.episode_returns[-100:]
         return dict(timesteps=self.num_timesteps, updates=n_updates, loss=float(last_loss),
                     episodes=len(self.episode_returns),

@@ -95,7 +95,7 @@ class _CParams(C.Structure):
                 ("angacc_max", C.c_double)]
 
 
-ENV_EXPORTS = ("mpcgpu_env_record_doubles", "mpcgpu_env_step_dev", "mpcgpu_env_last_error")
+ENV_EXPORTS = ("mpcgpu_env_record_doubles", "mpcgpu_env_step_dev", "mpcgpu_env_step_autoreset_dev", "mpcgpu_env_last_error")
 
 
 def _bind(lib):
@@ -106,6 +106,8 @@ def _bind(lib):
     lib.mpcgpu_env_record_doubles.restype = C.c_int32
     lib.mpcgpu_env_step_dev.argtypes = [C.c_int32, C.POINTER(_CParams), C.c_int32] + [vp] * 8
     lib.mpcgpu_env_step_dev.restype = C.c_int32
+    lib.mpcgpu_env_step_autoreset_dev.argtypes = [C.c_int32, C.POINTER(_CParams), C.c_int32] + [vp] * 10 + [C.c_int32, vp]
+    lib.mpcgpu_env_step_autoreset_dev.restype = C.c_int32
     lib.mpcgpu_env_last_error.argtypes = []
     lib.mpcgpu_env_last_error.restype = C.c_char_p
     lib._env_bound = True
@@ -144,6 +146,7 @@ def pack_records(maps: Sequence[Dict], n_kf_max: int = 2):
         cum, seg = path_lengths(path)
         n = len(path)
         r[0], r[1], r[3], r[4] = n, len(m["obstacles"]), m["goal"][0], m["goal"][1]
+        r[5:10] = np.asarray(m["start"], dtype=np.float64)
         r[o_cum:o_cum + n], r[o_len:o_len + n] = cum, seg
         r[o_xy:o_xy + 2 * n] = path.reshape(-1)
         edges = []
@@ -202,6 +205,9 @@ class BatchedRaysEnv:
         self.obs_external = torch.zeros(self.B, N_EXTERNAL, dtype=torch.float32, device=self.device)
         self.reward = torch.zeros(self.B, dtype=torch.float64, device=self.device)
         self.terminated = torch.zeros(self.B, dtype=torch.uint8, device=self.device)
+        self.truncated = torch.zeros(self.B, dtype=torch.uint8, device=self.device)
+        self.term_internal = torch.zeros_like(self.obs_internal)
+        self.term_external = torch.zeros_like(self.obs_external)
         self.max_episode_steps = max_episode_steps
         self.time_step = time_step
 
@@ -246,20 +252,37 @@ class BatchedRaysEnv:
         return self._obs()
 
     def step(self, actions, auto_reset: bool = False):
-        """``env.step`` (environment.py:199-213) -> (obs, reward [B], terminated [B] bool, truncated [B] bool, info)."""
+        """``env.step`` (environment.py:199-213) -> (obs, reward [B], terminated [B] bool, truncated [B] bool, info).
+
+        ``auto_reset=True`` is the vectorised-environment behaviour (SB3 VecEnv + gym TimeLimit): ended episodes are reset
+        INSIDE the same kernel launch, ``obs`` is then the first observation of the next episode and
+        ``info["terminal_observation"]`` the one the episode ended in (for the other rows it equals ``obs``)."""
         torch = self._torch
-        self._launch(actions)
+        if not auto_reset:
+            self._launch(actions)
+            obs = self._obs()
+            terminated = self.terminated.bool()
+            truncated = (self.state[:, 25] >= self.max_episode_steps) & ~terminated
+            return obs, self.reward.clone(), terminated, truncated, {"success": (self.state[:, 7].to(torch.int64) & 4) != 0}
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        actions = torch.as_tensor(actions, device=self.device).to(torch.int32).contiguous()
+        if actions.shape != (self.B,):
+            raise ValueError(f"actions must have shape ({self.B},)")
+        rc = self._lib.mpcgpu_env_step_autoreset_dev(
+            self.device_index, C.byref(self.params), self.B, self.records.data_ptr(), self.state.data_ptr(),
+            actions.data_ptr(), self.obs_internal.data_ptr(), self.obs_external.data_ptr(), self.reward.data_ptr(),
+            self.terminated.data_ptr(), self.truncated.data_ptr(), self.term_internal.data_ptr(),
+            self.term_external.data_ptr(), int(self.max_episode_steps), stream)
+        if rc != 0:
+            raise MpcGpuError(self._lib.mpcgpu_env_last_error().decode())
         obs = self._obs()
-        reward = self.reward.clone()
-        terminated = self.terminated.bool()
-        truncated = (self.state[:, 25] >= self.max_episode_steps) & ~terminated
-        info = {"success": (self.state[:, 7].to(torch.int64) & 4) != 0}
-        if auto_reset:
-            done = terminated | truncated
-            if bool(done.any()):
-                info["terminal_observation"] = obs
-                obs = self._merge(obs, self.reset(done), done)
-        return obs, reward, terminated, truncated, info
+        terminated, truncated = self.terminated.bool(), self.truncated.bool()
+        done = terminated | truncated
+        # state[7] already belongs to the next episode where a reset happened; state[26] keeps this step's flags
+        info = {"success": (self.state[:, 26].to(torch.int64) & 4) != 0,
+                "terminal_observation": {"internal": torch.where(done[:, None], self.term_internal, obs["internal"]),
+                                         "external": torch.where(done[:, None], self.term_external, obs["external"])}}
+        return obs, self.reward.clone(), terminated, truncated, info
 
     def _merge(self, old, new, mask):
         torch = self._torch
