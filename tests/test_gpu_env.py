@@ -225,3 +225,41 @@ def test_degenerate_maps_no_obstacles_and_longest_path():
             assert abs(float(env.path_progress[0]) - o.progress) <= 1e-12
     with pytest.raises(ValueError):
         rl_env.pack_records([dict(m, path=np.zeros((65, 2)))])
+
+
+def test_in_kernel_auto_reset_matches_oracle_reset_semantics():
+    """step(auto_reset=True): the episode bookkeeping done inside the kernel (second observation pass after the reset)
+    against the oracle driven the gym way -- step, and on termination / time limit keep the terminal observation,
+    reset(), continue.  Random actions make the robots collide every few dozen steps."""
+    import torch
+    _, maps = load()
+    m = maps["lhall"]
+    B, LIMIT = 6, 40
+    env = rl_env.BatchedRaysEnv([m] * B, max_episode_steps=LIMIT)
+    oracles = [orc.OracleRaysEnv(m) for _ in range(B)]
+    env.reset()
+    rng = np.random.default_rng(8)
+    steps = np.zeros(B, dtype=int)
+    ended = {"terminated": 0, "truncated": 0}
+    for t in range(150):
+        acts = rng.integers(0, 9, B)
+        acts[0] = 1 if t % 7 else 4                      # robot 0 mostly drives straight: it ends by collision
+        acts[1] = 7                                      # robot 1 brakes / reverses slowly: it ends by the time limit
+        obs, rew, term, trunc, info = env.step(torch.from_numpy(acts), auto_reset=True)
+        for b, o in enumerate(oracles):
+            ob, r, done, oinfo = o.step(int(acts[b]))
+            steps[b] += 1
+            timeout = (not done) and steps[b] >= LIMIT
+            assert bool(term[b]) == done and bool(trunc[b]) == timeout, (t, b)
+            assert abs(float(rew[b]) - r) <= 1e-9
+            assert bool(info["success"][b]) == oinfo["success"]
+            tob = {k: info["terminal_observation"][k][b].cpu().numpy() for k in ("internal", "external")}
+            assert np.abs(tob["internal"] - ob["internal"]).max() <= 1e-6 and np.abs(tob["external"] - ob["external"]).max() <= 2e-6
+            if done or timeout:
+                ended["terminated" if done else "truncated"] += 1
+                ob = o.reset()
+                steps[b] = 0
+            assert np.abs(obs["internal"][b].cpu().numpy() - ob["internal"]).max() <= 1e-6, (t, b)
+            assert np.abs(obs["external"][b].cpu().numpy() - ob["external"]).max() <= 2e-6, (t, b)
+            assert np.abs(env.agent_state[b].cpu().numpy() - o.state).max() <= 1e-12
+    assert ended["terminated"] >= 3 and ended["truncated"] >= 2
