@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MPCGPU_ABI_VERSION 1
+#define MPCGPU_ABI_VERSION 2
 
 /* replaces: the yaml config consumed by MpcModule.build (mpc_generator.py:151-158, config/mpc_default.yaml:7-55)
  * plus the SolverConfiguration of mpc_generator.py:285-293 (opengen defaults quoted there). */
@@ -63,7 +63,9 @@ typedef struct mpcgpu_config {
 /* exit_status codes; names as in config/mpc_default.yaml:54 */
 enum { MPCGPU_CONVERGED = 0, MPCGPU_NOT_CONVERGED_ITERATIONS = 1, MPCGPU_NOT_CONVERGED_OUT_OF_TIME = 2,
        /* OpEn reports this case as an error (SolverError::NotFiniteComputation -> the binding returns None) */
-       MPCGPU_NOT_FINITE_COMPUTATION = 3 };
+       MPCGPU_NOT_FINITE_COMPUTATION = 3,
+       /* not an OpEn status: the problem has more active rows than mpcgpu_reserve_shape promised */
+       MPCGPU_SHAPE_EXCEEDED = 4 };
 
 /* replaces: MpcModule.build + __import__(optimizer_name).solver()  (trajectory_generator.py:63-71) */
 int32_t mpcgpu_create(const mpcgpu_config* cfg, void** handle);
@@ -91,10 +93,16 @@ int32_t mpcgpu_solve_batch(void* handle, int32_t B, const double* p, const doubl
                            const double* c0, double* u, double* cost, int32_t* status, int32_t* inner_it,
                            int32_t* outer_it, double* fpr, double* f2norm, double* y_out, double* ms);
 
-/* Same, DEVICE pointers (e.g. torch tensors' data_ptr()), enqueued on `stream` (hipStream_t; NULL = the
- * handle's own stream).  Contains one small device->host read of the batch's active-obstacle counts, then
- * the solve kernel launch; returns after enqueueing the solve kernel (call hipStreamSynchronize / torch sync
- * before reading results). */
+/* `stream` arguments are raw hipStream_t values and are used as given: NULL is HIP's null stream (which is also
+ * torch's default stream, so a launch on it is ordered with the torch work around it).  This sentinel selects the
+ * handle's own non-blocking stream instead (no ordering with any other stream: synchronise it yourself). */
+#define MPCGPU_STREAM_OWN ((void*)(intptr_t)-1)
+
+/* Same, DEVICE pointers (e.g. torch tensors' data_ptr()), enqueued on `stream` (see MPCGPU_STREAM_OWN).  Returns after
+ * enqueueing the solve kernel (synchronise the stream before reading results).  The LDS carve of the launch is sized
+ * from the batch's active-row maxima: without a reservation (mpcgpu_reserve_shape) this call contains one small
+ * device->host read of those counts and blocks until the compaction kernel has run; with a reservation nothing is
+ * read back, the call never blocks and can be captured into a hipGraph. */
 int32_t mpcgpu_solve_batch_dev(void* handle, int32_t B, const double* p, const double* u0, const double* y0,
                                const double* c0, double* u, double* cost, int32_t* status, int32_t* inner_it,
                                int32_t* outer_it, double* fpr, double* f2norm, double* y_out, double* ms,
@@ -116,13 +124,35 @@ int32_t mpcgpu_last_timing(void* handle, double* prep_ms, double* solve_ms);
 
 /* Work counters of the last solve call, per problem: psi evaluations executed and how many of them also produced
  * grad psi (the counts OpEn's generated `cost` / `grad_cost` functions would see, minus the redundant re-evaluation of
- * psi(u) in the Lipschitz update).  Synchronises `stream` (NULL = the handle's own stream).  HOST output pointers. */
+ * psi(u) in the Lipschitz update).  Synchronises `stream` (the one the solve was enqueued on).  HOST output pointers. */
 int32_t mpcgpu_last_eval_counts(void* handle, int32_t B, int32_t* n_psi, int32_t* n_grad, void* stream);
 
 /* Batch-wide maxima of active entries seen by the last solve / cost_grad call: static obstacles, fleet
  * entries, dynamic-obstacle entries (sizes the LDS carve), and the LDS bytes per wavefront used. */
 int32_t mpcgpu_last_shape(void* handle, int32_t* max_static, int32_t* max_fleet, int32_t* max_dyn,
                           int32_t* lds_bytes);
+
+/*
+ * Promise upper bounds on the ACTIVE (non-zero) static-obstacle, other-robot and dynamic-obstacle rows of every problem
+ * of the following mpcgpu_solve_batch_dev calls, and whether a dynamic row may change (rx, ry, angle, alpha) over the
+ * horizon (var_shape != 0).  The LDS carve is then taken from these bounds instead of a read-back (single-robot callers
+ * of the reference reserve the configured maxima: a lone wavefront does not care about the size of its carve).
+ * A problem that exceeds the reservation is not solved: status = MPCGPU_SHAPE_EXCEEDED, cost = NaN, u = 0.
+ * All three bounds negative = drop the reservation.  Results do not depend on the carve (bitwise).
+ */
+int32_t mpcgpu_reserve_shape(void* handle, int32_t max_static, int32_t max_fleet, int32_t max_dyn, int32_t var_shape);
+
+/*
+ * Solver options that are not part of the reference's yaml / SolverConfiguration surface.  They select between readings
+ * of the OpEn algorithm that cannot be checked against an OpEn build here; the oracle has the same
+ * switch (oracle/mpc_oracle.h: ls_fallback).
+ *   MPCGPU_OPT_LINESEARCH_FALLBACK  what follows 10 line-search halvings without acceptance:
+ *       0 (default)  the last trial point (tau = 2^-10) becomes the iterate -- the effective behaviour of the published
+ *                    PANOC engine, whose `tau = 0; u <- u_half` fallback is overwritten by the copy of u_plus into u
+ *       1            tau = 0: the point u - gamma*fpr is evaluated and taken
+ */
+enum { MPCGPU_OPT_LINESEARCH_FALLBACK = 1 };
+int32_t mpcgpu_set_option(void* handle, int32_t option, double value);
 
 /* Register-allocation variant the last solve call was launched with: 3 (148 VGPRs, no spills) or 4 wavefronts per SIMD
  * (128 VGPRs; chosen when the LDS carve fits 16 times into a CU and the batch exceeds 12 problems per CU).  Both give

@@ -37,7 +37,7 @@ class OracleConfig(C.Structure):
         ("tol", C.c_double), ("delta_tol", C.c_double), ("init_tol", C.c_double),
         ("init_penalty", C.c_double), ("penalty_update", C.c_double), ("tol_update", C.c_double),
         ("suff_decrease", C.c_double),
-        ("max_inner", C.c_int32), ("max_outer", C.c_int32), ("lbfgs_mem", C.c_int32), ("_pad", C.c_int32),
+        ("max_inner", C.c_int32), ("max_outer", C.c_int32), ("lbfgs_mem", C.c_int32), ("ls_fallback", C.c_int32),
         ("max_duration_us", C.c_double),
     ]
 
@@ -45,9 +45,7 @@ class OracleConfig(C.Structure):
     def from_dict(cls, d: dict) -> "OracleConfig":
         cfg = cls()
         for name, _ in cls._fields_:
-            if name == "_pad":
-                continue
-            setattr(cfg, name, d[name])
+            setattr(cfg, name, d.get(name, 0) if name == "ls_fallback" else d[name])
         return cfg
 
 
@@ -91,6 +89,9 @@ def lib():
         L.mpc_oracle_solve.argtypes = [C.POINTER(OracleConfig), dp, dp, dp, C.c_double, dp, dp,
                                        C.POINTER(OracleResult)]
         L.mpc_oracle_solve.restype = C.c_int32
+        L.mpc_oracle_solve_trace.argtypes = [C.POINTER(OracleConfig), dp, dp, dp, C.c_double, dp, dp,
+                                             C.POINTER(OracleResult), dp, C.c_int32, C.POINTER(C.c_int32)]
+        L.mpc_oracle_solve_trace.restype = C.c_int32
         L.mpc_oracle_solve_batch.argtypes = [C.POINTER(OracleConfig), C.c_int32, dp, dp, dp, dp, dp, dp,
                                              C.c_void_p, C.c_int32]
         L.mpc_oracle_solve_batch.restype = C.c_int32
@@ -155,3 +156,22 @@ def solve(cfg: OracleConfig, p, u0=None, y0=None, c0: float = 0.0):
                                None if y0 is None else np.asarray(y0)[None],
                                None if not c0 else np.array([c0]), nthreads=1)
     return u[0], y[0], res[0]
+
+
+TRACE_FIELDS = ("outer", "step", "c", "L", "gamma", "nfpr", "psi_u", "n_lip", "lbfgs_pairs", "n_ls", "tau", "psi_next")
+
+
+def solve_trace(cfg: OracleConfig, p, u0=None, y0=None, c0: float = 0.0, cap: int = 200):
+    """One solve with its decision trace: (u, result record, trace[min(steps, cap), 12], steps).  Fields: TRACE_FIELDS."""
+    n = 2 * cfg.N
+    p = _f64(p, (num_params(cfg),))
+    u0 = None if u0 is None else _f64(u0, (n,))
+    y0 = None if y0 is None else _f64(y0, (n,))
+    u = np.empty(n); y = np.empty(n)
+    res = np.zeros(1, dtype=RESULT_DTYPE)
+    tr = np.full((cap, len(TRACE_FIELDS)), np.nan)
+    steps = C.c_int32()
+    rc = lib().mpc_oracle_solve_trace(C.byref(cfg), _dp(p), _dp(u0), _dp(y0), float(c0), _dp(u), _dp(y),
+                                      C.cast(res.ctypes.data, C.POINTER(OracleResult)), _dp(tr), cap, C.byref(steps))
+    assert rc == 0, rc
+    return u, res[0], tr[:min(steps.value, cap)], steps.value

@@ -427,6 +427,9 @@ typedef struct {
     double tol, akkt_tol;
     struct timespec t0;
     double max_us;
+    /* decision trace (mpc_oracle_solve_trace) */
+    double* trace;
+    int trace_cap, trace_n, outer;
 } panoc_t;
 
 static double elapsed_us(const struct timespec* t0) {
@@ -509,7 +512,7 @@ static int exit_condition(panoc_t* s) {
     return sqrt(r) < s->akkt_tol;
 }
 
-static void update_lipschitz(panoc_t* s, const double* u) {
+static int update_lipschitz(panoc_t* s, const double* u) {
     double cost_half = eval_cost(s, s->u_half);
     /* s->cost already holds psi(u) (the crate re-evaluates it; same value) */
     int it = 0;
@@ -528,6 +531,7 @@ static void update_lipschitz(panoc_t* s, const double* u) {
         ++it;
     }
     s->sigma = (1.0 - GAMMA_L_COEFF) / (4.0 * s->gamma);
+    return it;
 }
 
 static double fbe(const panoc_t* s) {
@@ -543,7 +547,9 @@ static int panoc_step(panoc_t* s, double* u) {
     if (s->iter >= 1) memcpy(s->grad_prev, s->grad, n * sizeof(double));
     compute_fpr(s, u);
     if (exit_condition(s)) return 0;
-    update_lipschitz(s, u);
+    const int n_lip = update_lipschitz(s, u);
+    const double psi_u = s->cost, nfpr_u = s->norm_gfpr;
+    int nls = -1;
     /* L-BFGS: buffer update with (state = u, g = gamma*fpr), direction = H * gfpr */
     lbfgs_update(&s->lb, s->gfpr, u);
     if (s->iter > 0) {
@@ -558,7 +564,7 @@ static int panoc_step(panoc_t* s, double* u) {
     } else {
         s->rhs_ls = fbe(s) - s->sigma * sq(s->norm_gfpr);
         s->tau = 1.0;
-        int nls = 0;
+        nls = 0;
         for (;;) {
             for (int i = 0; i < n; ++i) s->u_plus[i] = u[i] - (1.0 - s->tau) * s->gfpr[i] - s->tau * s->dir[i];
             s->cost = eval_cost_grad(s, s->u_plus, s->grad);
@@ -569,8 +575,26 @@ static int panoc_step(panoc_t* s, double* u) {
             s->tau /= 2.0;
             ++nls;
         }
-        /* after MAX_LINESEARCH_ITERATIONS halvings the last trial point is kept */
+        /* MAX_LINESEARCH_ITERATIONS halvings without acceptance.  ls_fallback = 0: the last trial point (tau = 2^-10) is
+         * the next iterate -- in the published code the `tau = 0; u <- u_half` fallback is immediately overwritten by the
+         * copy of u_plus into u, so this is what it effectively does.  ls_fallback = 1: the fallback as SURVEY.md
+         * Appendix B words it: tau = 0, the point u - gamma*fpr (the half step of u) is evaluated and taken. */
+        if (s->cfg->ls_fallback == 1 && s->lhs_ls > s->rhs_ls) {
+            s->tau = 0.0;
+            for (int i = 0; i < n; ++i) s->u_plus[i] = u[i] - s->gfpr[i];
+            s->cost = eval_cost_grad(s, s->u_plus, s->grad);
+            for (int i = 0; i < n; ++i) s->gstep[i] = s->u_plus[i] - s->gamma * s->grad[i];
+            half_step(s);
+        }
         memcpy(u, s->u_plus, n * sizeof(double));
+    }
+    if (s->trace) {
+        if (s->trace_n < s->trace_cap) {
+            double* r = s->trace + (size_t)s->trace_n * MPC_ORACLE_TRACE_FIELDS;
+            r[0] = s->outer; r[1] = s->iter; r[2] = s->c; r[3] = s->L; r[4] = s->gamma; r[5] = nfpr_u; r[6] = psi_u;
+            r[7] = n_lip; r[8] = s->lb.active; r[9] = nls; r[10] = s->tau; r[11] = s->cost;
+        }
+        s->trace_n++;
     }
     s->iter++;
     return 1;
@@ -597,8 +621,9 @@ static int panoc_solve(panoc_t* s, double* u, int max_iter, int* iters) {
 /* ------------------------------------------------------------------------------------------ */
 /* [OpEn] ALM / penalty-method outer loop                                                      */
 /* ------------------------------------------------------------------------------------------ */
-int32_t mpc_oracle_solve(const mpc_oracle_config* cfg, const double* p, const double* u0, const double* y0,
-                         double c0, double* u_out, double* y_out, mpc_oracle_result* res) {
+static int32_t solve_impl(const mpc_oracle_config* cfg, const double* p, const double* u0, const double* y0,
+                          double c0, double* u_out, double* y_out, mpc_oracle_result* res, double* trace,
+                          int32_t cap, int32_t* n_steps) {
     const int N = cfg->N, n = 2 * N, n1 = 2 * N, n2 = cfg->Ndynobs;
     if (N > NMAX || N < 1 || cfg->lbfgs_mem > MEM_MAX || cfg->lbfgs_mem < 1 || n2 > NDYN_MAX) return -1;
     const double SMALL_EPSILON = DBL_EPSILON;
@@ -608,6 +633,7 @@ int32_t mpc_oracle_solve(const mpc_oracle_config* cfg, const double* p, const do
     s->lb.n = n; s->lb.mem = cfg->lbfgs_mem;
     s->tol = cfg->tol;
     s->max_us = cfg->max_duration_us;
+    s->trace = trace; s->trace_cap = cap; s->trace_n = 0;
     clock_gettime(CLOCK_MONOTONIC, &s->t0);
 
     double u[NU_MAX], y[NU_MAX], y_plus[NU_MAX], F1[NU_MAX], F2[NDYN_MAX];
@@ -627,6 +653,7 @@ int32_t mpc_oracle_solve(const mpc_oracle_config* cfg, const double* p, const do
         /* y <- Proj_Y(y), Y = [-1e12, 1e12]^n1 */
         for (int i = 0; i < n1; ++i) y[i] = fmin(fmax(y[i], -1e12), 1e12);
         s->c = c;
+        s->outer = outer;
         int it = 0;
         const int inner_status = panoc_solve(s, u, cfg->max_inner, &it);
         inner_total += it;
@@ -682,8 +709,20 @@ int32_t mpc_oracle_solve(const mpc_oracle_config* cfg, const double* p, const do
         res->n_grad_evals = s->n_grad;
         res->_pad = 0;
     }
+    if (n_steps) *n_steps = s->trace_n;
     free(s);
     return 0;
+}
+
+int32_t mpc_oracle_solve(const mpc_oracle_config* cfg, const double* p, const double* u0, const double* y0,
+                         double c0, double* u_out, double* y_out, mpc_oracle_result* res) {
+    return solve_impl(cfg, p, u0, y0, c0, u_out, y_out, res, NULL, 0, NULL);
+}
+
+int32_t mpc_oracle_solve_trace(const mpc_oracle_config* cfg, const double* p, const double* u0, const double* y0,
+                               double c0, double* u_out, double* y_out, mpc_oracle_result* res, double* trace,
+                               int32_t cap, int32_t* n_steps) {
+    return solve_impl(cfg, p, u0, y0, c0, u_out, y_out, res, trace, cap, n_steps);
 }
 
 int32_t mpc_oracle_solve_batch(const mpc_oracle_config* cfg, int32_t B, const double* p, const double* u0,

@@ -53,7 +53,9 @@ typedef struct mpc_oracle_config {
     int32_t max_inner;     /* 500 */
     int32_t max_outer;     /* 10  */
     int32_t lbfgs_mem;     /* 10  */
-    int32_t _pad;
+    int32_t ls_fallback;   /* line search that fails 10 halvings: 0 = the last trial point (tau = 2^-10) is the next iterate
+                              [what the published code does: its tau = 0 copy is overwritten by the u_plus swap];
+                              1 = tau = 0, i.e. u - gamma*fpr is evaluated and taken */
     double max_duration_us; /* 5e6; <=0 disables the wall-clock test */
 } mpc_oracle_config;
 
@@ -92,6 +94,20 @@ typedef struct mpc_oracle_result {
 /* One solve. u0 / y0 may be NULL (zeros); c0 <= 0 means cfg->init_penalty. y_out may be NULL. */
 int32_t mpc_oracle_solve(const mpc_oracle_config* cfg, const double* p, const double* u0, const double* y0,
                          double c0, double* u_out, double* y_out, mpc_oracle_result* res);
+
+/*
+ * Decision trace of one solve (test infrastructure for the GPU kernel's trace build): one record of
+ * MPC_ORACLE_TRACE_FIELDS doubles per completed PANOC step, across all inner problems, first `cap` steps:
+ *   0 outer index   1 step index inside the inner problem   2 penalty c   3 Lipschitz estimate L (after back-tracking)
+ *   4 gamma         5 ||gamma*fpr|| at u                    6 psi(u)      7 Lipschitz doublings in this step
+ *   8 L-BFGS pairs held after the buffer update             9 line-search halvings (-1: first step, no line search)
+ *   10 accepted tau (1 on the first step; 0 after the fallback of ls_fallback = 1)          11 psi(u_next)
+ * Returns the number of PANOC steps taken (may exceed cap) in *n_steps.
+ */
+#define MPC_ORACLE_TRACE_FIELDS 12
+int32_t mpc_oracle_solve_trace(const mpc_oracle_config* cfg, const double* p, const double* u0, const double* y0,
+                               double c0, double* u_out, double* y_out, mpc_oracle_result* res, double* trace,
+                               int32_t cap, int32_t* n_steps);
 
 /* B independent solves, OpenMP over the batch with `nthreads` threads (<=0: all).  Returns threads used. */
 int32_t mpc_oracle_solve_batch(const mpc_oracle_config* cfg, int32_t B, const double* p, const double* u0,

@@ -1,0 +1,54 @@
+"""CPU: `python bench.py --gpus N` run DIRECTLY (no launcher, WORLD_SIZE unset) must start N rank processes itself
+(one per GPU on a real node), reduce over them and report n_gpus = N; a mismatch between --gpus and WORLD_SIZE, or too
+few devices, must fail loudly.  The solver is stubbed (MPCGPU_BENCH_STUB=1, gloo) -- this tests the launch and reduction
+plumbing only; the JSON line says data = "stub"."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(kw)
+    return env
+
+
+def test_bench_self_launches_two_ranks_when_run_without_a_launcher():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--batch", "64", "--cpu-seconds", "0"],
+                       env=_env(MPCGPU_BENCH_BACKEND="gloo", MPCGPU_BENCH_STUB="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                             # rank 0 only
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["data"] == "stub"
+    assert len(line["per_rank_solves_per_s"]) == 2
+    assert line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak"
+    # whole-job value = all ranks' problems / max-over-ranks time
+    assert abs(line["value"] - 2 * 64 * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["value"]
+    assert line["value"] <= sum(line["per_rank_solves_per_s"]) * (1 + 1e-9)
+    assert line["config"]["convergent"]["value"] > 0
+    assert "roofline" not in line and "cpu_baseline" not in line  # the stub measures nothing
+
+
+def test_bench_refuses_a_world_size_that_disagrees_with_gpus():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--batch", "8"],
+                       env=_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MPCGPU_BENCH_STUB="1"), capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--batch", "8"],
+                       env=_env(WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MPCGPU_BENCH_STUB="1"), capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_bench_exits_non_zero_when_fewer_devices_than_gpus():
+    import torch
+    have = torch.cuda.device_count()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(have + 2), "--batch", "8"],
+                       env=_env(), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "GPU(s) visible" in r.stderr

@@ -78,6 +78,19 @@ def test_rect_halfspaces_match_reference_representation():
     assert key(mine) == key(ref)
 
 
+def test_polygon_halfspace_representation_matches_all_reference_fixtures_in_row_order():
+    """a17: every one of the 16 (polygon -> b, a0, a1) pairs produced by the reference's own function; the ROW ORDER is
+    part of the layout (`update_static_constraints` writes b + a0 + a1 in facet order, interface_mpc.py:60-63)."""
+    from trajtrack_mpcndqn_rlboost_amd import geometry
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "halfspace.npz"))
+    assert len(fx["polygons"]) == 16
+    for poly, ref in zip(fx["polygons"], fx["b_a0_a1"]):
+        b, a0, a1 = geometry.polygon_halfspace_representation(poly)
+        mine = np.stack([b, a0, a1])
+        assert mine.shape == ref.shape
+        assert np.max(np.abs(mine - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref)))
+
+
 def _declared_symbols():
     text = open(os.path.join(ROOT, "include", "mpcgpu.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
@@ -93,7 +106,21 @@ def test_c_abi_library_exports_every_declared_symbol():
     for sym in declared:
         assert hasattr(lib, sym), sym
     lib.mpcgpu_abi_version.restype = ctypes.c_int32
-    assert lib.mpcgpu_abi_version() == 1
+    assert lib.mpcgpu_abi_version() == 2
+
+
+def test_variant_builds_export_the_abi_and_their_debug_hooks():
+    """Test-only builds (csrc/Makefile `variants`, compiled by __graft_entry__.build()): same C-ABI; the trace build adds
+    its two debug entry points, the product library must not carry them."""
+    prod = ctypes.CDLL(solver_mod.library_path())
+    assert not hasattr(prod, "mpcgpu_debug_set_trace") and not hasattr(prod, "mpcgpu_debug_read_trace")
+    for name in ("trace", "lbfgs_lds"):
+        path = solver_mod.variant_path(name)
+        assert os.path.exists(path), f"{path} missing -- run __graft_entry__.build()"
+        lib = ctypes.CDLL(path)
+        for sym in _declared_symbols():
+            assert hasattr(lib, sym), (name, sym)
+        assert hasattr(lib, "mpcgpu_debug_set_trace") == (name == "trace")
 
 
 def test_c_struct_layout_matches_header():

@@ -6,9 +6,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from trajtrack_mpcndqn_rlboost_amd import MpcConfig, BatchSolver, scenes
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-cfg = MpcConfig()
+NH = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+cfg = MpcConfig(N_hor=NH)
 bs = BatchSolver(cfg)
 sc = scenes.make_batch(cfg, B, n_dyn=8, seed=1236)
+print(f"N_hor {NH}  B {B}  8 dynamic obstacles (benchmark scene family)")
 res = bs.solve(sc["p"])
 out = (C.c_double * 24)()
 bs._L.mpcgpu_debug_read_prof.argtypes = [C.POINTER(C.c_double)]

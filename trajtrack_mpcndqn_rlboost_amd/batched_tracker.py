@@ -3,9 +3,11 @@
 The single-robot harness of the reference (``src/mpc_traj_tracker/trajectory_generator.py:235-339``,
 ``src/interface_mpc.py:16-88``) is applied to every robot, but the parameter vectors are stacked into one
 ``[B, np]`` array and solved by ONE call of the batched C-ABI entry point; the post-solve rollouts are vectorised.
-Robots are independent within a tick.  Fleet coupling uses the previous tick's predictions for every robot
-(Jacobi), whereas the reference's sequential loop (``src/scenario_simulator.py:226-233``) lets robot j see robot
-i < j's fresh prediction (Gauss-Seidel) -- a documented difference for B > 1 fleets.
+Robots are independent within a tick.  Fleet coupling comes in two forms: ``step()`` uses the previous tick's
+predictions for every robot (Jacobi: ONE solve per tick); ``step(groups=...)`` reproduces the reference's sequential
+loop (``src/scenario_simulator.py:226-233``: robot j sees the FRESH prediction of every robot i < j of its world --
+Gauss-Seidel) colour by colour: the robots at position c of every group are independent of each other, so a tick of
+G worlds x R robots is R batched solves of G problems.
 """
 from __future__ import annotations
 
@@ -153,36 +155,81 @@ class BatchedTracker:
         P[:, off["qdyn"]:off["qdyn"] + N] = self.dyn_weights
         return P
 
-    def step(self, mode: str = "work", initial_guess: Optional[np.ndarray] = None, refs: Optional[np.ndarray] = None):
+    def step(self, mode: str = "work", initial_guess: Optional[np.ndarray] = None, refs: Optional[np.ndarray] = None,
+             groups: Optional[Sequence[Sequence[int]]] = None):
         """Solve all robots, apply the first ``action_steps`` inputs.  Returns (actions [B, nu], pred_states
         [B, N, ns], cost [B]); robots that already reached their goal keep their state (action 0).
         ``refs`` [B, N, 3]: the reference each robot tracks this tick (``get_action(current_ref_traj)``,
-        ``interface_mpc.py:82-88``); default: the local window of its global reference."""
+        ``interface_mpc.py:82-88``); default: the local window of its global reference.
+        ``groups``: lists of mutually coupled robots (the robots of one world, in the reference's dictionary order).
+        Given, the tick is solved Gauss-Seidel like the reference's loop (``scenario_simulator.py:226-233``): colour c =
+        the c-th robot of every group; before colour c is solved its other-robot blocks are refreshed with the
+        predictions colours < c have just produced (and last tick's for colours > c).  Not given: one solve for the
+        whole batch with whatever ``other_robot_states`` holds (Jacobi when fed by ``share_predictions``)."""
         cfg = self.config
         near = np.all(np.abs(self.states[:, :2] - self.goals[:, :2]) <= 0.05, axis=1)
         self.active &= ~(near & (np.abs(self.last_actions[:, 0]) < 0.05))     # check_termination_condition
-        P = self.assemble(mode, refs)
         if initial_guess is None and self.warm_start and self.last_result is not None:
             # receding-horizon warm start (what OpEn's TCP server does with its cached solution): previous plan
             # shifted by the inputs already applied, last input repeated
             prev = self.last_result.solution.reshape(self.B, cfg.N_hor, cfg.nu)
             k = cfg.action_steps
             initial_guess = np.concatenate([prev[:, k:], np.repeat(prev[:, -1:], k, axis=1)], axis=1).reshape(self.B, -1)
-        res = self.solver.solve(P, initial_guess)
-        self.last_result = res
-        u = res.solution.reshape(self.B, cfg.N_hor, cfg.nu)
-        state = self.states.copy()
+        if groups is None:
+            P = self.assemble(mode, refs)
+            res = self.solver.solve(P, initial_guess)
+            self.last_result = res
+            actions = self._apply(np.arange(self.B), res.solution)
+            return actions, self.pred_states.copy(), res.cost
+        # ---- Gauss-Seidel over colours
+        if refs is None:
+            refs = self.local_refs()        # a robot's window depends on its own state only: taken once, up front
+        covered = np.sort(np.concatenate([np.asarray(g, dtype=np.int64) for g in groups])) if len(groups) else np.array([])
+        if not np.array_equal(covered, np.arange(self.B)):
+            raise ValueError("groups must partition the robots 0..B-1")
+        actions = np.zeros((self.B, cfg.nu))
+        parts = []
+        for c in range(max(len(g) for g in groups)):
+            idx = np.array([g[c] for g in groups if len(g) > c], dtype=np.int64)
+            self.share_predictions(groups)
+            P = self.assemble(mode, refs)
+            res = self.solver.solve(P[idx], None if initial_guess is None else initial_guess[idx])
+            actions[idx] = self._apply(idx, res.solution)
+            parts.append((idx, res))
+        self.last_result = _merge_results(self.B, parts)
+        return actions, self.pred_states.copy(), self.last_result.cost
+
+    def _apply(self, idx: np.ndarray, solution: np.ndarray) -> np.ndarray:
+        """Post-solve part of ``run_step`` for the robots ``idx`` (``trajectory_generator.py:325-339``): advance by the
+        first ``action_steps`` inputs, roll the prediction out; returns their applied first actions."""
+        cfg = self.config
+        u = solution.reshape(len(idx), cfg.N_hor, cfg.nu)
+        state = self.states[idx].copy()
         for s in range(cfg.action_steps):
             state = unicycle_model(state, u[:, s], cfg.ts)
-        pred = np.empty((self.B, cfg.N_hor, cfg.ns))
+        pred = np.empty((len(idx), cfg.N_hor, cfg.ns))
         rolling = state
         for k in range(cfg.N_hor):                      # rolled from the taken state, re-applying u[0] (reference quirk)
             rolling = unicycle_model(rolling, u[:, k], cfg.ts)
             pred[:, k] = rolling
-        act = self.active
-        self.states[act] = state[act]
-        self.last_actions[act] = u[act, cfg.action_steps - 1]
-        self.last_actions[~act] = 0.0
-        self.pred_states[act] = pred[act]
-        actions = np.where(act[:, None], u[:, 0], 0.0)
-        return actions, self.pred_states.copy(), res.cost
+        act = self.active[idx]
+        on, off = idx[act], idx[~act]
+        self.states[on] = state[act]
+        self.last_actions[on] = u[act, cfg.action_steps - 1]
+        self.last_actions[off] = 0.0
+        self.pred_states[on] = pred[act]
+        return np.where(act[:, None], u[:, 0], 0.0)
+
+
+def _merge_results(B: int, parts) -> BatchResult:
+    """One BatchResult for the whole fleet from the per-colour results."""
+    first = parts[0][1]
+    fields = {}
+    for name in ("solution", "cost", "status", "num_inner_iterations", "num_outer_iterations", "last_problem_norm_fpr",
+                 "f2_norm", "lagrange_multipliers", "solve_time_ms"):
+        proto = getattr(first, name)
+        full = np.zeros((B,) + proto.shape[1:], dtype=proto.dtype)
+        for idx, res in parts:
+            full[idx] = getattr(res, name)
+        fields[name] = full
+    return BatchResult(**fields)

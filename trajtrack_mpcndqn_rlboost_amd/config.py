@@ -28,6 +28,10 @@ SOLVER_DEFAULTS: Dict[str, Any] = dict(
     solver_lbfgs_memory=10,
     solver_max_duration_micros=5_000_000,  # MAX_SOVLER_TIME, mpc_generator.py:22
     fleet_weight=1000.0,                 # weight=1000, mpc_generator.py:216
+    # What follows 10 line-search halvings without acceptance [OpEn; cannot be checked against an OpEn build here]:
+    # 'last_trial' = the tau = 2^-10 trial point becomes the iterate (effective behaviour of the published engine),
+    # 'half_step'  = tau = 0, the point u - gamma*fpr is evaluated and taken.  DESIGN.md section 3.
+    solver_linesearch_fallback="last_trial",
 )
 
 REQUIRED_KEYS = ("ts", "N_hor", "nu", "ns", "nq", "Nother", "Nstcobs", "nstcobs", "Ndynobs", "ndynobs",
@@ -103,7 +107,8 @@ class MpcConfig:
             suff_decrease=float(self.solver_sufficient_decrease),
             max_inner=int(self.solver_max_inner_iterations), max_outer=int(self.solver_max_outer_iterations),
             lbfgs_mem=int(self.solver_lbfgs_memory), device=int(device),
-            max_duration_us=float(self.solver_max_duration_micros))
+            max_duration_us=float(self.solver_max_duration_micros),
+            ls_fallback=1 if self.solver_linesearch_fallback == "half_step" else 0)
 
 
 # The reference's class name (src/util/mpc_config.py:8): same constructor, same attribute semantics.

@@ -67,13 +67,15 @@ constexpr int SEG_WIN = 2;     // reference segments per item lane that are eval
 // header slots (doubles); 0..17 are p[0..17] of the reference layout
 enum { H_X0 = 0, H_Y0 = 1, H_TH0 = 2, H_XG = 3, H_YG = 4, H_THG = 5, H_VINIT = 6, H_WINIT = 7, H_QVEL = 9, H_RV = 11, H_RW = 12,
        H_QN = 13, H_QTHN = 14, H_QRPD = 15, H_ACC = 16, H_WACC = 17 };
-enum { H_KS = 18, H_KF = 19, H_KD = 20, H_CTH0 = 21, H_STH0 = 22, H_NPF = 23, H_NPD = 24, H_ENTRY = 26 /* .. +Ndynobs */ };
+enum { H_KS = 18, H_KF = 19, H_KD = 20, H_CTH0 = 21, H_STH0 = 22, H_NPF = 23, H_NPD = 24, H_VAR = 25 /* 1: some dynamic row changes shape over the horizon */,
+       H_ENTRY = 26 /* .. +Ndynobs */ };
 // batch-wide reductions written by the compaction kernel
 enum { CNT_KS = 0, CNT_KF = 1, CNT_KD = 2, CNT_VARSHAPE = 3 };
 
 struct KParams {
     int N, Nother, Nstcobs, Ndynobs, np, mem;
     int max_inner, max_outer;
+    int ls_fallback;  // line search without acceptance after 10 halvings: 0 = keep the last trial point, 1 = tau = 0
     double ts, inv_ts;
     double vmin, vmax, wmax, amin, amax, aamax;
     double W2, social, fleetw;
@@ -85,6 +87,7 @@ struct KParams {
     int ws_stride, ws_vref, ws_seg, ws_segc, ws_stc, ws_fxy, ws_dyn, ws_qd, ws_alpha, ws_lbs, ws_lby, ws_lold;
     // LDS layout (doubles), strides use the batch maxima mKs/mKf/mKd
     int mKs, mKf, mKd;
+    int reserved;  // 1: the carve comes from mpcgpu_reserve_shape, problems are checked against it on the device
     int l_seg, l_stc, l_fxy, l_dyn, l_dync, l_qd, l_pos, l_H, l_W, l_part, l_stash, l_hd, l_S, l_Y, l_rho, l_alpha, l_old, l_total;
 };
 
@@ -101,7 +104,10 @@ struct BatchPtrs {
     double* fpr; double* f2norm; double* y_out; double* ms;
     double* ws; int* counts;
     int32_t* evals;  // [B][2] psi evaluations / of those with gradient (library-owned; read by mpcgpu_last_eval_counts)
+    double* trace;   // -DMPC_TRACE builds only: [B][trace_cap][TRACE_W] decision trace, one record per PANOC step
+    int trace_cap;
 };
+constexpr int TRACE_W = 12;  // outer, step, c, L, gamma, ||gamma fpr||, psi(u), Lipschitz doublings, L-BFGS pairs, halvings, tau, psi(u+)
 
 // ------------------------------------------------------------------------------------------------
 // wave primitives on DPP (data-parallel primitives: cross-lane operands inside VALU instructions, no LDS
@@ -374,7 +380,7 @@ __global__ __launch_bounds__(WAVE) void prep_kernel(KParams kp, BatchPtrs io, in
     }
     const bool any_var = __ballot(varshape) != 0ull;
     if (lane == 0) {
-        ws[H_KS] = (double)Ks; ws[H_KF] = (double)Kf; ws[H_KD] = (double)Kd;
+        ws[H_KS] = (double)Ks; ws[H_KF] = (double)Kf; ws[H_KD] = (double)Kd; ws[H_VAR] = any_var ? 1.0 : 0.0;
         atomicMax(io.counts + CNT_KS, Ks);
         atomicMax(io.counts + CNT_KF, Kf);
         atomicMax(io.counts + CNT_KD, Kd);
@@ -873,6 +879,22 @@ __global__ __launch_bounds__(WAVE, MINW) void solve_kernel_pair(KParams kp, Batc
     const int lane = threadIdx.x, N = NT ? NT : kp.N, mem = kp.mem;
     constexpr int RV = Dim<NT>::ROWS_V;
     const double* ws = io.ws + (size_t)b * kp.ws_stride;
+    // Launches with a RESERVED LDS carve (mpcgpu_reserve_shape: no count read-back before the launch) check every problem
+    // against it: a problem with more active rows than reserved must not touch the tables -- it is reported, not solved.
+    if (kp.reserved) {
+        const bool over = (int)uniform(ws[H_KS]) > kp.mKs || (int)uniform(ws[H_KF]) > kp.mKf || (int)uniform(ws[H_KD]) > kp.mKd ||
+                          (SC && uniform(ws[H_VAR]) != 0.0);
+        if (over) {
+            if (lane < N) { io.u[(size_t)b * 2 * N + 2 * lane] = 0.0; io.u[(size_t)b * 2 * N + 2 * lane + 1] = 0.0; }
+            if (lane == 0) {
+                io.cost[b] = __builtin_nan(""); io.status[b] = 4;
+                if (io.inner_it) io.inner_it[b] = 0;
+                if (io.outer_it) io.outer_it[b] = 0;
+                if (io.evals) { io.evals[2 * b] = 0; io.evals[2 * b + 1] = 0; }
+            }
+            return;
+        }
+    }
     Ctx cx;
     load_problem<NT, SC>(kp, ws, lds, cx);
     // L-BFGS memory S, Y [mem][N][2]: in LDS (LBG = false) or in this problem's workspace record, i.e. in the
@@ -926,6 +948,18 @@ __global__ __launch_bounds__(WAVE, MINW) void solve_kernel_pair(KParams kp, Batc
     double dy_norm = 0, dy_norm_plus = 0, f2_norm = 0, f2_norm_plus = 0, last_fpr = 0, f_final = 0;
 
     int n_eval = 0, n_eval_grad = 0;
+#ifdef MPC_TRACE
+    int tr_n = 0;
+    double tr_psi_u = 0.0;
+    auto tr_write = [&](int nls_, double tau_) {
+        if (lane == 0 && io.trace && tr_n < io.trace_cap) {
+            double* r = io.trace + ((size_t)b * io.trace_cap + tr_n) * TRACE_W;
+            r[0] = alm_iteration; r[1] = iter; r[2] = c; r[3] = Lip; r[4] = gamma; r[5] = nfpr; r[6] = tr_psi_u;
+            r[7] = lip_it; r[8] = lb_active; r[9] = nls_; r[10] = tau_; r[11] = cost;
+        }
+        ++tr_n;
+    };
+#endif
     int state = ST_INIT0;
     double ev = uv, ew = uw;  // evaluation point
     bool want_grad = true;
@@ -981,6 +1015,9 @@ __global__ __launch_bounds__(WAVE, MINW) void solve_kernel_pair(KParams kp, Batc
                 continue;
             }
             sigma = uniform(KC(K_SIGMA) / gamma);
+#ifdef MPC_TRACE
+            tr_psi_u = cost;
+#endif
             // ---- L-BFGS buffer update with (state = u, g = gamma*fpr)   [crate lbfgs: C-BFGS acceptance]
             if (lb_first) {
                 lb_first = false;
@@ -1069,6 +1106,9 @@ __global__ __launch_bounds__(WAVE, MINW) void solve_kernel_pair(KParams kp, Batc
             cost = uniform(o.psi); gv = o.gv; gw = o.gw;
             gg = dot2r<RV>(gv, gw, gv, gw);
             d2h = half_step(uv, uw);
+#ifdef MPC_TRACE
+            tr_write(-1, 1.0);
+#endif
             ++iter;
             step_begin = true;
         } else if (state == ST_LS) {
@@ -1083,7 +1123,19 @@ __global__ __launch_bounds__(WAVE, MINW) void solve_kernel_pair(KParams kp, Batc
                 want_grad = true;
                 continue;
             }
-            uv = ev; uw = ew;  // after MAX_LS_IT halvings the last trial point is kept
+            // MAX_LS_IT halvings without acceptance.  ls_fallback = 0: the last trial point (tau = 2^-10) is the next
+            // iterate (what the published code effectively does); ls_fallback = 1: tau = 0, the
+            // point u - gamma*fpr is evaluated and taken unconditionally.
+            if (kp.ls_fallback == 1 && lhs > rhs && tau != 0.0) {
+                tau = 0.0;
+                ev = uv - rv_; ew = uw - rw_;
+                want_grad = true;
+                continue;
+            }
+            uv = ev; uw = ew;
+#ifdef MPC_TRACE
+            tr_write(nls, tau);
+#endif
             ++iter;
             step_begin = true;
         } else {  // ST_OUTER: evaluated at the inner solution (c, y still those of the inner problem)

@@ -33,13 +33,18 @@ struct Handle {
     bool timing_valid = false;
     std::string err;
     // grow-only device buffers
-    DevBuf ws, counts, evals, p, u0, y0, c0, u, cost, status, inner, outer, fpr, f2, y, ms, xi, psi, f, grad, F1, F2;
+    DevBuf ws, counts, evals, trace, p, u0, y0, c0, u, cost, status, inner, outer, fpr, f2, y, ms, xi, psi, f, grad, F1, F2;
     int* h_counts = nullptr;  // pinned
     int last_shape[4] = {0, 0, 0, 0};
     int last_B = 0;  // batch size of the last solve (for mpcgpu_last_eval_counts)
     bool shape_const = true;  // of the batch prepared last
     int last_min_waves = 0;   // launch-bounds variant of the last solve (3 or 4 wavefronts per SIMD)
     int num_cus = 256;
+    int trace_cap = 0;  // -DMPC_TRACE builds: PANOC steps recorded per problem (0 = tracing off)
+    // mpcgpu_reserve_shape: upper bounds of active rows promised by the caller -> no count read-back before the launch
+    bool capturing = false;  // the launch stream of the current call is being captured into a hipGraph: no event records
+    bool reserved = false;
+    int res_shape[4] = {0, 0, 0, 0};  // max static, fleet, dynamic rows; 1 = dynamic rows may change shape over the horizon
 };
 
 int fail(Handle* h, int code, const char* fmt, ...) {
@@ -58,13 +63,25 @@ int fail(Handle* h, int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail(h, -10, "%s failed: %s", #call, hipGetErrorString(e_));       \
     } while (0)
 
+// Grow-only buffer.  A buffer that must grow may still be read by work enqueued earlier on ANY stream the caller used
+// with this handle, so the device is drained before the old allocation is released (hipFree would do so implicitly; it is
+// spelled out because correctness depends on it).  Growth is geometric, so steady-state calls never get here.
 int ensure(Handle* h, DevBuf& b, size_t bytes) {
     if (bytes <= b.cap) return 0;
-    if (b.ptr) HIP_OK(h, hipFree(b.ptr));
-    b.ptr = nullptr; b.cap = 0;
-    HIP_OK(h, hipMalloc(&b.ptr, bytes));
-    b.cap = bytes;
+    if (b.ptr) {
+        HIP_OK(h, hipDeviceSynchronize());
+        HIP_OK(h, hipFree(b.ptr));
+    }
+    b.ptr = nullptr;
+    const size_t want = bytes > b.cap + b.cap / 2 ? bytes : b.cap + b.cap / 2;
+    b.cap = 0;
+    HIP_OK(h, hipMalloc(&b.ptr, want));
+    b.cap = want;
     return 0;
+}
+
+inline hipStream_t pick_stream(Handle* h, void* stream) {
+    return stream == MPCGPU_STREAM_OWN ? h->stream : (hipStream_t)stream;
 }
 
 inline int even(int x) { return (x + 1) & ~1; }
@@ -86,6 +103,7 @@ void fill_static_params(Handle* h) {
     k.N = N;
     k.Nother = c.Nother; k.Nstcobs = c.Nstcobs; k.Ndynobs = c.Ndynobs; k.mem = c.lbfgs_mem;
     k.max_inner = c.max_inner; k.max_outer = c.max_outer;
+    k.ls_fallback = 0;
     k.ts = c.ts; k.inv_ts = 1.0 / c.ts;
     k.vmin = c.lin_vel_min; k.vmax = c.lin_vel_max; k.wmax = c.ang_vel_max;
     k.amin = c.lin_acc_min; k.amax = c.lin_acc_max; k.aamax = c.ang_acc_max;
@@ -155,22 +173,35 @@ void fill_lds_layout(KParams& k, int mKs, int mKf, int mKd, bool shape_const, bo
     k.l_total = o;
 }
 
-// compaction kernel + count read-back + LDS layout.  Leaves kp ready for a launch on `s`.
-int prepare(Handle* h, int B, const double* d_p, hipStream_t s, BatchPtrs& io) {
+// compaction kernel + LDS layout (from the reserved shape, or from a blocking read-back of the batch's active-row
+// maxima).  Leaves kp ready for a launch on `s`.
+int prepare(Handle* h, int B, const double* d_p, hipStream_t s, BatchPtrs& io, bool allow_reserved) {
     if (int r = ensure(h, h->ws, (size_t)B * h->kp.ws_stride * sizeof(double))) return r;
     if (int r = ensure(h, h->counts, 4 * sizeof(int))) return r;
     io.p = d_p;
     io.ws = (double*)h->ws.ptr;
     io.counts = (int*)h->counts.ptr;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap);
+    h->capturing = cap != hipStreamCaptureStatusNone;
     HIP_OK(h, hipMemsetAsync(io.counts, 0, 4 * sizeof(int), s));
-    HIP_OK(h, hipEventRecord(h->ev[0], s));
+    if (!h->capturing) HIP_OK(h, hipEventRecord(h->ev[0], s));
     hipLaunchKernelGGL(prep_kernel, dim3(B), dim3(WAVE), 0, s, h->kp, io, B);
     HIP_OK(h, hipGetLastError());
-    HIP_OK(h, hipEventRecord(h->ev[1], s));
-    HIP_OK(h, hipMemcpyAsync(h->h_counts, io.counts, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
-    HIP_OK(h, hipStreamSynchronize(s));
-    const int mKs = h->h_counts[CNT_KS], mKf = h->h_counts[CNT_KF], mKd = h->h_counts[CNT_KD];
-    h->shape_const = h->h_counts[CNT_VARSHAPE] == 0;
+    if (!h->capturing) HIP_OK(h, hipEventRecord(h->ev[1], s));
+    int mKs, mKf, mKd;
+    if (allow_reserved && h->reserved) {
+        mKs = h->res_shape[0]; mKf = h->res_shape[1]; mKd = h->res_shape[2];
+        h->shape_const = h->res_shape[3] == 0;
+        h->kp.reserved = 1;
+    } else {
+        if (h->capturing) return fail(h, -6, "stream capture needs mpcgpu_reserve_shape: the automatic LDS carve reads the batch's row counts back");
+        HIP_OK(h, hipMemcpyAsync(h->h_counts, io.counts, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_OK(h, hipStreamSynchronize(s));
+        mKs = h->h_counts[CNT_KS]; mKf = h->h_counts[CNT_KF]; mKd = h->h_counts[CNT_KD];
+        h->shape_const = h->h_counts[CNT_VARSHAPE] == 0;
+        h->kp.reserved = 0;
+    }
     fill_lds_layout(h->kp, mKs, mKf, mKd, h->shape_const, !LBFGS_IN_WORKSPACE);
     const int lds_bytes = h->kp.l_total * (int)sizeof(double);
     h->last_shape[0] = mKs; h->last_shape[1] = mKf; h->last_shape[2] = mKd; h->last_shape[3] = lds_bytes;
@@ -241,7 +272,7 @@ void mpcgpu_destroy(void* handle) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf* bufs[] = {&h->ws, &h->counts, &h->evals, &h->p, &h->u0, &h->y0, &h->c0, &h->u, &h->cost, &h->status, &h->inner,
+    DevBuf* bufs[] = {&h->ws, &h->counts, &h->evals, &h->trace, &h->p, &h->u0, &h->y0, &h->c0, &h->u, &h->cost, &h->status, &h->inner,
                       &h->outer, &h->fpr, &h->f2, &h->y, &h->ms, &h->xi, &h->psi, &h->f, &h->grad, &h->F1, &h->F2};
     for (DevBuf* b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
@@ -272,15 +303,24 @@ int32_t mpcgpu_solve_batch_dev(void* handle, int32_t B, const double* p, const d
     if (B == 0) return 0;
     if (!p || !u || !cost || !status) return fail(h, -1, "p, u, cost and status must not be NULL");
     HIP_OK(h, hipSetDevice(h->device));
-    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    hipStream_t s = pick_stream(h, stream);
     BatchPtrs io{};
-    if (int r = prepare(h, B, p, s, io)) return r;
+    if (int r = prepare(h, B, p, s, io, true)) return r;
     io.u0 = u0; io.y0 = y0; io.c0 = c0; io.u = u; io.cost = cost; io.status = status; io.inner_it = inner_it;
     io.outer_it = outer_it; io.fpr = fpr; io.f2norm = f2norm; io.y_out = y_out; io.ms = ms;
     if (int r = ensure(h, h->evals, (size_t)B * 2 * sizeof(int32_t))) return r;
     io.evals = (int32_t*)h->evals.ptr;
+#ifdef MPC_TRACE
+    if (h->trace_cap > 0) {
+        const size_t tb = (size_t)B * h->trace_cap * TRACE_W * sizeof(double);
+        if (int r = ensure(h, h->trace, tb)) return r;
+        HIP_OK(h, hipMemsetAsync(h->trace.ptr, 0xFF, tb, s));  // NaN = record not written
+        io.trace = (double*)h->trace.ptr;
+        io.trace_cap = h->trace_cap;
+    }
+#endif
     h->last_B = B;
-    HIP_OK(h, hipEventRecord(h->ev[2], s));
+    if (!h->capturing) HIP_OK(h, hipEventRecord(h->ev[2], s));
     const size_t lds = h->kp.l_total * sizeof(double);
     // more than 64 KiB of dynamic LDS (long horizons with many time-varying obstacles) must be opted into per kernel
 #define LAUNCH_PAIR_W(NT, SC, MINW)                                                                                \
@@ -311,8 +351,8 @@ int32_t mpcgpu_solve_batch_dev(void* handle, int32_t B, const double* p, const d
 #undef LAUNCH_PAIR
 #undef LAUNCH_PAIR_W
     HIP_OK(h, hipGetLastError());
-    HIP_OK(h, hipEventRecord(h->ev[3], s));
-    h->timing_valid = true;
+    if (!h->capturing) HIP_OK(h, hipEventRecord(h->ev[3], s));
+    h->timing_valid = !h->capturing;
     return 0;
 }
 
@@ -345,7 +385,7 @@ int32_t mpcgpu_solve_batch(void* handle, int32_t B, const double* p, const doubl
                                    y0 ? (const double*)h->y0.ptr : nullptr, c0 ? (const double*)h->c0.ptr : nullptr,
                                    (double*)h->u.ptr, (double*)h->cost.ptr, (int32_t*)h->status.ptr,
                                    (int32_t*)h->inner.ptr, (int32_t*)h->outer.ptr, (double*)h->fpr.ptr,
-                                   (double*)h->f2.ptr, (double*)h->y.ptr, (double*)h->ms.ptr, s);
+                                   (double*)h->f2.ptr, (double*)h->y.ptr, (double*)h->ms.ptr, MPCGPU_STREAM_OWN);
     if (r) return r;
     HIP_OK(h, hipMemcpyAsync(u, h->u.ptr, Bz * n * 8, hipMemcpyDeviceToHost, s));
     HIP_OK(h, hipMemcpyAsync(cost, h->cost.ptr, Bz * 8, hipMemcpyDeviceToHost, s));
@@ -382,7 +422,7 @@ int32_t mpcgpu_cost_grad_batch(void* handle, int32_t B, const double* u, const d
     HIP_OK(h, hipMemcpyAsync(h->u.ptr, u, Bz * n * 8, hipMemcpyHostToDevice, s));
     HIP_OK(h, hipMemcpyAsync(h->xi.ptr, xi, Bz * (n + 1) * 8, hipMemcpyHostToDevice, s));
     BatchPtrs io{};
-    if (int r = prepare(h, B, (const double*)h->p.ptr, s, io)) return r;
+    if (int r = prepare(h, B, (const double*)h->p.ptr, s, io, false)) return r;
     const size_t lds_cg = h->kp.l_total * sizeof(double);
 #define LAUNCH_CG(NT, SC)                                                                                          \
     do {                                                                                                             \
@@ -436,9 +476,8 @@ int32_t mpcgpu_last_eval_counts(void* handle, int32_t B, int32_t* n_psi, int32_t
     if (!h) return -1;
     if (B != h->last_B || !h->evals.ptr) return fail(h, -4, "no solve of %d problems precedes this call (last: %d)", B, h->last_B);
     HIP_OK(h, hipSetDevice(h->device));
-    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    hipStream_t s = pick_stream(h, stream);
     HIP_OK(h, hipStreamSynchronize(s));
-    HIP_OK(h, hipEventSynchronize(h->ev[3]));
     int32_t* tmp = new (std::nothrow) int32_t[(size_t)B * 2];
     if (!tmp) return fail(h, -3, "out of host memory");
     hipError_t e = hipMemcpy(tmp, h->evals.ptr, (size_t)B * 2 * sizeof(int32_t), hipMemcpyDeviceToHost);
@@ -459,6 +498,55 @@ int32_t mpcgpu_last_shape(void* handle, int32_t* max_static, int32_t* max_fleet,
     if (lds_bytes) *lds_bytes = h->last_shape[3];
     return 0;
 }
+
+int32_t mpcgpu_reserve_shape(void* handle, int32_t max_static, int32_t max_fleet, int32_t max_dyn, int32_t var_shape) {
+    Handle* h = (Handle*)handle;
+    if (!h) return -1;
+    if (max_static < 0 && max_fleet < 0 && max_dyn < 0) { h->reserved = false; return 0; }
+    const mpcgpu_config& c = h->cfg;
+    if (max_static < 0 || max_static > c.Nstcobs || max_fleet < 0 || max_fleet > c.Nother || max_dyn < 0 || max_dyn > c.Ndynobs)
+        return fail(h, -1, "reserved shape (%d, %d, %d) outside the configured maxima (%d, %d, %d)", max_static, max_fleet,
+                    max_dyn, c.Nstcobs, c.Nother, c.Ndynobs);
+    KParams probe = h->kp;
+    fill_lds_layout(probe, max_static, max_fleet, max_dyn, var_shape == 0, !LBFGS_IN_WORKSPACE);
+    if (probe.l_total * (int)sizeof(double) > 160 * 1024) return fail(h, -5, "reserved LDS carve of %d bytes exceeds 160 KiB", probe.l_total * 8);
+    h->res_shape[0] = max_static; h->res_shape[1] = max_fleet; h->res_shape[2] = max_dyn; h->res_shape[3] = var_shape != 0;
+    h->reserved = true;
+    return 0;
+}
+
+int32_t mpcgpu_set_option(void* handle, int32_t option, double value) {
+    Handle* h = (Handle*)handle;
+    if (!h) return -1;
+    switch (option) {
+        case MPCGPU_OPT_LINESEARCH_FALLBACK:
+            if (value != 0.0 && value != 1.0) return fail(h, -1, "linesearch fallback must be 0 (last trial) or 1 (tau = 0), got %g", value);
+            h->kp.ls_fallback = (int)value;
+            return 0;
+        default:
+            return fail(h, -1, "unknown option %d", option);
+    }
+}
+
+#ifdef MPC_TRACE
+// trace builds only (tests): record the first `cap` PANOC steps of every problem of the following solves ...
+int32_t mpcgpu_debug_set_trace(void* handle, int32_t cap) {
+    Handle* h = (Handle*)handle;
+    if (!h || cap < 0) return -1;
+    h->trace_cap = cap;
+    return 0;
+}
+// ... and copy the records of the last solve of B problems to the host: out[B][cap][12], NaN = not written
+int32_t mpcgpu_debug_read_trace(void* handle, int32_t B, double* out) {
+    Handle* h = (Handle*)handle;
+    if (!h || !out) return -1;
+    if (B != h->last_B || h->trace_cap <= 0 || !h->trace.ptr) return fail(h, -4, "no traced solve of %d problems precedes this call", B);
+    HIP_OK(h, hipSetDevice(h->device));
+    HIP_OK(h, hipDeviceSynchronize());
+    HIP_OK(h, hipMemcpy(out, h->trace.ptr, (size_t)B * h->trace_cap * TRACE_W * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+#endif
 
 int32_t mpcgpu_last_waves_per_simd(void* handle) {
     Handle* h = (Handle*)handle;

@@ -25,14 +25,21 @@ class DqnTrainer:
                  target_update_interval: int = 10_000, max_grad_norm: float = 10.0, double_q: bool = False,
                  device: str = "cpu"):
         self.q_net = (q_net if q_net is not None else QNetwork()).to(device)
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self._params = [p for p in self.q_net.parameters()]
+        self._bucket = torch.zeros(sum(p.numel() for p in self._params), dtype=torch.float32, device=device)
+        if self.world > 1:
+            # Replicas must START equal: the same averaged gradient applied to different weights never re-converges.
+            # Rank 0's weights win (whatever seeding or checkpoint loading happened before on the other ranks).
+            with torch.no_grad():
+                self._pack([p.detach() for p in self._params])
+                dist.broadcast(self._bucket, src=0)
+                self._unpack([p for p in self._params])
         self.q_net_target = copy.deepcopy(self.q_net).requires_grad_(False)
         self.optimizer = torch.optim.Adam(self.q_net.parameters(), lr=lr)
         self.gamma, self.max_grad_norm, self.double_q = gamma, max_grad_norm, double_q
         self.target_update_interval = target_update_interval
         self.num_updates = 0
-        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        self._params = [p for p in self.q_net.parameters()]
-        self._bucket = torch.zeros(sum(p.numel() for p in self._params), dtype=torch.float32, device=device)
 
     def td_target(self, rewards, next_obs, dones) -> torch.Tensor:
         with torch.no_grad():
@@ -44,44 +51,55 @@ class DqnTrainer:
                 next_v = next_q.max(dim=1).values
             return rewards + (1.0 - dones) * self.gamma * next_v
 
+    def _pack(self, tensors):
+        off = 0
+        for t in tensors:
+            n = t.numel()
+            self._bucket[off:off + n].copy_(t.reshape(-1))
+            off += n
+
+    def _unpack(self, tensors, scale: Optional[float] = None):
+        off = 0
+        for t in tensors:
+            n = t.numel()
+            src = self._bucket[off:off + n].view_as(t)
+            t.copy_(src if scale is None else src * scale)
+            off += n
+
     def _all_reduce_gradients(self):
         """One flat bucket: pack, sum over ranks, average, unpack."""
-        off = 0
-        for p in self._params:
-            n = p.numel()
-            self._bucket[off:off + n].copy_(p.grad.reshape(-1))
-            off += n
+        self._pack([p.grad for p in self._params])
         dist.all_reduce(self._bucket, op=dist.ReduceOp.SUM)
-        self._bucket.div_(self.world)
-        off = 0
-        for p in self._params:
-            n = p.numel()
-            p.grad.copy_(self._bucket[off:off + n].view_as(p.grad))
-            off += n
+        self._unpack([p.grad for p in self._params], 1.0 / self.world)
+
+    def assert_replicas_equal(self) -> None:
+        """Debug aid: every rank holds bit-identical online weights (max - min over ranks of the flat bucket is 0)."""
+        if self.world == 1:
+            return
+        with torch.no_grad():
+            self._pack([p.detach() for p in self._params])
+            hi, lo = self._bucket.clone(), self._bucket.clone()
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            if not torch.equal(hi, lo):
+                raise AssertionError(f"Q-network replicas differ across ranks (max |diff| {float((hi - lo).abs().max()):.3e})")
 
     def update(self, batch: Dict[str, torch.Tensor]) -> float:
         """batch (this rank's shard): obs [b,46] f32, actions [b] i64, rewards [b], next_obs [b,46], dones [b]."""
-        target = self.td_target(batch["rewards"], batch["next_obs"], batch["dones"])
-        q = self.q_net(batch["obs"]).gather(1, batch["actions"].view(-1, 1)).squeeze(1)
-        loss = F.smooth_l1_loss(q, target)
-        self.optimizer.zero_grad(set_to_none=False)
-        loss.backward()
-        if self.world > 1:
-            self._all_reduce_gradients()
-        nn.utils.clip_grad_norm_(self._params, self.max_grad_norm)
-        self.optimizer.step()
+        loss = self._eager_step(batch)
         self.num_updates += 1
         if self.target_update_interval and self.num_updates % self.target_update_interval == 0:
             self.sync_target()
-        return loss.detach()
+        return loss
 
     # ---- hipGraph path: the update is ~40 tiny kernels (MLP forward / backward, Huber loss, clip, Adam) on 1 177
     # parameters, i.e. pure launch latency; captured once, it replays as ONE graph launch
     def enable_graph(self, batch_size: int, obs_dim: int = 46) -> None:
-        """Capture ``update`` for a fixed batch size into a HIP graph (``torch.cuda.CUDAGraph`` is hipGraph on ROCm).
-        Single-process only: the gradient all-reduce of the multi-rank path stays outside graphs."""
-        if self.world > 1:
-            raise RuntimeError("graph capture is built for the single-process update; multi-rank keeps the eager path")
+        """Capture ``update`` for a fixed batch size into HIP graphs (``torch.cuda.CUDAGraph`` is hipGraph on ROCm).
+        One process: ONE graph.  Several ranks: TWO graphs with the flat-bucket all-reduce between them -- graph A =
+        forward, backward and packing the gradients into the bucket; the collective (RCCL) is enqueued eagerly on the same
+        stream; graph B = averaging, unpacking, clipping and the Adam step.  Every rank must call this (the warm-up steps
+        contain collectives)."""
         dev = self._bucket.device
         if dev.type != "cuda":
             raise RuntimeError("enable_graph needs the GPU")
@@ -100,8 +118,17 @@ class DqnTrainer:
                 self._eager_step(self._g_batch)
         torch.cuda.current_stream().wait_stream(side)
         self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
-            self._g_loss.copy_(self._eager_step(self._g_batch))
+        if self.world == 1:
+            with torch.cuda.graph(self._graph):
+                self._g_loss.copy_(self._eager_step(self._g_batch))
+        else:
+            with torch.cuda.graph(self._graph):
+                self._g_loss.copy_(self._backward(self._g_batch))
+                self._pack([p.grad for p in self._params])
+            self._graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph_b, pool=self._graph.pool()):
+                self._unpack([p.grad for p in self._params], 1.0 / self.world)
+                self._apply()
         with torch.no_grad():                              # undo the warm-up / capture steps on the zero batch
             for p, p0 in zip(self._params, state[0]):
                 p.copy_(p0)
@@ -110,21 +137,33 @@ class DqnTrainer:
         self.num_updates = state[1]
         self.target_update_interval = keep_interval
 
-    def _eager_step(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+    def _backward(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         target = self.td_target(batch["rewards"], batch["next_obs"], batch["dones"])
         q = self.q_net(batch["obs"]).gather(1, batch["actions"].view(-1, 1)).squeeze(1)
         loss = F.smooth_l1_loss(q, target)
         self.optimizer.zero_grad(set_to_none=False)
         loss.backward()
-        nn.utils.clip_grad_norm_(self._params, self.max_grad_norm)
-        self.optimizer.step()
         return loss.detach()
 
+    def _apply(self) -> None:
+        nn.utils.clip_grad_norm_(self._params, self.max_grad_norm)
+        self.optimizer.step()
+
+    def _eager_step(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
+        loss = self._backward(batch)
+        if self.world > 1:
+            self._all_reduce_gradients()
+        self._apply()
+        return loss
+
     def update_graphed(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
-        """Same arithmetic as :meth:`update`, replayed from the captured graph (batch size fixed by enable_graph)."""
+        """Same arithmetic as :meth:`update`, replayed from the captured graph(s) (batch size fixed by enable_graph)."""
         for k, v in self._g_batch.items():
             v.copy_(batch[k])
         self._graph.replay()
+        if self.world > 1:
+            dist.all_reduce(self._bucket, op=dist.ReduceOp.SUM)
+            self._graph_b.replay()
         self.num_updates += 1
         if self.target_update_interval and self.num_updates % self.target_update_interval == 0:
             self.sync_target()

@@ -244,11 +244,18 @@ class BatchedRaysEnv:
         fresh[:, :5] = self._start
         fresh[:, 8:24] = keep
         self.state = torch.where(mask[:, None], fresh, self.state)
-        # update_status(reset=True) + get_observation for the reset rows only: observe on a scratch copy of the others
+        # update_status(reset=True) + get_observation for the reset rows only: the launch observes every environment, so the
+        # rows that are NOT reset get their state, observation (including its one-step memory half), reward and
+        # termination flag restored afterwards -- a partial reset must leave them bit-identical
         others = self.state.clone()
+        kept = (self._obs(), self.reward.clone(), self.terminated.clone())
         self._launch(None)
         self.state = torch.where(mask[:, None], self.state, others)
         self.state[:, 6] = torch.where(mask, torch.zeros_like(self.state[:, 6]), self.state[:, 6])
+        merged = self._merge(kept[0], self._obs(), mask)
+        self.obs_internal.copy_(merged["internal"]); self.obs_external.copy_(merged["external"])
+        self.reward.copy_(torch.where(mask, self.reward, kept[1]))
+        self.terminated.copy_(torch.where(mask, self.terminated, kept[2]))
         return self._obs()
 
     def step(self, actions, auto_reset: bool = False):

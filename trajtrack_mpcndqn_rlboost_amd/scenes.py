@@ -41,11 +41,23 @@ def work_mode_weights(cfg: MpcConfig) -> np.ndarray:
 
 
 def make_batch(cfg: MpcConfig, B: int, n_dyn: int = 8, seed: int = 1234, n_other: int = 0,
-               with_box: bool = True, with_walls: bool = True, v_init_range=(0.0, 1.2)) -> Dict[str, np.ndarray]:
+               with_box: bool = True, with_walls: bool = True, v_init_range=(0.0, 1.2),
+               dyn_clearance: Optional[float] = None, box_clearance: Optional[float] = None,
+               on_track: bool = False) -> Dict[str, np.ndarray]:
     """Returns dict(p=[B, np] float64, start=[B,3], ref=[B,N,3]).
 
     ``v_init_range``: range of the previously applied linear speed (p[6]).  Close to the reference speed
-    (1.2 m/s) the acceleration constraints stay inactive and the ALM loop converges in two outer iterations."""
+    (1.2 m/s) the acceleration constraints stay inactive and the ALM loop converges in two outer iterations.
+    ``dyn_clearance``: None = the benchmark family (discs anywhere within 3 m of the path, crossing it: 8 discs of
+    radius 1.6 m cover more area than the corridor has, most problems have no collision-free plan and the solver
+    stops at its iteration caps).  A number = the "passing" family: every disc keeps that gap (metres) between its
+    hard radius and the reference path over the whole horizon (it travels parallel to the path on either side), so
+    a collision-free plan exists, the soft margin (social_margin) still bends the plan, and the solver converges.
+    ``box_clearance``: None = the box sits on the path (benchmark family: the product-of-squared-hinges constraint is
+    flat at the box edge, so the penalty method leaves ||F2|| > 1e-4 at the iteration caps).  A number = the inflated
+    box stands beside the path with that gap (metres); it is still evaluated at every step of every iteration.
+    ``on_track``: the robot starts aligned with a straight reference (what a tick in the middle of a closed-loop run
+    looks like) instead of up to 0.45 rad off a reference with a corner."""
     N = int(cfg.N_hor)
     off = cfg.offsets()
     assert n_dyn <= cfg.Ndynobs and n_other <= cfg.Nother
@@ -60,6 +72,9 @@ def make_batch(cfg: MpcConfig, B: int, n_dyn: int = 8, seed: int = 1234, n_other
     head0 = rng.uniform(-0.15, 0.15, B)
     turn = rng.uniform(-0.6, 0.6, B) * (rng.random(B) < 0.7)
     corner = rng.integers(6, N, B)                       # reference index where the path bends
+    if on_track:
+        turn = 0.0 * turn
+        th = head0 + 0.1 * th
     ks = np.arange(N)[None, :]
     before = np.minimum(ks + 1, corner[:, None])
     after = np.maximum(ks + 1 - corner[:, None], 0)
@@ -112,6 +127,11 @@ def make_batch(cfg: MpcConfig, B: int, n_dyn: int = 8, seed: int = 1234, n_other
         by = ref[np.arange(B), kb, 1] + lat * np.cos(ref[np.arange(B), kb, 2])
         hx = 0.5 * rng.uniform(1.0, 2.0, B) + INFLATE
         hy = 0.5 * rng.uniform(1.0, 2.0, B) + INFLATE
+        if box_clearance is not None:   # beside the path: centre beyond the box's circumscribed radius + gap
+            side = np.where(lat >= 0.0, 1.0, -1.0)
+            lat = side * (np.hypot(hx, hy) + box_clearance)
+            bx = ref[np.arange(B), kb, 0] - lat * np.sin(ref[np.arange(B), kb, 2])
+            by = ref[np.arange(B), kb, 1] + lat * np.cos(ref[np.arange(B), kb, 2])
         p[:, off["os"] + 12 * o: off["os"] + 12 * (o + 1)] = rect_halfspaces(bx - hx, bx + hx, by - hy, by + hy)
         o += 1
 
@@ -119,10 +139,17 @@ def make_batch(cfg: MpcConfig, B: int, n_dyn: int = 8, seed: int = 1234, n_other
     for i in range(n_dyn):
         kc = rng.integers(4, N, B)
         lat = rng.uniform(-3.0, 3.0, B)
-        cxp = ref[np.arange(B), kc, 0] - lat * np.sin(ref[np.arange(B), kc, 2]) + rng.uniform(-0.5, 0.5, B)
-        cyp = ref[np.arange(B), kc, 1] + lat * np.cos(ref[np.arange(B), kc, 2]) + rng.uniform(-0.5, 0.5, B)
+        if dyn_clearance is not None:   # passing family: lateral offset beyond radius + gap, either side
+            lat = np.sign(lat) * (DYN_OBS_SIZE + dyn_clearance + np.abs(lat) / 3.0 * 1.5)
+        jx, jy = rng.uniform(-0.5, 0.5, B), rng.uniform(-0.5, 0.5, B)
+        if dyn_clearance is not None:
+            jx, jy = 0.0 * jx, 0.0 * jy
+        cxp = ref[np.arange(B), kc, 0] - lat * np.sin(ref[np.arange(B), kc, 2]) + jx
+        cyp = ref[np.arange(B), kc, 1] + lat * np.cos(ref[np.arange(B), kc, 2]) + jy
         spd = rng.uniform(0.05, 0.3, B)
         dirn = rng.uniform(-np.pi, np.pi, B)
+        if dyn_clearance is not None:   # along the path (either way), so the gap holds over the horizon
+            dirn = ref[np.arange(B), kc, 2] + np.where(dirn > 0.0, 0.0, np.pi)
         dx, dy = spd * np.cos(dirn), spd * np.sin(dirn)
         ox = cxp[:, None] + dx[:, None] * (ks - kc[:, None])
         oy = cyp[:, None] + dy[:, None] * (ks - kc[:, None])

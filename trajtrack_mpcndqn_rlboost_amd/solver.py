@@ -20,7 +20,17 @@ from .config import MpcConfig
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.environ.get("MPCGPU_LIB", os.path.join(_PKG, "libmpcgpu.so"))  # override: kernel A/B experiments
 
-STATUS_NAMES = ("Converged", "NotConvergedIterations", "NotConvergedOutOfTime", "NotFiniteComputation")
+STATUS_NAMES = ("Converged", "NotConvergedIterations", "NotConvergedOutOfTime", "NotFiniteComputation",
+                "ShapeExceeded")
+ABI_VERSION = 2
+_STREAM_OWN = C.c_void_p(-1)      # MPCGPU_STREAM_OWN: the handle's own non-blocking stream
+OPT_LINESEARCH_FALLBACK = 1       # MPCGPU_OPT_LINESEARCH_FALLBACK
+
+
+def _stream_arg(stream):
+    """``None`` -> the handle's own stream; an int is a raw hipStream_t used as given (0 = HIP's null stream =
+    torch's default stream, ordered with the torch work around the call)."""
+    return _STREAM_OWN if stream is None else C.c_void_p(int(stream))
 
 
 class MpcGpuError(RuntimeError):
@@ -44,7 +54,8 @@ class _CConfig(C.Structure):
 
 EXPORTS = ("mpcgpu_abi_version", "mpcgpu_create", "mpcgpu_destroy", "mpcgpu_last_error", "mpcgpu_num_params",
            "mpcgpu_solve_batch", "mpcgpu_solve_batch_dev", "mpcgpu_cost_grad_batch", "mpcgpu_last_timing",
-           "mpcgpu_last_eval_counts", "mpcgpu_last_shape", "mpcgpu_last_waves_per_simd")
+           "mpcgpu_last_eval_counts", "mpcgpu_last_shape", "mpcgpu_last_waves_per_simd", "mpcgpu_reserve_shape",
+           "mpcgpu_set_option")
 
 
 def library_path() -> str:
@@ -60,13 +71,20 @@ def build_library(force: bool = False) -> str:
     return _LIB
 
 
-_lib = None
+_libs = {}
 
 
-def load_library():
-    global _lib
-    if _lib is not None:
-        return _lib
+def variant_path(name: str) -> str:
+    """Path of a test-only variant build (csrc/Makefile `variants`): 'trace' or 'lbfgs_lds'."""
+    return os.path.join(_PKG, "variants", f"libmpcgpu_{name}.so")
+
+
+def load_library(path: Optional[str] = None):
+    """ctypes handle of libmpcgpu.so (or of another build of it given by ``path``: the tests load the decision-trace
+    and L-BFGS-in-LDS variants next to the product library)."""
+    _LIB = os.path.abspath(path) if path else globals()["_LIB"]
+    if _LIB in _libs:
+        return _libs[_LIB]
     # PyTorch's ROCm wheel bundles its own libamdhip64 / libhsa-runtime64 (same SONAME as the system's).  If torch is
     # imported first, our library binds to that already-loaded runtime and the process has ONE HIP runtime (torch
     # tensors' pointers and stream handles are then first-class here).  The other order puts two runtimes in the
@@ -103,7 +121,18 @@ def load_library():
     L.mpcgpu_last_shape.restype = C.c_int32
     L.mpcgpu_last_waves_per_simd.argtypes = [vp]
     L.mpcgpu_last_waves_per_simd.restype = C.c_int32
-    _lib = L
+    L.mpcgpu_reserve_shape.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    L.mpcgpu_reserve_shape.restype = C.c_int32
+    L.mpcgpu_set_option.argtypes = [vp, C.c_int32, C.c_double]
+    L.mpcgpu_set_option.restype = C.c_int32
+    if L.mpcgpu_abi_version() != ABI_VERSION:
+        raise MpcGpuError(f"{_LIB} has ABI version {L.mpcgpu_abi_version()}, this binding needs {ABI_VERSION}: rebuild it")
+    if hasattr(L, "mpcgpu_debug_set_trace"):     # -DMPC_TRACE builds (tests)
+        L.mpcgpu_debug_set_trace.argtypes = [vp, C.c_int32]
+        L.mpcgpu_debug_set_trace.restype = C.c_int32
+        L.mpcgpu_debug_read_trace.argtypes = [vp, C.c_int32, dp]
+        L.mpcgpu_debug_read_trace.restype = C.c_int32
+    _libs[_LIB] = L
     return L
 
 
@@ -137,12 +166,12 @@ def _ip(a):
 class BatchSolver:
     """One handle of libmpcgpu.so = one generated solver of the reference, for batches of problems."""
 
-    def __init__(self, config: Optional[MpcConfig] = None, device: int = 0):
+    def __init__(self, config: Optional[MpcConfig] = None, device: int = 0, library: Optional[str] = None):
         self.config = config if config is not None else MpcConfig()
-        self._L = load_library()
+        self._L = load_library(library)
         self._h = C.c_void_p()
         d = self.config.solver_dict(device)
-        self._cfg = _CConfig(**d)
+        self._cfg = _CConfig(**{name: d[name] for name, _ in _CConfig._fields_})
         rc = self._L.mpcgpu_create(C.byref(self._cfg), C.byref(self._h))
         if rc != 0:
             msg = self._L.mpcgpu_last_error(None).decode()
@@ -153,6 +182,11 @@ class BatchSolver:
         self.n = 2 * self.N
         self.np = int(self._L.mpcgpu_num_params(self._h))
         assert self.np == self.config.num_params
+        fb = getattr(self.config, "solver_linesearch_fallback", "last_trial")
+        if fb not in ("last_trial", "half_step"):
+            raise MpcGpuError(f"solver_linesearch_fallback must be 'last_trial' or 'half_step', got {fb!r}")
+        self._check(self._L.mpcgpu_set_option(self._h, OPT_LINESEARCH_FALLBACK, 1.0 if fb == "half_step" else 0.0),
+                    "mpcgpu_set_option")
 
     # -- lifetime ---------------------------------------------------------------------------------
     def close(self):
@@ -220,13 +254,15 @@ class BatchSolver:
 
     # -- device-pointer API (torch tensors on this solver's device) ---------------------------------
     def solve_device(self, p, out: dict, initial_guess=None, initial_lagrange_multipliers=None,
-                     initial_penalty=None, stream: int = 0):
+                     initial_penalty=None, stream: Optional[int] = None):
         """Enqueue a batch whose inputs/outputs are float64/int32 CUDA tensors (HBM-resident).
 
         ``out`` must hold preallocated tensors ``u [B,2N] f64, cost [B] f64, status [B] i32`` and may hold
         ``inner_it, outer_it (i32), fpr, f2norm, ms (f64 [B]), y (f64 [B,2N])``.  ``stream`` is a raw
-        hipStream_t (e.g. ``torch.cuda.current_stream().cuda_stream``); 0 = the handle's own stream.
-        Returns after the solve kernel has been enqueued.
+        hipStream_t used as given -- pass ``torch.cuda.current_stream().cuda_stream`` (0 for torch's default
+        stream = HIP's null stream) and the solve is ordered with the torch kernels that produce ``p`` and consume
+        ``out``; ``None`` = the handle's own non-blocking stream (no ordering with torch: synchronise yourself).
+        Returns after the solve kernel has been enqueued (without blocking when ``reserve_shape`` was called).
         """
         B = int(p.shape[0])
         if tuple(p.shape) != (B, self.np) or not p.is_contiguous():
@@ -238,19 +274,47 @@ class BatchSolver:
             self._h, B, ptr(p), ptr(initial_guess), ptr(initial_lagrange_multipliers), ptr(initial_penalty),
             ptr(out["u"]), ptr(out["cost"]), ptr(out["status"]), ptr(out.get("inner_it")),
             ptr(out.get("outer_it")), ptr(out.get("fpr")), ptr(out.get("f2norm")), ptr(out.get("y")),
-            ptr(out.get("ms")), C.c_void_p(stream) if stream else None)
+            ptr(out.get("ms")), _stream_arg(stream))
         self._check(rc, "mpcgpu_solve_batch_dev")
+
+    def reserve_shape(self, max_static: Optional[int] = None, max_fleet: Optional[int] = None,
+                      max_dyn: Optional[int] = None, var_shape: bool = True):
+        """Promise upper bounds on the active rows of the following ``solve_device`` batches (``None`` = the
+        configured maximum): the launch then needs no count read-back -- it never blocks and can be captured into
+        a hipGraph.  Problems that exceed the reservation come back with status 4 (``ShapeExceeded``)."""
+        c = self.config
+        self._check(self._L.mpcgpu_reserve_shape(
+            self._h, int(c.Nstcobs if max_static is None else max_static),
+            int(c.Nother if max_fleet is None else max_fleet), int(c.Ndynobs if max_dyn is None else max_dyn),
+            1 if var_shape else 0), "mpcgpu_reserve_shape")
+
+    def release_shape(self):
+        self._check(self._L.mpcgpu_reserve_shape(self._h, -1, -1, -1, 0), "mpcgpu_reserve_shape")
+
+    # -- decision trace (only with a -DMPC_TRACE build of the library; tests) ------------------------
+    def set_trace(self, cap: int):
+        if not hasattr(self._L, "mpcgpu_debug_set_trace"):
+            raise MpcGpuError("this libmpcgpu.so was not built with -DMPC_TRACE")
+        self._check(self._L.mpcgpu_debug_set_trace(self._h, int(cap)), "mpcgpu_debug_set_trace")
+        self._trace_cap = int(cap)
+
+    def read_trace(self, B: int) -> np.ndarray:
+        """[B, cap, 12] records of the last solve (fields: oracle.TRACE_FIELDS); NaN rows were not written."""
+        out = np.empty((B, self._trace_cap, 12))
+        self._check(self._L.mpcgpu_debug_read_trace(self._h, B, _dp(out)), "mpcgpu_debug_read_trace")
+        return out
 
     def last_timing(self):
         a, b = C.c_double(), C.c_double()
         self._check(self._L.mpcgpu_last_timing(self._h, C.byref(a), C.byref(b)), "mpcgpu_last_timing")
         return dict(prep_ms=a.value, solve_ms=b.value)
 
-    def last_eval_counts(self, B: int, stream: int = 0):
-        """(psi evaluations, of which with gradient) per problem of the last solve of B problems."""
+    def last_eval_counts(self, B: int, stream: Optional[int] = None):
+        """(psi evaluations, of which with gradient) per problem of the last solve of B problems (``stream``: the
+        one that solve was enqueued on, same convention as ``solve_device``)."""
         n_psi = np.empty(B, np.int32); n_grad = np.empty(B, np.int32)
-        self._check(self._L.mpcgpu_last_eval_counts(self._h, B, _ip(n_psi), _ip(n_grad),
-                                                    C.c_void_p(stream) if stream else None), "mpcgpu_last_eval_counts")
+        self._check(self._L.mpcgpu_last_eval_counts(self._h, B, _ip(n_psi), _ip(n_grad), _stream_arg(stream)),
+                    "mpcgpu_last_eval_counts")
         return n_psi, n_grad
 
     def last_shape(self):
