@@ -150,14 +150,24 @@ int32_t mpcgpu_reserve_shape(void* handle, int32_t max_static, int32_t max_fleet
  *       0 (default)  the last trial point (tau = 2^-10) becomes the iterate -- the effective behaviour of the published
  *                    PANOC engine, whose `tau = 0; u <- u_half` fallback is overwritten by the copy of u_plus into u
  *       1            tau = 0: the point u - gamma*fpr is evaluated and taken
+ *   MPCGPU_OPT_PAIRING  problems per wavefront of the solve kernel:
+ *       -1 (default) automatic: the faster layout as measured on the MI355X -- today one problem per wavefront for every
+ *                    horizon
+ *        0           one problem per wavefront (the layout BASELINE.json's north_star words)
+ *        1           two problems per wavefront (rows 0-1 / rows 2-3; compiled for N_hor = 20, error for other horizons)
+ *     The choice never depends on the batch.  Both layouts run the same source (csrc/mpc_kernels.hpp, lane models Solo / Duo);
+ *     their results differ by floating-point summation order only.
  */
-enum { MPCGPU_OPT_LINESEARCH_FALLBACK = 1 };
+enum { MPCGPU_OPT_LINESEARCH_FALLBACK = 1, MPCGPU_OPT_PAIRING = 2 };
 int32_t mpcgpu_set_option(void* handle, int32_t option, double value);
 
 /* Register-allocation variant the last solve call was launched with: 3 (148 VGPRs, no spills) or 4 wavefronts per SIMD
  * (128 VGPRs; chosen when the LDS carve fits 16 times into a CU and the batch exceeds 12 problems per CU).  Both give
  * bitwise identical results. */
 int32_t mpcgpu_last_waves_per_simd(void* handle);
+
+/* Problems per wavefront of the last solve / cost_grad launch: 1 or 2 (MPCGPU_OPT_PAIRING). */
+int32_t mpcgpu_last_problems_per_wavefront(void* handle);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""End-to-end protocol run: the reference's UNCHANGED harness (its InterfaceMpc -> TrajectoryGenerator) loads THIS
+build's plugin module exactly the way it loads an OpEn build --
+
+    sys.path.append(os.path.join('', config.build_directory, config.optimizer_name))   # ./mpc_solver/navi_default
+    built_solver = __import__(config.optimizer_name); solver = built_solver.solver()
+    solution = solver.run(parameters, initial_guess)                    (src/mpc_traj_tracker/trajectory_generator.py:63-71,318)
+
+-- and drives a closed loop with it.  There is no GPU in the build container, so the ``BatchSolver`` behind the plugin
+is replaced by the oracle-backed stand-in (tests/support/oracle_solver.py); everything ABOVE the C-ABI is the real thing:
+mpc_solver/navi_default/navi_default.py, plugin.Solver.run, its result object, and all of the reference's harness code.
+
+Run in the build container only (needs /root/reference):   python tests/golden/make_protocol_fixture.py
+Stores inputs and outputs only (protocol_trace.npz): per tick the parameter vector the reference handed to the plugin,
+what the plugin returned, and the state the reference's harness derived from it.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+# the reference's harness imports opengen / casadi at import time; neither is in this image
+og = types.ModuleType("opengen"); og.opengen = og
+og.tcp = types.ModuleType("opengen.tcp"); og.tcp.OptimizerTcpManager = object
+og.tcp.solver_status = types.SimpleNamespace(SolverStatus=object)
+sys.modules["opengen"] = og; sys.modules["opengen.tcp"] = og.tcp
+cs = types.ModuleType("casadi.casadi"); cs.SX = type("SX", (), {})
+cas = types.ModuleType("casadi"); cas.casadi = cs
+sys.modules["casadi"] = cas; sys.modules["casadi.casadi"] = cs
+
+# the solver behind the plugin: oracle stand-in (no GPU here); recorded so that the calls can be checked
+from support.oracle_solver import OracleBatchSolver  # noqa: E402
+import trajtrack_mpcndqn_rlboost_amd.plugin as plugin  # noqa: E402
+
+CALLS = []
+
+
+class RecordingSolver(plugin.Solver):
+    def run(self, p, initial_guess=None, *a, **kw):
+        sol = super().run(p, initial_guess, *a, **kw)
+        CALLS.append((np.array(p, dtype=float), None if initial_guess is None else np.array(initial_guess), sol))
+        return sol
+
+
+import trajtrack_mpcndqn_rlboost_amd as pkg  # noqa: E402
+
+plugin.BatchSolver = OracleBatchSolver
+plugin.Solver = RecordingSolver
+pkg.Solver = RecordingSolver          # the name mpc_solver/navi_default/navi_default.py imports
+
+os.chdir(ROOT)                                                   # the reference resolves ./mpc_solver/<optimizer_name>
+os.environ["MPCGPU_CONFIG"] = os.path.join(REF, "config", "mpc_default.yaml")
+sys.path.insert(0, os.path.join(REF, "src"))
+from util.mpc_config import Configurator  # noqa: E402 (reference)
+from interface_mpc import InterfaceMpc  # noqa: E402 (reference)
+
+if __name__ == "__main__":
+    cfg = Configurator(os.path.join(REF, "config", "mpc_default.yaml"), verbose=False)
+    mpc = InterfaceMpc(cfg, motion_model=None)                    # -> __import__('navi_default').solver()
+    assert type(mpc._traj_gen.solver).__name__ == "RecordingSolver", type(mpc._traj_gen.solver)
+    assert "navi_default" in sys.modules and sys.modules["navi_default"].__file__.startswith(os.path.join(ROOT, "mpc_solver"))
+    path = [(0.6, 3.5), (5.0, 3.5), (8.0, 5.5), (11.0, 3.5)]
+    box = [(6.7, 1.2), (9.3, 1.2), (9.3, 3.0), (6.7, 3.0)]       # beside the path
+    mpc.initialization(np.array([0.6, 3.5, 0.0]), np.array([11.0, 3.5, 0.0]), path, "work")
+    mpc.update_static_constraints([box])
+    T = 30
+    out = dict(p=[], u=[], cost=[], status=[], action=[], state=[], pred=[])
+    for t in range(T):
+        ref, _ = mpc.get_local_ref_traj()
+        CALLS.clear()
+        action, pred, cost = mpc.get_action(ref, mode="work")
+        assert len(CALLS) == 1 and CALLS[0][1] is None            # one plugin call per tick, initial_guess=None
+        p, _, sol = CALLS[0]
+        out["p"].append(p); out["u"].append(np.array(sol.solution)); out["cost"].append(sol.cost)
+        out["status"].append(sol.exit_status); out["action"].append(np.array(action))
+        out["state"].append(mpc.state.copy()); out["pred"].append(np.array(pred))
+    save = {k: np.array(v) for k, v in out.items()}
+    save["path"] = np.array(path); save["box"] = np.array(box)
+    print("ticks", T, "converged", sum(s == "Converged" for s in out["status"]), "final state", mpc.state)
+    np.savez_compressed(os.path.join(HERE, "protocol_trace.npz"), **save)

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Debug aid: first PANOC step at which two TRACE builds of the library differ (bitwise) on the same problems.
+usage: trace_diff.py libA.so libB.so [N] [B]"""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from trajtrack_mpcndqn_rlboost_amd import MpcConfig, BatchSolver, scenes
+import oracle
+N = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+B = int(sys.argv[4]) if len(sys.argv) > 4 else 64
+cfg = MpcConfig(N_hor=N)
+sc = scenes.make_batch(cfg, B, n_dyn=8, seed=31 + N, dyn_clearance=0.1, box_clearance=0.3)
+out = []
+for lib in sys.argv[1:3]:
+    bs = BatchSolver(cfg, library=lib)
+    bs.set_trace(400)
+    res = bs.solve(sc["p"])
+    out.append((res, bs.read_trace(B)))
+    bs.close()
+(ra, ta), (rb, tb) = out
+print("solutions bitwise equal:", np.array_equal(ra.solution, rb.solution))
+for b in range(B):
+    d = ~((ta[b] == tb[b]) | (np.isnan(ta[b]) & np.isnan(tb[b])))
+    if d.any():
+        k = int(np.argmax(d.any(axis=1)))
+        f = np.nonzero(d[k])[0]
+        print(f"problem {b}: first difference at step {k}, fields {[oracle.TRACE_FIELDS[i] for i in f]}:", ta[b, k, f], tb[b, k, f])
+        if b > 8: break

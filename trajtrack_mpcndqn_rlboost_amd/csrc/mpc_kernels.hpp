@@ -166,15 +166,33 @@ __device__ __forceinline__ double row_suffix(double x) {
     x += dpp0<DPP_ROW_SHL0 + 8>(x);
     return x;
 }
-// sum over the first ROWS*16 lanes (lanes that do not take part must carry 0); uniform result
+// sum over the first ROWS*16 lanes (lanes that do not take part must carry 0); uniform result.
+// Row totals are chained with row_bcast15 / row_bcast31 (2 DPP moves + 1 add each; rows without a source read 0 through
+// bound_ctrl, their lanes are not used) and the total is read from the last lane: 17 / 20 VALU instructions for 2 / 4 rows
+// instead of 20 / 27 with one v_readlane pair per row.
 template <int ROWS>
 __device__ __forceinline__ double wave_sum_u(double x) {
     x = row_prefix(x);  // lane 15 of each row = row total
-    double t = readlane_d(x, 15);
-    if (ROWS > 1) t += readlane_d(x, 31);
-    if (ROWS > 2) t += readlane_d(x, 47);
-    if (ROWS > 3) t += readlane_d(x, 63);
-    return uniform(t);
+    if (ROWS == 1) return readlane_d(x, 15);
+    if (ROWS == 3) {    // rows 1 and 3 only, then rows 2-3: lane 47 = r2 + (r1 + r0)
+        x += dpp0<DPP_BCAST15, 0xA>(x);
+        x += dpp0<DPP_BCAST31, 0xC>(x);
+        return readlane_d(x, 47);
+    }
+    x += dpp0<DPP_BCAST15>(x);                 // lane 31 = r1 + r0, lane 63 = r3 + r2 (the other lanes are not used)
+    if (ROWS == 4) x += dpp0<DPP_BCAST31>(x);  // lane 63 = (r3 + r2) + (r1 + r0)
+    return readlane_d(x, 16 * ROWS - 1);
+}
+// two sums over lanes 0..31 for the price of one: b travels in rows 2-3 (v_permlane32_swap), one DPP sequence serves both.
+// Bitwise the same totals as wave_sum_u<2>(a), wave_sum_u<2>(b).
+__device__ __forceinline__ void wave_sum2_u(double a, double b, double& sa, double& sb) {
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    double x = __hiloint2double((int)hi[0], (int)lo[0]);  // lanes 0..31: a, lanes 32..63: b (lanes 0..31 of it)
+    x = row_prefix(x);
+    x += dpp0<DPP_BCAST15>(x);
+    sa = readlane_d(x, 31);
+    sb = readlane_d(x, 63);
 }
 // inclusive prefix sum over lanes 0..16*ROWS-1 (lanes >= n must carry 0)
 template <int ROWS>
@@ -219,6 +237,99 @@ __device__ __forceinline__ void scan_cprod(double& re, double& im) {
     if (ROWS > 1) cmul_step<DPP_BCAST15, 0xA>(re, im);
     if (ROWS > 2) cmul_step<DPP_BCAST31, 0xC>(re, im);
 }
+// ------------------------------------------------------------------------------------------------
+// Lane models of the solver (template parameter P of load_problem / eval_point / solve_body).
+//   Solo<NT>: one problem per wavefront.  Iteration scalars are wave-uniform and live in SGPRs (sums come back through
+//             v_readlane), every lane is an item lane, N <= 64.
+//   Duo<NT> : TWO problems per wavefront, rows 0-1 = problem 2*blockIdx, rows 2-3 = problem 2*blockIdx+1 (N <= 31).  At
+//             N = 20 the scans, the PANOC vector algebra and the ~40 inner products per iteration keep 20 of 64 lanes busy
+//             in the Solo layout; here the same instruction serves both problems.  The two halves run their own state
+//             machines (the compiler's EXEC masking does the bookkeeping: a "scalar" of the iteration is a VGPR whose 32
+//             lanes hold bitwise the same value), every cross-lane operation stays inside a half:
+//               * all-reduce: xor butterfly inside each 16-lane row (quad_perm, row_half_mirror, row_mirror: addition is
+//                 commutative, so every lane of a row ends with the same bits), then v_permlane16_swap exchanges the two
+//                 rows of each half;
+//               * prefix scans: row_shr + row_bcast15 with row mask 0xA (rows 0 -> 1 and 2 -> 3 in one instruction);
+//               * suffix scans: row_shl, then the first lane of the upper row via v_permlane16_swap + row_newbcast:0.
+//             (tools/probes/duo_lanes.hip checks these on the hardware, also with one half masked off.)
+// ------------------------------------------------------------------------------------------------
+enum : int { DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_ROW_MIRROR = 0x140, DPP_ROW_HALF_MIRROR = 0x141, DPP_ROW_NEWBCAST0 = 0x150 };
+// total of every 16-lane row, bitwise identical in all of its lanes
+__device__ __forceinline__ double row_allsum(double x) {
+    x += dpp0<DPP_QUAD_XOR1>(x);
+    x += dpp0<DPP_QUAD_XOR2>(x);
+    x += dpp0<DPP_ROW_HALF_MIRROR>(x);
+    x += dpp0<DPP_ROW_MIRROR>(x);
+    return x;
+}
+// lane for lane: x of the even row of this lane's half (rows 0 / 2) and of the odd row (rows 1 / 3)
+__device__ __forceinline__ void row_pair(double x, double& even_row, double& odd_row) {
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    even_row = __hiloint2double((int)b[0], (int)a[0]);
+    odd_row = __hiloint2double((int)b[1], (int)a[1]);
+}
+// total of every 32-lane half, bitwise identical in all of its lanes
+__device__ __forceinline__ double half_allsum(double x) {
+    x = row_allsum(x);
+    double e, o;
+    row_pair(x, e, o);
+    return e + o;
+}
+// inclusive suffix sum inside every 32-lane half
+__device__ __forceinline__ double half_suffix(double x) {
+    x = row_suffix(x);
+    double e, o;
+    row_pair(x, e, o);
+    return x + dpp0<DPP_ROW_NEWBCAST0, 0x5>(o);  // rows 0 / 2 += first lane of rows 1 / 3
+}
+
+template <int NT>
+struct Solo {
+    static constexpr bool DUO = false;
+    static constexpr int W = WAVE;             // lanes per problem
+    static constexpr int RV = Dim<NT>::ROWS_V;  // rows holding vector lanes
+    static constexpr int RI = 4;               // rows holding item lanes
+    static __device__ __forceinline__ int lane() { return threadIdx.x; }
+    static __device__ __forceinline__ int half() { return 0; }
+    static __device__ __forceinline__ int problem() { return blockIdx.x; }
+    static __device__ __forceinline__ double uni(double x) { return uniform(x); }
+    template <int ROWS> static __device__ __forceinline__ double sum(double x) { return wave_sum_u<ROWS>(x); }
+    // two independent sums over the vector lanes
+    static __device__ __forceinline__ void sum2(double a, double b, double& sa, double& sb) {
+        if (RV <= 2) wave_sum2_u(a, b, sa, sb);
+        else { sa = wave_sum_u<RV>(a); sb = wave_sum_u<RV>(b); }
+    }
+    static __device__ __forceinline__ bool any(bool c) { return __ballot(c) != 0ull; }
+    template <int ROWS> static __device__ __forceinline__ double prefix(double x) { return scan_prefix<ROWS>(x); }
+    template <int ROWS> static __device__ __forceinline__ void cprod(double& re, double& im) { scan_cprod<ROWS>(re, im); }
+    template <int ROWS> static __device__ __forceinline__ double suffix(double x, int lane) { return scan_suffix<ROWS>(x, lane); }
+    static __device__ __forceinline__ double from_lane(double x, int l) { return readlane_d(x, l); }
+};
+template <int NT>
+struct Duo {
+    static_assert(NT >= 2 && NT <= 31, "two problems per wavefront need a compile-time horizon of at most 31 steps");
+    static constexpr bool DUO = true;
+    static constexpr int W = WAVE / 2;
+    static constexpr int RV = 2;
+    static constexpr int RI = 2;
+    static __device__ __forceinline__ int lane() { return threadIdx.x & 31; }
+    static __device__ __forceinline__ int half() { return threadIdx.x >> 5; }
+    static __device__ __forceinline__ int problem() { return 2 * blockIdx.x + (threadIdx.x >> 5); }
+    static __device__ __forceinline__ double uni(double x) { return x; }
+    template <int ROWS> static __device__ __forceinline__ double sum(double x) { return half_allsum(x); }
+    static __device__ __forceinline__ void sum2(double a, double b, double& sa, double& sb) { sa = half_allsum(a); sb = half_allsum(b); }
+    static __device__ __forceinline__ bool any(bool c) {
+        const unsigned long long m = __ballot(c);
+        return ((threadIdx.x & 32) ? (unsigned)(m >> 32) : (unsigned)m) != 0u;
+    }
+    template <int ROWS> static __device__ __forceinline__ double prefix(double x) { return scan_prefix<2>(x); }
+    template <int ROWS> static __device__ __forceinline__ void cprod(double& re, double& im) { scan_cprod<2>(re, im); }
+    template <int ROWS> static __device__ __forceinline__ double suffix(double x, int) { return half_suffix(x); }
+    static __device__ __forceinline__ double from_lane(double x, int l) { return half_allsum(lane() == l ? x : 0.0); }
+};
+
 // Double-precision literals cannot be instruction operands on gfx950; the compiler materialises each one in a VGPR
 // pair and keeps it there for the whole solver loop (two registers per literal, >20 literals on the hot path).
 // Reading them from constant memory makes them scalar loads into SGPRs instead.
@@ -418,10 +529,10 @@ struct EvalOut {
     double F2e, F2pad;      // lane i < Kd: F2 of dynamic entry i; uniform: F2 of every padded row
 };
 
-template <int NT, bool SC>
+template <int NT, bool SC, class P>
 __device__ __forceinline__ void load_problem(const KParams& kp, const double* __restrict__ ws, double* lds,
                                              Ctx& cx) {
-    const int lane = threadIdx.x;
+    const int lane = P::lane();  // lane inside the problem; `lds` is this problem's carve
     const int N = NT ? NT : kp.N;
     cx.lane = lane;
     cx.vl = lane < N;
@@ -432,7 +543,7 @@ __device__ __forceinline__ void load_problem(const KParams& kp, const double* __
     if (lane < KC_BASE) hd[lane] = ws[lane];
     if (lane < 27) hd[KC_BASE + lane] = KTAB[lane];
     cx.hd = hd;
-    auto U = [&](int i) { return uniform(ws[i]); };
+    auto U = [&](int i) { return P::uni(ws[i]); };
     cx.Ks = (int)U(H_KS); cx.Kf = (int)U(H_KF); cx.Kd = (int)U(H_KD);
     cx.pad_f = U(H_NPF) > 0.0; cx.pad_d = U(H_NPD) > 0.0;
     cx.terminal = U(H_QN) != 0.0 || U(H_QTHN) != 0.0;
@@ -442,22 +553,22 @@ __device__ __forceinline__ void load_problem(const KParams& kp, const double* __
     cx.dyn = lds + kp.l_dyn; cx.dync = lds + kp.l_dync; cx.qd = lds + kp.l_qd; cx.pos = lds + kp.l_pos; cx.H = lds + kp.l_H;
     cx.W = lds + kp.l_W; cx.part = lds + kp.l_part; cx.stash = lds + kp.l_stash;
     // coalesced table copies HBM -> LDS (only the active entries of this problem)
-    for (int i = lane; i < N * SEGW; i += WAVE) cx.seg[i] = ws[kp.ws_seg + i];
-    for (int i = lane; i < cx.Ks * STCW; i += WAVE) cx.stc[i] = ws[kp.ws_stc + i];
-    for (int i = lane; i < cx.Kf * N * 2; i += WAVE) cx.fxy[i] = ws[kp.ws_fxy + i];
+    for (int i = lane; i < N * SEGW; i += P::W) cx.seg[i] = ws[kp.ws_seg + i];
+    for (int i = lane; i < cx.Ks * STCW; i += P::W) cx.stc[i] = ws[kp.ws_stc + i];
+    for (int i = lane; i < cx.Kf * N * 2; i += P::W) cx.fxy[i] = ws[kp.ws_fxy + i];
     if (SC) {
         // shape-constant rows: per-row constants from the step-0 record (+ alpha), per-step centre, per-step q_dyn
-        for (int i = lane; i < cx.Kd * DYNC; i += WAVE) {
+        for (int i = lane; i < cx.Kd * DYNC; i += P::W) {
             const int r = i / DYNC, f = i - r * DYNC;
             cx.dync[i] = f < 6 ? ws[kp.ws_dyn + (r * N) * DYNW + 2 + f] : ws[kp.ws_alpha + r];
         }
-        for (int i = lane; i < cx.Kd * N; i += WAVE) {
+        for (int i = lane; i < cx.Kd * N; i += P::W) {
             const double* d = ws + kp.ws_dyn + i * DYNW;
             cx.dyn[i * DYNP] = d[0]; cx.dyn[i * DYNP + 1] = d[1];
         }
-        for (int i = lane; i < N; i += WAVE) cx.qd[i] = ws[kp.ws_qd + i];
+        for (int i = lane; i < N; i += P::W) cx.qd[i] = ws[kp.ws_qd + i];
     } else {
-        for (int i = lane; i < cx.Kd * N * DYNW; i += WAVE) cx.dyn[i] = ws[kp.ws_dyn + i];
+        for (int i = lane; i < cx.Kd * N * DYNW; i += P::W) cx.dyn[i] = ws[kp.ws_dyn + i];
     }
     wave_sync();
 }
@@ -488,8 +599,8 @@ __device__ __forceinline__ DynItem dyn_item(const Ctx& cx, int i, int k, int N, 
 // ------------------------------------------------------------------------------------------------
 // psi(u; c, y), f(u), F1, F2 and (optionally) grad psi at the point held by the vector lanes.
 // ------------------------------------------------------------------------------------------------
-template <int NT, bool SC>
-__device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, double v, double w, double c,
+template <int NT, bool SC, class P>
+__device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, double v, double w, double c, double icm,
                                            double ya, double yb, bool want_grad, bool want_f, EvalOut& out PROF_ARG) {
     const int N = NT ? NT : kp.N;
     int lane = cx.lane;
@@ -498,12 +609,13 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     // item lanes: lane = sub*N + k.  Step k is served by LPS = (63-k)/N + 1 lanes (3-4 at N = 20; at N = 40 the 24 spare
     // lanes double up on the first 24 steps, which also carry the most reference segments)
     // When 64 is almost a multiple of N (N = 20: 60 lanes) a uniform split is cheaper: the loop strides are constants.
-    constexpr bool UNIFORM = NT != 0 && (WAVE % NT) * 5 <= NT;
+    constexpr int PW = P::W;  // lanes of this problem
+    constexpr bool UNIFORM = NT != 0 && (PW % NT) * 5 <= NT;
     const bool c_vl = lane < N;
-    const bool c_il = UNIFORM ? lane < (WAVE / N) * N : true;
+    const bool c_il = UNIFORM ? lane < (PW / N) * N : true;
     const int c_ik = lane % N, c_isub = lane / N;
-    const int LPS = UNIFORM ? WAVE / N : (WAVE - 1 - c_ik) / N + 1;
-    constexpr int RV = Dim<NT>::ROWS_V, RI = Dim<NT>::ROWS_I;
+    const int LPS = UNIFORM ? PW / N : (PW - 1 - c_ik) / N + 1;
+    constexpr int RV = P::RV, RI = P::RI;
     const double ts = kp.ts;
     const double inf = __builtin_huge_val();
     if (!c_vl) { v = 0.0; w = 0.0; }
@@ -513,12 +625,12 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     double c0, s0, cm, sm, c2, s2;
     {
         const double hd = 0.5 * ts * w;  // half-step heading increment
-        const bool small = __ballot(fabs(hd) > KC(K_SMALL)) == 0ull;
+        const bool small = !P::any(fabs(hd) > KC(K_SMALL));
         if (small) {
             double sh, ch;
             sincos_small(hd, cx.hd + KC_BASE, sh, ch);
             double er = ch * ch - sh * sh, ei = 2.0 * sh * ch;  // e^{i ts w_k}
-            scan_cprod<RV>(er, ei);                               // prod_{j<=k} e^{i ts w_j}
+            P::template cprod<RV>(er, ei);                               // prod_{j<=k} e^{i ts w_j}
             c2 = HD(H_CTH0) * er - HD(H_STH0) * ei;                      // heading k+1
             s2 = HD(H_CTH0) * ei + HD(H_STH0) * er;
             c0 = shift_up1(c2, lane, HD(H_CTH0));
@@ -527,7 +639,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
             sm = c0 * sh + s0 * ch;
         } else {  // a trial point far outside the input box: plain sincos of the summed angles
             const double tw = ts * w;
-            const double th1 = HD(H_TH0) + scan_prefix<RV>(tw);
+            const double th1 = HD(H_TH0) + P::template prefix<RV>(tw);
             sincos(th1 - 0.5 * tw, &sm, &cm);
             sincos(th1, &s2, &c2);
             c0 = shift_up1(c2, lane, HD(H_CTH0));
@@ -539,8 +651,8 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     {
     const double Cx = (c0 + 4.0 * cm + c2) * sixth, Sy = (s0 + 4.0 * sm + s2) * sixth;
     const double dCw = -ts * (2.0 * sm + s2) * sixth, dSw = ts * (2.0 * cm + c2) * sixth;
-    const double X = HD(H_X0) + scan_prefix<RV>(c_vl ? ts * v * Cx : 0.0);
-    const double Y = HD(H_Y0) + scan_prefix<RV>(c_vl ? ts * v * Sy : 0.0);
+    const double X = HD(H_X0) + P::template prefix<RV>(c_vl ? ts * v * Cx : 0.0);
+    const double Y = HD(H_Y0) + P::template prefix<RV>(c_vl ? ts * v * Sy : 0.0);
     if (c_vl) {
         cx.pos[2 * lane] = X; cx.pos[2 * lane + 1] = Y;
         // rollout quantities needed again only after the item phase (per-step terms, adjoint): parked in LDS so
@@ -590,7 +702,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
             const double bx = px - sg[5], by = py - sg[6], reach = (sb + sg[7]) * KC(K_REACH);
             more = bx * bx + by * by < reach * reach;
         }
-        if (__ballot(more) != 0ull) {
+        if (P::any(more)) {
             // (3) rare: per-segment test (midpoint distance vs sqrt(best) + half length), evaluate on demand
             MPC_ITEM_LOOP
             for (; i < N; i += LPS) {
@@ -679,14 +791,14 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
             hp = fmax(0.0, 1.0 - X * X * ipad - Y * Y * ipad);
         }
     }
-    const bool any_hp = __ballot(hp > 0.0) != 0ull;
-    const bool any_h = __ballot(anyh) != 0ull;
+    const bool any_hp = P::any(hp > 0.0);
+    const bool any_h = P::any(anyh);
     wave_sync();
 
     // ---- constraint sums: S (static, broadcast into every F2 component), D_i (row sums of H).
     //      Every reduction is skipped when the ballots show that all its terms are zero.
-    const bool any_S = __ballot(S_l > 0.0) != 0ull;
-    const double S = any_S ? wave_sum_u<RI>(S_l) : 0.0;
+    const bool any_S = P::any(S_l > 0.0);
+    const double S = any_S ? P::template sum<RI>(S_l) : 0.0;
     double F2e = 0.0;
     if (lane < cx.Kd) {
         double D = 0.0;
@@ -694,7 +806,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
             for (int k = 0; k < N; ++k) D += cx.H[lane * N + k];
         F2e = S + D;
     }
-    const double F2pad = cx.pad_d ? S + (any_hp ? wave_sum_u<RV>(hp) : 0.0) : 0.0;
+    const double F2pad = cx.pad_d ? S + (any_hp ? P::template sum<RV>(hp) : 0.0) : 0.0;
     const bool viol = any_S || any_h || any_hp;  // some penalty constraint is violated
     out.F2e = F2e;
     out.F2pad = F2pad;
@@ -703,7 +815,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     // ---- item phase B (only when some penalty constraint is violated): weighted hard-constraint gradients
     double Gpx = 0.0, Gpy = 0.0;  // vector lanes: gradient of the padded-row terms w.r.t. the position
     if (want_grad && viol) {
-        const double sumF2 = wave_sum_u<2>(F2e) + HD(H_NPD) * F2pad;
+        const double sumF2 = P::template sum<2>(F2e) + HD(H_NPD) * F2pad;
         if (lane < cx.Kd) cx.W[lane] = c * F2e;
         wave_sync();
         if (c_il) {
@@ -762,7 +874,6 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     const double a = c_vl ? (v - vprev) * kp.inv_ts : 0.0;
     const double bacc = c_vl ? (w - wprev) * kp.inv_ts : 0.0;
     out.F1a = a; out.F1b = bacc;
-    const double icm = 1.0 / fmax(c, 1.0);
     const double za = a + ya * icm, zb = bacc + yb * icm;
     const double ea = za > kp.amax ? za - kp.amax : (za < kp.amin ? za - kp.amin : 0.0);
     const double eb = zb > kp.aamax ? zb - kp.aamax : (zb < -kp.aamax ? zb + kp.aamax : 0.0);
@@ -772,24 +883,24 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         vcost += HD(H_QVEL) * dv * dv + HD(H_RV) * v * v + HD(H_RW) * w * w + HD(H_ACC) * a * a + HD(H_WACC) * bacc * bacc;
     }
     if (cx.terminal) {  // terminal cost (weights are 0 in the reference's yaml)
-        const double thN = HD(H_TH0) + wave_sum_u<RV>(ts * w);
+        const double thN = HD(H_TH0) + P::template sum<RV>(ts * w);
         if (lane == N - 1) {
             const double ex = X - HD(H_XG), ey = Y - HD(H_YG), et = thN - HD(H_THG);
             vcost += HD(H_QN) * (ex * ex + ey * ey) + HD(H_QTHN) * et * et;
             Gx += 2.0 * HD(H_QN) * ex; Gy += 2.0 * HD(H_QN) * ey;
             gthN = 2.0 * HD(H_QTHN) * et;
         }
-        gthN = readlane_d(gthN, N - 1);
+        gthN = P::from_lane(gthN, N - 1);
     }
     // psi = f + c/2 dist^2_C(F1 + y/max(c,1)) + c/2 ||F2||^2 in ONE wave reduction of per-lane partials
     // (item lanes: stage costs; vector lanes: per-step costs + box distance; lanes < Kd: their F2 entry)
     const double dist_l = c_vl ? ea * ea + eb * eb : 0.0;
     const double f2_l = viol ? F2e * F2e : 0.0;
     const double pad2 = viol ? HD(H_NPD) * F2pad * F2pad : 0.0;
-    out.psi = wave_sum_u<RI>(cost_l + vcost + 0.5 * c * (dist_l + f2_l)) + 0.5 * c * pad2;
+    out.psi = P::template sum<RI>(cost_l + vcost + 0.5 * c * (dist_l + f2_l)) + 0.5 * c * pad2;
     if (want_f) {  // f and ||F2||^2 on their own (outer loop, test hook): two more reductions
-        out.f = wave_sum_u<RI>(cost_l + vcost);
-        out.nrm2F2 = viol ? wave_sum_u<2>(f2_l) + pad2 : 0.0;
+        out.f = P::template sum<RI>(cost_l + vcost);
+        out.nrm2F2 = viol ? P::template sum<2>(f2_l) + pad2 : 0.0;
     }
 
     PROF_MARK(8);  // vector terms + psi
@@ -802,9 +913,9 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         // adjoint of the rollout: suffix sums instead of a serial backward sweep
         double Cx = 0.0, Sy = 0.0, dCw = 0.0, dSw = 0.0;
         if (c_vl) { const double* st = cx.stash + lane * 6; Cx = st[0]; Sy = st[1]; dCw = st[2]; dSw = st[3]; }
-        const double Ax = scan_suffix<RV>(Gx, lane), Ay = scan_suffix<RV>(Gy, lane);
+        const double Ax = P::template suffix<RV>(Gx, lane), Ay = P::template suffix<RV>(Gy, lane);
         const double T = c_vl ? ts * v * (-Sy * Ax + Cx * Ay) : 0.0;
-        const double Bx = scan_suffix<RV>(T, lane) - T;
+        const double Bx = P::template suffix<RV>(T, lane) - T;
         gv += ts * (Cx * Ax + Sy * Ay);
         gw += ts * v * (dCw * Ax + dSw * Ay) + ts * (Bx + gthN);
         out.gv = c_vl ? gv : 0.0;
@@ -816,17 +927,17 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
 // ------------------------------------------------------------------------------------------------
 // test-hook kernel: one evaluation per problem through eval_point
 // ------------------------------------------------------------------------------------------------
-template <int NT, bool SC>
+template <int NT, bool SC, class P>
 __global__ __launch_bounds__(WAVE) void cost_grad_kernel(KParams kp, BatchPtrs io, const double* __restrict__ u,
                                                          const double* __restrict__ xi, double* psi, double* f,
                                                          double* grad, double* F1, double* F2, int B) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int b = blockIdx.x;
+    const int b = P::problem();
     if (b >= B) return;
-    const int lane = threadIdx.x, N = NT ? NT : kp.N;
+    const int lane = P::lane(), N = NT ? NT : kp.N;
     const double* ws = io.ws + (size_t)b * kp.ws_stride;
     Ctx cx;
-    load_problem<NT, SC>(kp, ws, lds, cx);
+    load_problem<NT, SC, P>(kp, ws, lds + P::half() * kp.l_total, cx);
     const double* ub = u + (size_t)b * 2 * N;
     const double* xb = xi + (size_t)b * (1 + 2 * N);
     const double v = cx.vl ? ub[2 * lane] : 0.0, w = cx.vl ? ub[2 * lane + 1] : 0.0;
@@ -836,7 +947,7 @@ __global__ __launch_bounds__(WAVE) void cost_grad_kernel(KParams kp, BatchPtrs i
 #ifdef MPC_PROFILE
     Prof prof; prof.start();
 #endif
-    eval_point<NT, SC>(kp, cx, v, w, c, ya, yb, true, true, o PROF_PASS);
+    eval_point<NT, SC, P>(kp, cx, v, w, c, 1.0 / fmax(c, 1.0), ya, yb, true, true, o PROF_PASS);
     if (lane == 0) {
         if (psi) psi[b] = o.psi;
         if (f) f[b] = o.f;
@@ -847,7 +958,7 @@ __global__ __launch_bounds__(WAVE) void cost_grad_kernel(KParams kp, BatchPtrs i
     }
     if (F2 && lane < kp.Ndynobs) {
         const int e = (int)ws[H_ENTRY + lane];
-        const double val = __shfl(o.F2e, e < 0 ? 0 : e);  // test hook only: one LDS-crossbar gather
+        const double val = __shfl(o.F2e, (threadIdx.x - lane) + (e < 0 ? 0 : e));  // test hook only: one LDS-crossbar gather
         F2[(size_t)b * kp.Ndynobs + lane] = e < 0 ? o.F2pad : val;
     }
 }
@@ -862,28 +973,32 @@ __global__ __launch_bounds__(WAVE) void cost_grad_kernel(KParams kp, BatchPtrs i
 // ------------------------------------------------------------------------------------------------
 enum { ST_INIT0 = 0, ST_INIT1, ST_LIP, ST_NOLS, ST_LS, ST_OUTER };
 
-template <int ROWS>
+// The fused form is spelled out: under -ffp-contract=fast `a0*b0 + a1*b1` may become fma(a0,b0,a1*b1) in one
+// instantiation of the solver kernel and fma(a1,b1,a0*b0) in another, and the L-BFGS-in-LDS and workspace builds must agree
+// bit for bit (tests/test_gpu_baseline_parity.py).
+template <class P, int ROWS>
 __device__ __forceinline__ double dot2r(double a0, double a1, double b0, double b1) {
-    return wave_sum_u<ROWS>(a0 * b0 + a1 * b1);
+    return P::template sum<ROWS>(__builtin_fma(a0, b0, a1 * b1));
 }
 
 #ifndef MPC_MIN_WAVES
 #define MPC_MIN_WAVES 3  // waves per SIMD the register allocator must leave room for (512 / MPC_MIN_WAVES VGPRs)
 #endif
-template <int NT, bool SC, bool LBG, int MINW>
-__global__ __launch_bounds__(WAVE, MINW) void solve_kernel_pair(KParams kp, BatchPtrs io, int B) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int b = blockIdx.x;
+// The whole ALM / PANOC solve of problem P::problem() on the lanes P gives it.  `lds` is the workgroup's dynamic LDS.
+template <int NT, bool SC, bool LBG, class P>
+__device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& io, int B, double* lds) {
+    const int b = P::problem();
     if (b >= B) return;
     const long long t_start = wall_clock64();
-    const int lane = threadIdx.x, N = NT ? NT : kp.N, mem = kp.mem;
-    constexpr int RV = Dim<NT>::ROWS_V;
+    const int lane = P::lane(), N = NT ? NT : kp.N, mem = kp.mem;
+    constexpr int RV = P::RV;
+    lds += P::half() * kp.l_total;  // this problem's carve
     const double* ws = io.ws + (size_t)b * kp.ws_stride;
     // Launches with a RESERVED LDS carve (mpcgpu_reserve_shape: no count read-back before the launch) check every problem
     // against it: a problem with more active rows than reserved must not touch the tables -- it is reported, not solved.
     if (kp.reserved) {
-        const bool over = (int)uniform(ws[H_KS]) > kp.mKs || (int)uniform(ws[H_KF]) > kp.mKf || (int)uniform(ws[H_KD]) > kp.mKd ||
-                          (SC && uniform(ws[H_VAR]) != 0.0);
+        const bool over = (int)P::uni(ws[H_KS]) > kp.mKs || (int)P::uni(ws[H_KF]) > kp.mKf || (int)P::uni(ws[H_KD]) > kp.mKd ||
+                          (SC && P::uni(ws[H_VAR]) != 0.0);
         if (over) {
             if (lane < N) { io.u[(size_t)b * 2 * N + 2 * lane] = 0.0; io.u[(size_t)b * 2 * N + 2 * lane + 1] = 0.0; }
             if (lane == 0) {
@@ -896,7 +1011,7 @@ __global__ __launch_bounds__(WAVE, MINW) void solve_kernel_pair(KParams kp, Batc
         }
     }
     Ctx cx;
-    load_problem<NT, SC>(kp, ws, lds, cx);
+    load_problem<NT, SC, P>(kp, ws, lds, cx);
     // L-BFGS memory S, Y [mem][N][2]: in LDS (LBG = false) or in this problem's workspace record, i.e. in the
     // L2-resident HBM workspace (LBG = true: 6.4 KB less LDS per wavefront -> more resident wavefronts; the pairs are
     // streamed once per PANOC iteration, one pair ahead of the dot product that consumes them)
@@ -931,7 +1046,8 @@ __global__ __launch_bounds__(WAVE, MINW) void solve_kernel_pair(KParams kp, Batc
     double uv = u0v, uw = u0w;
     double c = kp.init_penalty;
     if (io.c0) { const double c0 = io.c0[b]; if (c0 > 0.0) c = c0; }
-    c = uniform(c);
+    c = P::uni(c);
+    double icm = P::uni(1.0 / fmax(c, 1.0));  // 1 / max(c, 1) of the augmented Lagrangian: changes with the penalty only
     ya = clampd(ya, -KC(K_YBOUND), KC(K_YBOUND)); yb = clampd(yb, -KC(K_YBOUND), KC(K_YBOUND));  // y <- Proj_Y(y), Y = [-1e12, 1e12]^n1
     // PANOC cache: vector state u, grad, u_half, gamma*fpr, direction (2 doubles per vector lane each);
     // ||grad||^2 and ||gradient_step - u_half||^2 are carried as scalars (they only enter the envelope)
@@ -968,53 +1084,61 @@ __global__ __launch_bounds__(WAVE, MINW) void solve_kernel_pair(KParams kp, Batc
     Prof prof; prof.start();
 #endif
 
-    // u_half <- Proj_U(base - gamma*grad); returns ||gradient_step - u_half||^2
+    // u_half <- Proj_U(base - gamma*grad); returns this lane's share of ||gradient_step - u_half||^2
     auto half_step = [&](double bv, double bw) -> double {
         const double sv = bv - gamma * gv, sw = bw - gamma * gw;
         hv = vl ? clampd(sv, kp.vmin, kp.vmax) : 0.0;
         hw = vl ? clampd(sw, -kp.wmax, kp.wmax) : 0.0;
         const double e0 = vl ? sv - hv : 0.0, e1 = vl ? sw - hw : 0.0;
-        return dot2r<RV>(e0, e1, e0, e1);
+        return __builtin_fma(e0, e0, e1 * e1);
     };
+    // the two sums of the forward-backward envelope at the point whose gradient is (gv, gw): ||grad||^2 and
+    // ||gradient_step - u_half||^2, in ONE packed reduction (bitwise the same totals as two separate ones)
+    auto envelope_sums = [&](double bv, double bw) {
+        const double e2 = half_step(bv, bw);
+        P::sum2(__builtin_fma(gv, gv, gw * gw), e2, gg, d2h);
+    };
+    double ip = 0.0;  // <grad, gamma*fpr> of the current step (Lipschitz test)
 
     for (;;) {
         PROF_MARK(10 + state);  // solver logic that led to this evaluation (by the state it was issued for)
         PROF_COUNT(16 + state);
         ++n_eval; n_eval_grad += want_grad ? 1 : 0;
-        eval_point<NT, SC>(kp, cx, ev, ew, c, ya, yb, want_grad, state == ST_OUTER, o PROF_PASS);
+        eval_point<NT, SC, P>(kp, cx, ev, ew, c, icm, ya, yb, want_grad, state == ST_OUTER, o PROF_PASS);
         bool step_begin = false;
 
         if (state == ST_INIT0) {
             // cost + gradient at u; perturbation for the local Lipschitz estimate: h_i = max(delta, eps*u_i)
-            cost = uniform(o.psi); gv = o.gv; gw = o.gw;
+            cost = P::uni(o.psi); gv = o.gv; gw = o.gw;
             const double h0 = vl ? ((EPS_LIP * uv > DELTA_LIP) ? EPS_LIP * uv : DELTA_LIP) : 0.0;
             const double h1 = vl ? ((EPS_LIP * uw > DELTA_LIP) ? EPS_LIP * uw : DELTA_LIP) : 0.0;
-            nh = uniform(sqrt(dot2r<RV>(h0, h1, h0, h1)));
+            nh = P::uni(sqrt(dot2r<P, RV>(h0, h1, h0, h1)));
             ev = uv + h0; ew = uw + h1; want_grad = true; state = ST_INIT1;
             continue;
         } else if (state == ST_INIT1) {
             const double d0 = o.gv - gv, d1 = o.gw - gw;
-            Lip = uniform(sqrt(dot2r<RV>(d0, d1, d0, d1)) / nh);
-            gamma = uniform(GAMMA_L_COEFF / fmax(Lip, MIN_L));
-            sigma = uniform(KC(K_SIGMA) / gamma);
-            gg = dot2r<RV>(gv, gw, gv, gw);
-            d2h = half_step(uv, uw);
+            Lip = P::uni(sqrt(dot2r<P, RV>(d0, d1, d0, d1)) / nh);
+            gamma = P::uni(GAMMA_L_COEFF / fmax(Lip, MIN_L));
+            sigma = P::uni(KC(K_SIGMA) / gamma);
+            envelope_sums(uv, uw);
             step_begin = true;
         } else if (state == ST_LIP) {
             const double cost_half = o.psi;
-            const double ip = dot2r<RV>(gv, gw, rv_, rw_);
             const double rhs_lip = cost + LIP_UPD_EPS * fabs(cost) - ip + (GAMMA_L_COEFF / (2.0 * gamma)) * nfpr * nfpr;
             if (cost_half > rhs_lip && lip_it < MAX_LIP_IT && Lip < MAX_LIP) {
                 lb_active = 0; lb_first = true;  // invalidate the L-BFGS buffer
-                Lip = uniform(Lip * 2.0); gamma = uniform(gamma * 0.5);
-                d2h = half_step(uv, uw);
+                Lip = P::uni(Lip * 2.0); gamma = P::uni(gamma * 0.5);
+                const double e2 = half_step(uv, uw);
                 rv_ = uv - hv; rw_ = uw - hw;
-                nfpr = uniform(sqrt(dot2r<RV>(rv_, rw_, rv_, rw_)));
+                double rr;
+                P::sum2(e2, __builtin_fma(rv_, rv_, rw_ * rw_), d2h, rr);
+                nfpr = P::uni(sqrt(rr));
+                ip = dot2r<P, RV>(gv, gw, rv_, rw_);
                 ++lip_it;
                 ev = hv; ew = hw; want_grad = false;
                 continue;
             }
-            sigma = uniform(KC(K_SIGMA) / gamma);
+            sigma = P::uni(KC(K_SIGMA) / gamma);
 #ifdef MPC_TRACE
             tr_psi_u = cost;
 #endif
@@ -1028,7 +1152,8 @@ __global__ __launch_bounds__(WAVE, MINW) void solve_kernel_pair(KParams kp, Batc
                     s0 = uv - LOLD[lane * 4]; s1 = uw - LOLD[lane * 4 + 1];
                     y0_ = rv_ - LOLD[lane * 4 + 2]; y1_ = rw_ - LOLD[lane * 4 + 3];
                 }
-                const double ys = dot2r<RV>(s0, s1, y0_, y1_), ss = dot2r<RV>(s0, s1, s0, s1);
+                double ys, ss;
+                P::sum2(__builtin_fma(s0, y0_, s1 * y1_), __builtin_fma(s0, s0, s1 * s1), ys, ss);
                 if (!(ss <= DBLMIN || ys <= KC(K_MIN_L)) && (ys / ss > KC(K_CBFGS) * nfpr)) {
                     lb_head = (lb_head + mem - 1) % mem;
                     if (vl) {
@@ -1037,7 +1162,7 @@ __global__ __launch_bounds__(WAVE, MINW) void solve_kernel_pair(KParams kp, Batc
                         LY[(lb_head * N + lane) * 2] = y0_; LY[(lb_head * N + lane) * 2 + 1] = y1_;
                     }
                     if (lane == 0) LRHO[lb_head] = 1.0 / ys;
-                    lb_gamma = uniform(ys / dot2r<RV>(y0_, y1_, y0_, y1_));
+                    lb_gamma = P::uni(ys / dot2r<P, RV>(y0_, y1_, y0_, y1_));
                     lb_active = (lb_active + 1 < mem) ? lb_active + 1 : mem;
                 }
             }
@@ -1061,7 +1186,7 @@ __global__ __launch_bounds__(WAVE, MINW) void solve_kernel_pair(KParams kp, Batc
                     const int sl = (lb_head + j) % mem;
                     double2 sn = sc, yn = yc;
                     if (j + 1 < lb_active) { const int nx = (lb_head + j + 1) % mem; sn = pair_at(LS, nx); yn = pair_at(LY, nx); }
-                    const double al = LRHO[sl] * dot2r<RV>(sc.x, sc.y, q0, q1);
+                    const double al = LRHO[sl] * dot2r<P, RV>(sc.x, sc.y, q0, q1);
                     if (lane == 0) LALPHA[j] = al;
                     q0 -= al * yc.x; q1 -= al * yc.y;
                     sc = sn; yc = yn;  // after the last step (sc, yc) still hold pair lb_active-1
@@ -1072,7 +1197,7 @@ __global__ __launch_bounds__(WAVE, MINW) void solve_kernel_pair(KParams kp, Batc
                     const int sl = (lb_head + j) % mem;
                     double2 sp = sc, yp = yc;
                     if (j > 0) { const int pv = (lb_head + j - 1) % mem; sp = pair_at(LS, pv); yp = pair_at(LY, pv); }
-                    const double be = LRHO[sl] * dot2r<RV>(yc.x, yc.y, q0, q1);
+                    const double be = LRHO[sl] * dot2r<P, RV>(yc.x, yc.y, q0, q1);
                     const double co = LALPHA[j] - be;
                     q0 += co * sc.x; q1 += co * sc.y;
                     sc = sp; yc = yp;
@@ -1081,7 +1206,7 @@ __global__ __launch_bounds__(WAVE, MINW) void solve_kernel_pair(KParams kp, Batc
                 for (int j = 0; j < lb_active; ++j) {
                     const int sl = (lb_head + j) % mem;
                     const double sj0 = vl ? LS[(sl * N + lane) * 2] : 0.0, sj1 = vl ? LS[(sl * N + lane) * 2 + 1] : 0.0;
-                    const double al = LRHO[sl] * dot2r<RV>(sj0, sj1, q0, q1);
+                    const double al = LRHO[sl] * dot2r<P, RV>(sj0, sj1, q0, q1);
                     if (lane == 0) LALPHA[j] = al;
                     if (vl) { q0 -= al * LY[(sl * N + lane) * 2]; q1 -= al * LY[(sl * N + lane) * 2 + 1]; }
                 }
@@ -1090,22 +1215,21 @@ __global__ __launch_bounds__(WAVE, MINW) void solve_kernel_pair(KParams kp, Batc
                 for (int j = lb_active - 1; j >= 0; --j) {
                     const int sl = (lb_head + j) % mem;
                     const double yj0 = vl ? LY[(sl * N + lane) * 2] : 0.0, yj1 = vl ? LY[(sl * N + lane) * 2 + 1] : 0.0;
-                    const double be = LRHO[sl] * dot2r<RV>(yj0, yj1, q0, q1);
+                    const double be = LRHO[sl] * dot2r<P, RV>(yj0, yj1, q0, q1);
                     const double co = LALPHA[j] - be;
                     if (vl) { q0 += co * LS[(sl * N + lane) * 2]; q1 += co * LS[(sl * N + lane) * 2 + 1]; }
                 }
             }
             dv = q0; dw = q1;
             // ---- line search on the forward-backward envelope
-            rhs = uniform((cost - 0.5 * gamma * gg + 0.5 * d2h / gamma) - sigma * nfpr * nfpr);
+            rhs = P::uni((cost - 0.5 * gamma * gg + 0.5 * d2h / gamma) - sigma * nfpr * nfpr);
             tau = 1.0; nls = 0;
             ev = uv - (1.0 - tau) * rv_ - tau * dv; ew = uw - (1.0 - tau) * rw_ - tau * dw;  // u_plus
             want_grad = true; state = ST_LS;
             continue;
         } else if (state == ST_NOLS) {
-            cost = uniform(o.psi); gv = o.gv; gw = o.gw;
-            gg = dot2r<RV>(gv, gw, gv, gw);
-            d2h = half_step(uv, uw);
+            cost = P::uni(o.psi); gv = o.gv; gw = o.gw;
+            envelope_sums(uv, uw);
 #ifdef MPC_TRACE
             tr_write(-1, 1.0);
 #endif
@@ -1113,12 +1237,11 @@ __global__ __launch_bounds__(WAVE, MINW) void solve_kernel_pair(KParams kp, Batc
             step_begin = true;
         } else if (state == ST_LS) {
             // (ev, ew) is the trial point u_plus
-            cost = uniform(o.psi); gv = o.gv; gw = o.gw;
-            gg = dot2r<RV>(gv, gw, gv, gw);
-            d2h = half_step(ev, ew);
+            cost = P::uni(o.psi); gv = o.gv; gw = o.gw;
+            envelope_sums(ev, ew);
             const double lhs = cost - 0.5 * gamma * gg + 0.5 * d2h / gamma;
             if (lhs > rhs && nls < MAX_LS_IT) {
-                tau = uniform(tau * 0.5); ++nls;
+                tau = P::uni(tau * 0.5); ++nls;
                 ev = uv - (1.0 - tau) * rv_ - tau * dv; ew = uw - (1.0 - tau) * rw_ - tau * dw;
                 want_grad = true;
                 continue;
@@ -1141,17 +1264,17 @@ __global__ __launch_bounds__(WAVE, MINW) void solve_kernel_pair(KParams kp, Batc
         } else {  // ST_OUTER: evaluated at the inner solution (c, y still those of the inner problem)
             inner_total += num_iter;
             last_fpr = nfpr;
-            f_final = uniform(o.f);
+            f_final = P::uni(o.f);
             // y+ <- y + c (F1(u) - Proj_C(F1(u) + y/c))
             double dy2l = 0.0, ypa = 0.0, ypb = 0.0;
             if (vl) {
                 const double za = o.F1a + ya / c, zb = o.F1b + yb / c;
                 ypa = ya + c * (o.F1a - clampd(za, kp.amin, kp.amax));
                 ypb = yb + c * (o.F1b - clampd(zb, -kp.aamax, kp.aamax));
-                dy2l = (ypa - ya) * (ypa - ya) + (ypb - yb) * (ypb - yb);
+                dy2l = __builtin_fma(ypa - ya, ypa - ya, (ypb - yb) * (ypb - yb));
             }
-            dy_norm_plus = uniform(sqrt(wave_sum_u<RV>(dy2l)));
-            f2_norm_plus = uniform(sqrt(o.nrm2F2));
+            dy_norm_plus = P::uni(sqrt(P::template sum<RV>(dy2l)));
+            f2_norm_plus = P::uni(sqrt(o.nrm2F2));
             const bool crit1 = alm_iteration > 0 && dy_norm_plus <= c * kp.delta_tol + SMALL_EPS;
             const bool crit2 = f2_norm_plus <= kp.delta_tol + SMALL_EPS;
             const bool crit3 = akkt_tol <= kp.tol + SMALL_EPS;
@@ -1173,8 +1296,8 @@ __global__ __launch_bounds__(WAVE, MINW) void solve_kernel_pair(KParams kp, Batc
             }
             const bool stall = alm_iteration == 0 || (dy_norm_plus <= kp.suff_decrease * dy_norm + SMALL_EPS &&
                                                       f2_norm_plus <= kp.suff_decrease * f2_norm + SMALL_EPS);
-            if (!stall) c = uniform(c * kp.penalty_update);
-            akkt_tol = uniform(fmax(akkt_tol * kp.tol_update, kp.tol));
+            if (!stall) { c = P::uni(c * kp.penalty_update); icm = P::uni(1.0 / fmax(c, 1.0)); }
+            akkt_tol = P::uni(fmax(akkt_tol * kp.tol_update, kp.tol));
             ++alm_iteration; ++num_outer;
             dy_norm = dy_norm_plus; f2_norm = f2_norm_plus;
             ya = clampd(ypa, -KC(K_YBOUND), KC(K_YBOUND)); yb = clampd(ypb, -KC(K_YBOUND), KC(K_YBOUND));  // y <- Proj_Y(y+)
@@ -1198,13 +1321,15 @@ __global__ __launch_bounds__(WAVE, MINW) void solve_kernel_pair(KParams kp, Batc
             }
             if (!inner_done) {
                 rv_ = uv - hv; rw_ = uw - hw;
-                nfpr = uniform(sqrt(dot2r<RV>(rv_, rw_, rv_, rw_)));
+                double rr;
+                P::sum2(__builtin_fma(rv_, rv_, rw_ * rw_), __builtin_fma(gv, rv_, gw * rw_), rr, ip);  // ||gamma fpr||^2, <grad, gamma fpr>
+                nfpr = P::uni(sqrt(rr));
                 bool ex = nfpr < kp.tol;
                 if (ex) {
                     // AKKT residual || gfpr/gamma + grad - grad_prev || < eps_nu.  grad_prev is the zero vector
                     // on the first step of an inner problem and the current gradient afterwards.
                     const double a0 = rv_ / gamma + (iter == 0 ? gv : 0.0), a1 = rw_ / gamma + (iter == 0 ? gw : 0.0);
-                    ex = sqrt(dot2r<RV>(a0, a1, a0, a1)) < akkt_tol;
+                    ex = sqrt(dot2r<P, RV>(a0, a1, a0, a1)) < akkt_tol;
                 }
                 if (ex) {
                     inner_done = true;
@@ -1226,7 +1351,7 @@ __global__ __launch_bounds__(WAVE, MINW) void solve_kernel_pair(KParams kp, Batc
 #endif
     // a NaN / inf anywhere in the iteration ends here too (every comparison with it is false): report it the way
     // OpEn does (SolverError::NotFiniteComputation) instead of returning the garbage as a solution
-    if (__ballot(vl && !(isfinite(uv) && isfinite(uw))) != 0ull || !isfinite(f_final)) status = 3;
+    if (P::any(vl && !(isfinite(uv) && isfinite(uw))) || !isfinite(f_final)) status = 3;
     // ---- write results (coalesced per problem)
     if (vl) {
         io.u[(size_t)b * 2 * N + 2 * lane] = uv;
@@ -1244,6 +1369,17 @@ __global__ __launch_bounds__(WAVE, MINW) void solve_kernel_pair(KParams kp, Batc
     }
 }
 
+template <int NT, bool SC, bool LBG, int MINW>
+__global__ __launch_bounds__(WAVE, MINW) void solve_kernel_pair(KParams kp, BatchPtrs io, int B) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    solve_body<NT, SC, LBG, Solo<NT>>(kp, io, B, lds);
+}
+// two problems per wavefront (grid = ceil(B / 2)); 2 wavefronts per SIMD = the same 16 resident problems per CU
+template <int NT, bool SC, bool LBG>
+__global__ __launch_bounds__(WAVE, 2) void solve_kernel_duo(KParams kp, BatchPtrs io, int B) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    solve_body<NT, SC, LBG, Duo<NT>>(kp, io, B, lds);
+}
 
 #undef GAMMA_L_COEFF
 #undef DELTA_LIP

@@ -40,6 +40,8 @@ struct Handle {
     bool shape_const = true;  // of the batch prepared last
     int last_min_waves = 0;   // launch-bounds variant of the last solve (3 or 4 wavefronts per SIMD)
     int num_cus = 256;
+    int pairing = -1;   // MPCGPU_OPT_PAIRING: -1 automatic, 0 one problem per wavefront, 1 two per wavefront (N_hor = 20)
+    int last_pairing = 0;  // layout of the last solve / cost_grad launch
     int trace_cap = 0;  // -DMPC_TRACE builds: PANOC steps recorded per problem (0 = tracing off)
     // mpcgpu_reserve_shape: upper bounds of active rows promised by the caller -> no count read-back before the launch
     bool capturing = false;  // the launch stream of the current call is being captured into a hipGraph: no event records
@@ -85,6 +87,14 @@ inline hipStream_t pick_stream(Handle* h, void* stream) {
 }
 
 inline int even(int x) { return (x + 1) & ~1; }
+
+// Two problems per wavefront (Duo layout, mpc_kernels.hpp) exist for the compiled horizon N_hor = 20.  Measured on the
+// benchmark batch it is SLOWER than one problem per wavefront (1631 vs 1274 ms for 32 768 solves: 11 % fewer VALU
+// instructions per solve, but 219 VGPRs and two LDS carves leave 2 wavefronts per SIMD and the kernel turns latency bound;
+// DESIGN.md section 7), so the automatic rule keeps one problem per wavefront and the layout stays an explicit option.
+// The choice never depends on the batch: results must not change with the batch a problem travels in.
+inline bool duo_available(const Handle* h) { return h->kp.N == 20; }
+inline bool use_duo(const Handle* h) { return duo_available(h) && h->pairing == 1; }
 
 // Where the L-BFGS memory (2 x 10 x 2N doubles per problem) lives.  true: in the problem's workspace record (HBM,
 // L2-resident while the solve runs), which frees 6.4 KB of LDS per wavefront at N = 20; false: in LDS.
@@ -206,6 +216,7 @@ int prepare(Handle* h, int B, const double* d_p, hipStream_t s, BatchPtrs& io, b
     const int lds_bytes = h->kp.l_total * (int)sizeof(double);
     h->last_shape[0] = mKs; h->last_shape[1] = mKf; h->last_shape[2] = mKd; h->last_shape[3] = lds_bytes;
     if (lds_bytes > 160 * 1024) return fail(h, -5, "LDS carve of %d bytes exceeds 160 KiB", lds_bytes);
+    h->last_pairing = use_duo(h) && 2 * lds_bytes <= 160 * 1024 ? 1 : 0;
     return 0;
 }
 
@@ -340,6 +351,17 @@ int32_t mpcgpu_solve_batch_dev(void* handle, int32_t B, const double* p, const d
     const bool sc = h->shape_const;
     const bool four = MPC_TRY_FOUR_WAVES && lds <= 10 * 1024 && B > 4 * MPC_MIN_WAVES * h->num_cus;
     h->last_min_waves = four && h->kp.N == 20 ? 4 : MPC_MIN_WAVES;
+#define LAUNCH_DUO(NT, SC)                                                                                          \
+    do {                                                                                                             \
+        auto kern = solve_kernel_duo<NT, SC, LBFGS_IN_WORKSPACE>;                                                    \
+        if (2 * lds > 64 * 1024)                                                                                     \
+            HIP_OK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds)));  \
+        hipLaunchKernelGGL(kern, dim3((B + 1) / 2), dim3(WAVE), 2 * lds, s, h->kp, io, B);                           \
+    } while (0)
+    if (h->last_pairing) {
+        h->last_min_waves = 2;
+        if (sc) LAUNCH_DUO(20, true); else LAUNCH_DUO(20, false);
+    } else
     switch (h->kp.N) {
         case 20:
             if (four) { if (sc) LAUNCH_PAIR_W(20, true, 4); else LAUNCH_PAIR_W(20, false, 4); }
@@ -348,6 +370,7 @@ int32_t mpcgpu_solve_batch_dev(void* handle, int32_t B, const double* p, const d
         case 40: if (sc) LAUNCH_PAIR(40, true); else LAUNCH_PAIR(40, false); break;
         default: if (sc) LAUNCH_PAIR(0, true); else LAUNCH_PAIR(0, false); break;
     }
+#undef LAUNCH_DUO
 #undef LAUNCH_PAIR
 #undef LAUNCH_PAIR_W
     HIP_OK(h, hipGetLastError());
@@ -424,28 +447,33 @@ int32_t mpcgpu_cost_grad_batch(void* handle, int32_t B, const double* u, const d
     BatchPtrs io{};
     if (int r = prepare(h, B, (const double*)h->p.ptr, s, io, false)) return r;
     const size_t lds_cg = h->kp.l_total * sizeof(double);
-#define LAUNCH_CG(NT, SC)                                                                                          \
+#define LAUNCH_CG(NT, SC, PP, GRID, LDSB)                                                                           \
     do {                                                                                                             \
-        auto kern = cost_grad_kernel<NT, SC>;                                                                        \
-        if (lds_cg > 64 * 1024)                                                                                      \
-            HIP_OK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cg)); \
-        hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE), lds_cg, s, h->kp, io, (const double*)h->u.ptr,                 \
+        auto kern = cost_grad_kernel<NT, SC, PP>;                                                                    \
+        if ((LDSB) > 64 * 1024)                                                                                      \
+            HIP_OK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDSB))); \
+        hipLaunchKernelGGL(kern, dim3(GRID), dim3(WAVE), (LDSB), s, h->kp, io, (const double*)h->u.ptr,              \
                            (const double*)h->xi.ptr, (double*)h->psi.ptr, (double*)h->f.ptr, (double*)h->grad.ptr,   \
                            (double*)h->F1.ptr, (double*)h->F2.ptr, B);                                               \
     } while (0)
-    if (h->shape_const) {
+#define LAUNCH_CG1(NT, SC) LAUNCH_CG(NT, SC, Solo<NT>, B, lds_cg)
+    if (h->last_pairing) {
+        if (h->shape_const) LAUNCH_CG(20, true, Duo<20>, (B + 1) / 2, 2 * lds_cg);
+        else LAUNCH_CG(20, false, Duo<20>, (B + 1) / 2, 2 * lds_cg);
+    } else if (h->shape_const) {
         switch (h->kp.N) {
-            case 20: LAUNCH_CG(20, true); break;
-            case 40: LAUNCH_CG(40, true); break;
-            default: LAUNCH_CG(0, true); break;
+            case 20: LAUNCH_CG1(20, true); break;
+            case 40: LAUNCH_CG1(40, true); break;
+            default: LAUNCH_CG1(0, true); break;
         }
     } else {
         switch (h->kp.N) {
-            case 20: LAUNCH_CG(20, false); break;
-            case 40: LAUNCH_CG(40, false); break;
-            default: LAUNCH_CG(0, false); break;
+            case 20: LAUNCH_CG1(20, false); break;
+            case 40: LAUNCH_CG1(40, false); break;
+            default: LAUNCH_CG1(0, false); break;
         }
     }
+#undef LAUNCH_CG1
 #undef LAUNCH_CG
     HIP_OK(h, hipGetLastError());
     if (psi) HIP_OK(h, hipMemcpyAsync(psi, h->psi.ptr, Bz * 8, hipMemcpyDeviceToHost, s));
@@ -523,6 +551,11 @@ int32_t mpcgpu_set_option(void* handle, int32_t option, double value) {
             if (value != 0.0 && value != 1.0) return fail(h, -1, "linesearch fallback must be 0 (last trial) or 1 (tau = 0), got %g", value);
             h->kp.ls_fallback = (int)value;
             return 0;
+        case MPCGPU_OPT_PAIRING:
+            if (value != -1.0 && value != 0.0 && value != 1.0) return fail(h, -1, "pairing must be -1 (automatic), 0 or 1, got %g", value);
+            if (value == 1.0 && !duo_available(h)) return fail(h, -1, "two problems per wavefront are compiled for N_hor = 20 only (N_hor = %d)", h->kp.N);
+            h->pairing = (int)value;
+            return 0;
         default:
             return fail(h, -1, "unknown option %d", option);
     }
@@ -551,6 +584,11 @@ int32_t mpcgpu_debug_read_trace(void* handle, int32_t B, double* out) {
 int32_t mpcgpu_last_waves_per_simd(void* handle) {
     Handle* h = (Handle*)handle;
     return h ? h->last_min_waves : -1;
+}
+
+int32_t mpcgpu_last_problems_per_wavefront(void* handle) {
+    Handle* h = (Handle*)handle;
+    return h ? 1 + h->last_pairing : -1;
 }
 
 #ifdef MPC_PROFILE
