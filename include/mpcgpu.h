@@ -157,14 +157,21 @@ int32_t mpcgpu_reserve_shape(void* handle, int32_t max_static, int32_t max_fleet
  *        1           two problems per wavefront (rows 0-1 / rows 2-3; compiled for N_hor = 20, error for other horizons)
  *     The choice never depends on the batch.  Both layouts run the same source (csrc/mpc_kernels.hpp, lane models Solo / Duo);
  *     their results differ by floating-point summation order only.
+ *   MPCGPU_OPT_TEAM_BATCH  largest batch that is solved by the LATENCY kernel (csrc/mpc_team.hpp: one problem per workgroup of
+ *       four wavefronts that evaluate the Lipschitz test and the line-search trials of a PANOC step side by side; compaction
+ *       fused; LDS carve from the configured maxima, nothing read back before the launch).  -1 (default): 2 x the number of
+ *       compute units; 0 switches it off.  Compiled for N_hor = 20; results are bitwise those of the throughput kernel.
  */
-enum { MPCGPU_OPT_LINESEARCH_FALLBACK = 1, MPCGPU_OPT_PAIRING = 2 };
+enum { MPCGPU_OPT_LINESEARCH_FALLBACK = 1, MPCGPU_OPT_PAIRING = 2, MPCGPU_OPT_TEAM_BATCH = 3 };
 int32_t mpcgpu_set_option(void* handle, int32_t option, double value);
 
 /* Register-allocation variant the last solve call was launched with: 3 (148 VGPRs, no spills) or 4 wavefronts per SIMD
  * (128 VGPRs; chosen when the LDS carve fits 16 times into a CU and the batch exceeds 12 problems per CU).  Both give
  * bitwise identical results. */
 int32_t mpcgpu_last_waves_per_simd(void* handle);
+
+/* 1 when the last solve call ran the latency kernel (MPCGPU_OPT_TEAM_BATCH), else 0. */
+int32_t mpcgpu_last_latency_kernel(void* handle);
 
 /* Problems per wavefront of the last solve / cost_grad launch: 1 or 2 (MPCGPU_OPT_PAIRING). */
 int32_t mpcgpu_last_problems_per_wavefront(void* handle);

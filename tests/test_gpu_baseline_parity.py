@@ -173,8 +173,8 @@ def test_lbfgs_in_lds_build_is_bitwise_equal_to_the_product_build(N, B):
     (measured).  The LDS variant must give the very same bits."""
     cfg = make_cfg(N)
     sc = scenes.make_batch(cfg, B, n_dyn=8, seed=31 + N, dyn_clearance=0.1, box_clearance=0.3)
-    a = BatchSolver(cfg)
-    b = BatchSolver(cfg, library=variant_path("lbfgs_lds"))
+    a = BatchSolver(cfg, latency_batch=0)           # throughput kernel on both sides (the latency kernel keeps S, Y in LDS anyway)
+    b = BatchSolver(cfg, library=variant_path("lbfgs_lds"), latency_batch=0)
     ra, rb = a.solve(sc["p"]), b.solve(sc["p"])
     assert b.last_shape()["lds_bytes"] > a.last_shape()["lds_bytes"] + 2 * 10 * 2 * N * 8   # S and Y really are in LDS
     assert np.array_equal(ra.solution, rb.solution)

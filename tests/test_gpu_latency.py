@@ -1,0 +1,85 @@
+"""GPU (-m gpu): the latency kernel (csrc/mpc_team.hpp: one problem per workgroup of four wavefronts, Lipschitz test and
+line-search trials of a PANOC step evaluated side by side, compaction fused, no count read-back) against the throughput
+kernel (one problem per wavefront, sequential evaluations).  Same device functions on the same inputs: every output must be
+BITWISE equal -- solutions, costs, statuses, iteration counts, multipliers and the evaluation counts of the sequential
+algorithm.  The reference's own call pattern is one problem per call (src/interface_mpc.py:82-88)."""
+import numpy as np
+import pytest
+
+from conftest import make_cfg
+from trajtrack_mpcndqn_rlboost_amd import BatchSolver, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b):
+    assert np.array_equal(a.solution, b.solution)
+    assert np.array_equal(a.cost, b.cost, equal_nan=True)
+    assert np.array_equal(a.status, b.status)
+    assert np.array_equal(a.num_inner_iterations, b.num_inner_iterations)
+    assert np.array_equal(a.num_outer_iterations, b.num_outer_iterations)
+    assert np.array_equal(a.last_problem_norm_fpr, b.last_problem_norm_fpr)
+    assert np.array_equal(a.f2_norm, b.f2_norm)
+    assert np.array_equal(a.lagrange_multipliers, b.lagrange_multipliers)
+
+
+FAMILIES = {
+    "benchmark (cap-limited, hard constraints active)": dict(n_dyn=8),
+    "passing (about half converge)": dict(n_dyn=8, dyn_clearance=0.1, box_clearance=0.3),
+    "free corridor (converge quickly)": dict(n_dyn=0, with_box=False, v_init_range=(1.0, 1.2)),
+    "fleet + few obstacles": dict(n_dyn=3, n_other=2),
+}
+
+
+@pytest.mark.parametrize("family", list(FAMILIES))
+@pytest.mark.parametrize("fallback", ["last_trial", "half_step"])
+def test_latency_kernel_is_bitwise_equal_to_the_throughput_kernel(family, fallback):
+    cfg = make_cfg(20, solver_linesearch_fallback=fallback)
+    B = 40
+    sc = scenes.make_batch(cfg, B, seed=97, **FAMILIES[family])
+    fast = BatchSolver(cfg)                       # library rule: latency kernel for small batches
+    seq = BatchSolver(cfg, latency_batch=0)       # throughput kernel only
+    for u0 in (None, np.tile([0.6, 0.1], (B, 20))):
+        a, b = fast.solve(sc["p"], u0), seq.solve(sc["p"], u0)
+        assert fast.last_shape()["latency_kernel"] and not seq.last_shape()["latency_kernel"]
+        _same(a, b)
+        ea, eb = fast.last_eval_counts(B), seq.last_eval_counts(B)
+        assert np.array_equal(ea[0], eb[0]) and np.array_equal(ea[1], eb[1])
+    print(f"\n[{family}, {fallback}] statuses {np.bincount(a.status, minlength=3).tolist()}, inner iterations "
+          f"{a.num_inner_iterations.min()}..{a.num_inner_iterations.max()}")
+    fast.close(); seq.close()
+
+
+def test_latency_kernel_with_short_caps_warm_start_and_multipliers():
+    """Iteration caps that end inner problems mid-way, a warm start with multipliers and penalty handed in."""
+    cfg = make_cfg(20, solver_max_inner_iterations=7, solver_max_outer_iterations=3)
+    B = 24
+    sc = scenes.make_batch(cfg, B, n_dyn=6, seed=5)
+    rng = np.random.default_rng(5)
+    u0 = np.stack([rng.uniform(0.0, 1.2, (B, 20)), rng.uniform(-0.4, 0.4, (B, 20))], axis=2).reshape(B, 40)
+    y0 = rng.normal(0.0, 0.3, (B, 40))
+    c0 = rng.uniform(5.0, 200.0, B)
+    fast, seq = BatchSolver(cfg), BatchSolver(cfg, latency_batch=0)
+    _same(fast.solve(sc["p"], u0, y0, c0), seq.solve(sc["p"], u0, y0, c0))
+    assert fast.last_shape()["latency_kernel"]
+    fast.close(); seq.close()
+
+
+def test_selection_rule_and_single_problem_call():
+    cfg = make_cfg(20)
+    sc = scenes.make_batch(cfg, 1024, n_dyn=4, seed=3, dyn_clearance=0.1, box_clearance=0.3)
+    bs = BatchSolver(cfg)
+    big = bs.solve(sc["p"])
+    assert not bs.last_shape()["latency_kernel"]                  # 1024 > 2 x 256 compute units
+    one = bs.solve(sc["p"][17])
+    assert bs.last_shape()["latency_kernel"]
+    assert np.array_equal(one.solution[0], big.solution[17]) and one.status[0] == big.status[17]
+    few = bs.solve(sc["p"][100:108])
+    assert np.array_equal(few.solution, big.solution[100:108])
+    bs.close()
+    # a horizon without the compiled latency kernel keeps the throughput kernel
+    cfg12 = make_cfg(12, solver_max_inner_iterations=10, solver_max_outer_iterations=2)
+    bs = BatchSolver(cfg12)
+    bs.solve(scenes.make_batch(cfg12, 4, n_dyn=2, seed=1)["p"])
+    assert not bs.last_shape()["latency_kernel"]
+    bs.close()

@@ -514,7 +514,7 @@ def test_both_register_allocation_variants_give_bitwise_identical_solutions():
     carve exceeds 10 KiB, and the 128-VGPR build (4 wavefronts/SIMD, a few spilled registers) otherwise.  Same
     arithmetic: the same problems must come out bitwise equal from both."""
     cfg = make_cfg(20)
-    bs = BatchSolver(cfg)
+    bs = BatchSolver(cfg, latency_batch=0)          # the throughput kernel's two builds (small batches would take the latency kernel)
     big = scenes.make_batch(cfg, 4096, n_dyn=8, seed=77)
     res_big = bs.solve(big["p"])
     shape = bs.last_shape()

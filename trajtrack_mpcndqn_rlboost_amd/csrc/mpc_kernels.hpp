@@ -89,6 +89,7 @@ struct KParams {
     int mKs, mKf, mKd;
     int reserved;  // 1: the carve comes from mpcgpu_reserve_shape, problems are checked against it on the device
     int l_seg, l_stc, l_fxy, l_dyn, l_dync, l_qd, l_pos, l_H, l_W, l_part, l_stash, l_hd, l_S, l_Y, l_rho, l_alpha, l_old, l_total;
+    int l_wstride, l_xch;  // team kernel (mpc_team.hpp): doubles per wavefront work block, offset of the exchange area
 };
 
 // compile-time horizon NT (0 = runtime horizon from KParams; DPP row counts then cover the whole wave)
@@ -373,13 +374,10 @@ __device__ __forceinline__ void sincos_small(double x, const double* k, double& 
 //   * all-zero dynamic-obstacle rows are `npd` identical ellipses (rx=ry=0, alpha=0) at the origin -> closed form
 // one 64-thread block per problem.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WAVE) void prep_kernel(KParams kp, BatchPtrs io, int B) {
-    const int b = blockIdx.x;
-    if (b >= B) return;
-    const int lane = threadIdx.x;
+// One wavefront compacts problem b (lane = its lane index 0..63).  `counts` may be NULL (no batch maxima wanted).
+__device__ __forceinline__ void prep_problem(const KParams& kp, const double* __restrict__ p, double* __restrict__ ws,
+                                             int* counts, int lane) {
     const int N = kp.N;
-    const double* __restrict__ p = io.p + (size_t)b * kp.np;
-    double* __restrict__ ws = io.ws + (size_t)b * kp.ws_stride;
 
     if (lane < 18) ws[lane] = p[lane];
     if (lane == 0) {
@@ -469,7 +467,7 @@ __global__ __launch_bounds__(WAVE) void prep_kernel(KParams kp, BatchPtrs io, in
             s_entry[lane] = idx;
         }
         if (lane == 0) ws[H_NPD] = (double)(kp.Ndynobs - Kd);
-        __syncthreads();
+        wave_sync();  // s_entry is exchanged inside ONE wavefront
         // (row, step) items: sincos of the ellipse angle and the inverse squared semi-axes, once per solve
         for (int t = lane; t < kp.Ndynobs * N; t += WAVE) {
             const int i = t / N, k = t - i * N;
@@ -492,11 +490,18 @@ __global__ __launch_bounds__(WAVE) void prep_kernel(KParams kp, BatchPtrs io, in
     const bool any_var = __ballot(varshape) != 0ull;
     if (lane == 0) {
         ws[H_KS] = (double)Ks; ws[H_KF] = (double)Kf; ws[H_KD] = (double)Kd; ws[H_VAR] = any_var ? 1.0 : 0.0;
-        atomicMax(io.counts + CNT_KS, Ks);
-        atomicMax(io.counts + CNT_KF, Kf);
-        atomicMax(io.counts + CNT_KD, Kd);
-        if (any_var) atomicMax(io.counts + CNT_VARSHAPE, 1);
+        if (counts) {
+            atomicMax(counts + CNT_KS, Ks);
+            atomicMax(counts + CNT_KF, Kf);
+            atomicMax(counts + CNT_KD, Kd);
+            if (any_var) atomicMax(counts + CNT_VARSHAPE, 1);
+        }
     }
+}
+__global__ __launch_bounds__(WAVE) void prep_kernel(KParams kp, BatchPtrs io, int B) {
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    prep_problem(kp, io.p + (size_t)b * kp.np, io.ws + (size_t)b * kp.ws_stride, io.counts, threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -973,25 +978,219 @@ __global__ __launch_bounds__(WAVE) void cost_grad_kernel(KParams kp, BatchPtrs i
 // ------------------------------------------------------------------------------------------------
 enum { ST_INIT0 = 0, ST_INIT1, ST_LIP, ST_NOLS, ST_LS, ST_OUTER };
 
-// The fused form is spelled out: under -ffp-contract=fast `a0*b0 + a1*b1` may become fma(a0,b0,a1*b1) in one
-// instantiation of the solver kernel and fma(a1,b1,a0*b0) in another, and the L-BFGS-in-LDS and workspace builds must agree
-// bit for bit (tests/test_gpu_baseline_parity.py).
+#ifndef MPC_MIN_WAVES
+#define MPC_MIN_WAVES 3  // waves per SIMD the register allocator must leave room for (512 / MPC_MIN_WAVES VGPRs)
+#endif
+
+// ------------------------------------------------------------------------------------------------
+// The steps of the iteration [OpEn], shared by every solver kernel (solve_body below, mpc_team.hpp): the same device
+// function on the same inputs gives the same bits.  (The library is built with -ffp-contract=on: an expression is
+// contracted the way it is written, whatever code surrounds it after inlining.)
+// Each use of a double literal reads the LDS table (KC): a local copy would live in two VGPRs across the whole loop.
+// ------------------------------------------------------------------------------------------------
 template <class P, int ROWS>
 __device__ __forceinline__ double dot2r(double a0, double a1, double b0, double b1) {
     return P::template sum<ROWS>(__builtin_fma(a0, b0, a1 * b1));
 }
+// perturbation of the local Lipschitz estimate: h_i = max(delta, eps * u_i); nh = ||h||
+template <class P>
+__device__ __forceinline__ void panoc_lip_perturbation(const Ctx& cx, bool vl, double uv, double uw, double& h0, double& h1, double& nh) {
+    h0 = vl ? ((KC(K_EPS_LIP) * uv > KC(K_DELTA_LIP)) ? KC(K_EPS_LIP) * uv : KC(K_DELTA_LIP)) : 0.0;
+    h1 = vl ? ((KC(K_EPS_LIP) * uw > KC(K_DELTA_LIP)) ? KC(K_EPS_LIP) * uw : KC(K_DELTA_LIP)) : 0.0;
+    nh = P::uni(sqrt(dot2r<P, P::RV>(h0, h1, h0, h1)));
+}
+// L = ||grad(u + h) - grad(u)|| / ||h||, gamma = 0.95 / L, sigma = 0.05 / (4 gamma)
+template <class P>
+__device__ __forceinline__ void panoc_lip_estimate(const Ctx& cx, double d0, double d1, double nh, double& Lip, double& gamma, double& sigma) {
+    Lip = P::uni(sqrt(dot2r<P, P::RV>(d0, d1, d0, d1)) / nh);
+    gamma = P::uni(KC(K_GAMMA_L) / fmax(Lip, KC(K_MIN_L)));
+    sigma = P::uni(KC(K_SIGMA) / gamma);
+}
+// u_half <- Proj_U(base - gamma * grad); returns this lane's share of ||gradient_step - u_half||^2
+__device__ __forceinline__ double panoc_half_step(const KParams& kp, bool vl, double bv, double bw, double gamma, double g0, double g1,
+                                                  double& hv, double& hw) {
+    const double sv = bv - gamma * g0, sw = bw - gamma * g1;
+    hv = vl ? clampd(sv, kp.vmin, kp.vmax) : 0.0;
+    hw = vl ? clampd(sw, -kp.wmax, kp.wmax) : 0.0;
+    const double e0 = vl ? sv - hv : 0.0, e1 = vl ? sw - hw : 0.0;
+    return __builtin_fma(e0, e0, e1 * e1);
+}
+// half step from (bv, bw) plus the two sums of the forward-backward envelope there, ||grad||^2 and
+// ||gradient_step - u_half||^2, in ONE packed reduction
+template <class P>
+__device__ __forceinline__ void panoc_envelope_sums(const KParams& kp, bool vl, double bv, double bw, double gamma, double g0, double g1,
+                                                    double& hv, double& hw, double& gg, double& d2h) {
+    const double e2 = panoc_half_step(kp, vl, bv, bw, gamma, g0, g1, hv, hw);
+    P::sum2(__builtin_fma(g0, g0, g1 * g1), e2, gg, d2h);
+}
+__device__ __forceinline__ double panoc_fbe(double cost, double gamma, double gg, double d2h) {
+    return cost - 0.5 * gamma * gg + 0.5 * d2h / gamma;
+}
+__device__ __forceinline__ double panoc_fbe_rhs(double cost, double gamma, double gg, double d2h, double sigma, double nfpr) {
+    return panoc_fbe(cost, gamma, gg, d2h) - sigma * nfpr * nfpr;
+}
+__device__ __forceinline__ double panoc_trial(double u, double r, double d, double tau) { return u - (1.0 - tau) * r - tau * d; }
+// Lipschitz test: psi(u_half) > psi(u) + eps |psi(u)| - <grad, gamma fpr> + (0.95 / (2 gamma)) ||gamma fpr||^2
+__device__ __forceinline__ bool panoc_lip_test_fails(const Ctx& cx, double cost_half, double cost, double ip, double gamma, double nfpr) {
+    const double rhs_lip = cost + KC(K_EPS_LIP) * fabs(cost) - ip + (KC(K_GAMMA_L) / (2.0 * gamma)) * nfpr * nfpr;
+    return cost_half > rhs_lip;
+}
+// L <- 2L, gamma <- gamma / 2, new half step, fpr and the sums that belong to it
+template <class P>
+__device__ __forceinline__ void panoc_lip_update(const KParams& kp, bool vl, double uv, double uw, double gv, double gw, double& Lip,
+                                                 double& gamma, double& hv, double& hw, double& rv, double& rw, double& d2h,
+                                                 double& nfpr, double& ip) {
+    Lip = P::uni(Lip * 2.0); gamma = P::uni(gamma * 0.5);
+    const double e2 = panoc_half_step(kp, vl, uv, uw, gamma, gv, gw, hv, hw);
+    rv = uv - hv; rw = uw - hw;
+    double rr;
+    P::sum2(e2, __builtin_fma(rv, rv, rw * rw), d2h, rr);
+    nfpr = P::uni(sqrt(rr));
+    ip = dot2r<P, P::RV>(gv, gw, rv, rw);
+}
+// gamma*fpr of the step, its norm, <grad, gamma fpr>; true when the inner problem is solved: ||gamma fpr|| < eps and the
+// AKKT residual || gfpr/gamma + grad - grad_prev || < eps_nu (grad_prev is the zero vector on the first step of an inner
+// problem and the current gradient afterwards)
+template <class P>
+__device__ __forceinline__ bool panoc_step_residual(const Ctx& cx, const KParams& kp, bool vl, double uv, double uw, double hv, double hw,
+                                                    double gv, double gw, double gamma, int iter, double akkt_tol, double& rv,
+                                                    double& rw, double& nfpr, double& ip) {
+    rv = uv - hv; rw = uw - hw;
+    double rr;
+    P::sum2(__builtin_fma(rv, rv, rw * rw), __builtin_fma(gv, rv, gw * rw), rr, ip);
+    nfpr = P::uni(sqrt(rr));
+    bool ex = nfpr < kp.tol;
+    if (ex) {
+        const double a0 = rv / gamma + (iter == 0 ? gv : 0.0), a1 = rw / gamma + (iter == 0 ? gw : 0.0);
+        ex = sqrt(dot2r<P, P::RV>(a0, a1, a0, a1)) < akkt_tol;
+    }
+    return ex;
+}
 
-#ifndef MPC_MIN_WAVES
-#define MPC_MIN_WAVES 3  // waves per SIMD the register allocator must leave room for (512 / MPC_MIN_WAVES VGPRs)
-#endif
+// L-BFGS buffer of PANOC [crate lbfgs: C-BFGS acceptance]: ring of `mem` pairs (s, y) = (delta u, delta gamma*fpr), newest at
+// `head`; S, Y [mem][N][2], OLD [N][4] = previous (u, gamma*fpr), RHO [mem].
+struct PanocLbfgs {
+    int active = 0, head = 0;
+    bool first = true;
+    double hgamma = 1.0;  // s'y / y'y of the newest pair
+    __device__ __forceinline__ void flush() { active = 0; first = true; }
+    template <class P>
+    __device__ __forceinline__ void update(const Ctx& cx, bool vl, int lane, int N, int mem, double uv, double uw, double rv, double rw,
+                                           double nfpr, double* LS, double* LY, double* LOLD, double* LRHO) {
+        if (first) {
+            first = false;
+            if (vl) { LOLD[lane * 4] = uv; LOLD[lane * 4 + 1] = uw; LOLD[lane * 4 + 2] = rv; LOLD[lane * 4 + 3] = rw; }
+            return;
+        }
+        double s0 = 0, s1 = 0, y0_ = 0, y1_ = 0;
+        if (vl) {
+            s0 = uv - LOLD[lane * 4]; s1 = uw - LOLD[lane * 4 + 1];
+            y0_ = rv - LOLD[lane * 4 + 2]; y1_ = rw - LOLD[lane * 4 + 3];
+        }
+        double ys, ss;
+        P::sum2(__builtin_fma(s0, y0_, s1 * y1_), __builtin_fma(s0, s0, s1 * s1), ys, ss);
+        if (!(ss <= KC(K_DBLMIN) || ys <= KC(K_MIN_L)) && (ys / ss > KC(K_CBFGS) * nfpr)) {
+            head = (head + mem - 1) % mem;
+            if (vl) {
+                LOLD[lane * 4] = uv; LOLD[lane * 4 + 1] = uw; LOLD[lane * 4 + 2] = rv; LOLD[lane * 4 + 3] = rw;
+                LS[(head * N + lane) * 2] = s0; LS[(head * N + lane) * 2 + 1] = s1;
+                LY[(head * N + lane) * 2] = y0_; LY[(head * N + lane) * 2 + 1] = y1_;
+            }
+            if (lane == 0) LRHO[head] = 1.0 / ys;
+            hgamma = P::uni(ys / dot2r<P, P::RV>(y0_, y1_, y0_, y1_));
+            active = (active + 1 < mem) ? active + 1 : mem;
+        }
+    }
+    // d = H * (gamma*fpr): two-loop recursion, newest pair first.  LBG: S, Y live in the workspace record (global memory):
+    // pair j+1 is requested before pair j is consumed.
+    template <class P, bool LBG>
+    __device__ __forceinline__ void direction(bool vl, int lane, int N, int mem, double rv, double rw, const double* LS, const double* LY,
+                                              const double* LRHO, double* LALPHA, double& dv, double& dw) const {
+        double q0 = rv, q1 = rw;
+        if (LBG) {
+            auto pair_at = [&](const double* base, int sl) -> double2 {
+                return vl ? *reinterpret_cast<const double2*>(base + (sl * N + lane) * 2) : make_double2(0.0, 0.0);
+            };
+            double2 sc = make_double2(0.0, 0.0), yc = sc;
+            if (active > 0) { sc = pair_at(LS, head); yc = pair_at(LY, head); }
+            for (int j = 0; j < active; ++j) {
+                const int sl = (head + j) % mem;
+                double2 sn = sc, yn = yc;
+                if (j + 1 < active) { const int nx = (head + j + 1) % mem; sn = pair_at(LS, nx); yn = pair_at(LY, nx); }
+                const double al = LRHO[sl] * dot2r<P, P::RV>(sc.x, sc.y, q0, q1);
+                if (lane == 0) LALPHA[j] = al;
+                q0 -= al * yc.x; q1 -= al * yc.y;
+                sc = sn; yc = yn;  // after the last step (sc, yc) still hold pair active-1
+            }
+            wave_sync();
+            if (active > 0) { q0 *= hgamma; q1 *= hgamma; }
+            for (int j = active - 1; j >= 0; --j) {
+                const int sl = (head + j) % mem;
+                double2 sp = sc, yp = yc;
+                if (j > 0) { const int pv = (head + j - 1) % mem; sp = pair_at(LS, pv); yp = pair_at(LY, pv); }
+                const double be = LRHO[sl] * dot2r<P, P::RV>(yc.x, yc.y, q0, q1);
+                const double co = LALPHA[j] - be;
+                q0 += co * sc.x; q1 += co * sc.y;
+                sc = sp; yc = yp;
+            }
+        } else {
+            for (int j = 0; j < active; ++j) {
+                const int sl = (head + j) % mem;
+                const double sj0 = vl ? LS[(sl * N + lane) * 2] : 0.0, sj1 = vl ? LS[(sl * N + lane) * 2 + 1] : 0.0;
+                const double al = LRHO[sl] * dot2r<P, P::RV>(sj0, sj1, q0, q1);
+                if (lane == 0) LALPHA[j] = al;
+                if (vl) { q0 -= al * LY[(sl * N + lane) * 2]; q1 -= al * LY[(sl * N + lane) * 2 + 1]; }
+            }
+            wave_sync();
+            if (active > 0) { q0 *= hgamma; q1 *= hgamma; }
+            for (int j = active - 1; j >= 0; --j) {
+                const int sl = (head + j) % mem;
+                const double yj0 = vl ? LY[(sl * N + lane) * 2] : 0.0, yj1 = vl ? LY[(sl * N + lane) * 2 + 1] : 0.0;
+                const double be = LRHO[sl] * dot2r<P, P::RV>(yj0, yj1, q0, q1);
+                const double co = LALPHA[j] - be;
+                if (vl) { q0 += co * LS[(sl * N + lane) * 2]; q1 += co * LS[(sl * N + lane) * 2 + 1]; }
+            }
+        }
+        dv = q0; dw = q1;
+    }
+};
+
+// ALM / PM outer step: y+ <- y + c (F1(u) - Proj_C(F1(u) + y/c)); ||y+ - y||
+template <class P>
+__device__ __forceinline__ void alm_multiplier_step(const KParams& kp, bool vl, double F1a, double F1b, double ya, double yb, double c,
+                                                    double& ypa, double& ypb, double& dy_norm_plus) {
+    double dy2l = 0.0;
+    ypa = 0.0; ypb = 0.0;
+    if (vl) {
+        const double za = F1a + ya / c, zb = F1b + yb / c;
+        ypa = ya + c * (F1a - clampd(za, kp.amin, kp.amax));
+        ypb = yb + c * (F1b - clampd(zb, -kp.aamax, kp.aamax));
+        dy2l = __builtin_fma(ypa - ya, ypa - ya, (ypb - yb) * (ypb - yb));
+    }
+    dy_norm_plus = P::uni(sqrt(P::template sum<P::RV>(dy2l)));
+}
+__device__ __forceinline__ bool alm_exit(const Ctx& cx, const KParams& kp, int alm_iteration, double dy_norm_plus, double f2_norm_plus,
+                                         double akkt_tol, double c) {
+    const bool crit1 = alm_iteration > 0 && dy_norm_plus <= c * kp.delta_tol + KC(K_EPS);
+    const bool crit2 = f2_norm_plus <= kp.delta_tol + KC(K_EPS);
+    const bool crit3 = akkt_tol <= kp.tol + KC(K_EPS);
+    return crit1 && crit2 && crit3;
+}
+// the penalty stays when this is the first outer iteration or both infeasibilities shrank by the factor theta
+__device__ __forceinline__ bool alm_stalled(const Ctx& cx, const KParams& kp, int alm_iteration, double dy_norm_plus, double dy_norm,
+                                            double f2_norm_plus, double f2_norm) {
+    return alm_iteration == 0 || (dy_norm_plus <= kp.suff_decrease * dy_norm + KC(K_EPS) &&
+                                  f2_norm_plus <= kp.suff_decrease * f2_norm + KC(K_EPS));
+}
+
 // The whole ALM / PANOC solve of problem P::problem() on the lanes P gives it.  `lds` is the workgroup's dynamic LDS.
+// The iteration is a small state machine around ONE call site of eval_point.
 template <int NT, bool SC, bool LBG, class P>
 __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& io, int B, double* lds) {
     const int b = P::problem();
     if (b >= B) return;
     const long long t_start = wall_clock64();
     const int lane = P::lane(), N = NT ? NT : kp.N, mem = kp.mem;
-    constexpr int RV = P::RV;
     lds += P::half() * kp.l_total;  // this problem's carve
     const double* ws = io.ws + (size_t)b * kp.ws_stride;
     // Launches with a RESERVED LDS carve (mpcgpu_reserve_shape: no count read-back before the launch) check every problem
@@ -1024,17 +1223,6 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
     // benchmark batch and slower for small batches and for N = 40).
     double* LOLD = LBG ? io.ws + (size_t)b * kp.ws_stride + kp.ws_lold : lds + kp.l_old;
     const bool vl = cx.vl;
-
-    // PANOC constants [OpEn]
-    // (each use reads the literal from the LDS table; a local copy would live in two VGPRs across the whole loop)
-#define GAMMA_L_COEFF KC(K_GAMMA_L)
-#define DELTA_LIP KC(K_DELTA_LIP)
-#define EPS_LIP KC(K_EPS_LIP)
-#define LIP_UPD_EPS KC(K_EPS_LIP)
-#define MAX_LIP KC(K_MAX_LIP)
-#define MIN_L KC(K_MIN_L)
-#define SMALL_EPS KC(K_EPS)
-#define DBLMIN KC(K_DBLMIN)
     const int MAX_LIP_IT = 10, MAX_LS_IT = 10;
 
     // decision vector and multipliers (vector lanes; zeros elsewhere)
@@ -1053,12 +1241,11 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
     // ||grad||^2 and ||gradient_step - u_half||^2 are carried as scalars (they only enter the envelope)
     double gv = 0, gw = 0, hv = 0, hw = 0, rv_ = 0, rw_ = 0, dv = 0, dw = 0;
     double gamma = 0, Lip = 0, sigma = 0, cost = 0, nfpr = 0, tau = 1, rhs = 0, nh = 1, gg = 0, d2h = 0;
+    double ip = 0.0;  // <grad, gamma*fpr> of the current step (Lipschitz test)
     double akkt_tol = kp.init_tol;
     int iter = 0, num_iter = 0, lip_it = 0, nls = 0;
     bool cont_iters = true, cont_time = true;
-    int lb_active = 0, lb_head = 0;
-    bool lb_first = true;
-    double lb_gamma = 1.0;
+    PanocLbfgs lb;
     // ALM cache
     int alm_iteration = 0, num_outer = 1, inner_total = 0, status = 0;
     double dy_norm = 0, dy_norm_plus = 0, f2_norm = 0, f2_norm_plus = 0, last_fpr = 0, f_final = 0;
@@ -1071,7 +1258,7 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
         if (lane == 0 && io.trace && tr_n < io.trace_cap) {
             double* r = io.trace + ((size_t)b * io.trace_cap + tr_n) * TRACE_W;
             r[0] = alm_iteration; r[1] = iter; r[2] = c; r[3] = Lip; r[4] = gamma; r[5] = nfpr; r[6] = tr_psi_u;
-            r[7] = lip_it; r[8] = lb_active; r[9] = nls_; r[10] = tau_; r[11] = cost;
+            r[7] = lip_it; r[8] = lb.active; r[9] = nls_; r[10] = tau_; r[11] = cost;
         }
         ++tr_n;
     };
@@ -1084,22 +1271,6 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
     Prof prof; prof.start();
 #endif
 
-    // u_half <- Proj_U(base - gamma*grad); returns this lane's share of ||gradient_step - u_half||^2
-    auto half_step = [&](double bv, double bw) -> double {
-        const double sv = bv - gamma * gv, sw = bw - gamma * gw;
-        hv = vl ? clampd(sv, kp.vmin, kp.vmax) : 0.0;
-        hw = vl ? clampd(sw, -kp.wmax, kp.wmax) : 0.0;
-        const double e0 = vl ? sv - hv : 0.0, e1 = vl ? sw - hw : 0.0;
-        return __builtin_fma(e0, e0, e1 * e1);
-    };
-    // the two sums of the forward-backward envelope at the point whose gradient is (gv, gw): ||grad||^2 and
-    // ||gradient_step - u_half||^2, in ONE packed reduction (bitwise the same totals as two separate ones)
-    auto envelope_sums = [&](double bv, double bw) {
-        const double e2 = half_step(bv, bw);
-        P::sum2(__builtin_fma(gv, gv, gw * gw), e2, gg, d2h);
-    };
-    double ip = 0.0;  // <grad, gamma*fpr> of the current step (Lipschitz test)
-
     for (;;) {
         PROF_MARK(10 + state);  // solver logic that led to this evaluation (by the state it was issued for)
         PROF_COUNT(16 + state);
@@ -1108,32 +1279,21 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
         bool step_begin = false;
 
         if (state == ST_INIT0) {
-            // cost + gradient at u; perturbation for the local Lipschitz estimate: h_i = max(delta, eps*u_i)
+            // cost + gradient at u; perturbation for the local Lipschitz estimate
             cost = P::uni(o.psi); gv = o.gv; gw = o.gw;
-            const double h0 = vl ? ((EPS_LIP * uv > DELTA_LIP) ? EPS_LIP * uv : DELTA_LIP) : 0.0;
-            const double h1 = vl ? ((EPS_LIP * uw > DELTA_LIP) ? EPS_LIP * uw : DELTA_LIP) : 0.0;
-            nh = P::uni(sqrt(dot2r<P, RV>(h0, h1, h0, h1)));
+            double h0, h1;
+            panoc_lip_perturbation<P>(cx, vl, uv, uw, h0, h1, nh);
             ev = uv + h0; ew = uw + h1; want_grad = true; state = ST_INIT1;
             continue;
         } else if (state == ST_INIT1) {
-            const double d0 = o.gv - gv, d1 = o.gw - gw;
-            Lip = P::uni(sqrt(dot2r<P, RV>(d0, d1, d0, d1)) / nh);
-            gamma = P::uni(GAMMA_L_COEFF / fmax(Lip, MIN_L));
-            sigma = P::uni(KC(K_SIGMA) / gamma);
-            envelope_sums(uv, uw);
+            panoc_lip_estimate<P>(cx, o.gv - gv, o.gw - gw, nh, Lip, gamma, sigma);
+            panoc_envelope_sums<P>(kp, vl, uv, uw, gamma, gv, gw, hv, hw, gg, d2h);
             step_begin = true;
         } else if (state == ST_LIP) {
             const double cost_half = o.psi;
-            const double rhs_lip = cost + LIP_UPD_EPS * fabs(cost) - ip + (GAMMA_L_COEFF / (2.0 * gamma)) * nfpr * nfpr;
-            if (cost_half > rhs_lip && lip_it < MAX_LIP_IT && Lip < MAX_LIP) {
-                lb_active = 0; lb_first = true;  // invalidate the L-BFGS buffer
-                Lip = P::uni(Lip * 2.0); gamma = P::uni(gamma * 0.5);
-                const double e2 = half_step(uv, uw);
-                rv_ = uv - hv; rw_ = uw - hw;
-                double rr;
-                P::sum2(e2, __builtin_fma(rv_, rv_, rw_ * rw_), d2h, rr);
-                nfpr = P::uni(sqrt(rr));
-                ip = dot2r<P, RV>(gv, gw, rv_, rw_);
+            if (panoc_lip_test_fails(cx, cost_half, cost, ip, gamma, nfpr) && lip_it < MAX_LIP_IT && Lip < KC(K_MAX_LIP)) {
+                lb.flush();  // invalidate the L-BFGS buffer
+                panoc_lip_update<P>(kp, vl, uv, uw, gv, gw, Lip, gamma, hv, hw, rv_, rw_, d2h, nfpr, ip);
                 ++lip_it;
                 ev = hv; ew = hw; want_grad = false;
                 continue;
@@ -1142,30 +1302,8 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
 #ifdef MPC_TRACE
             tr_psi_u = cost;
 #endif
-            // ---- L-BFGS buffer update with (state = u, g = gamma*fpr)   [crate lbfgs: C-BFGS acceptance]
-            if (lb_first) {
-                lb_first = false;
-                if (vl) { LOLD[lane * 4] = uv; LOLD[lane * 4 + 1] = uw; LOLD[lane * 4 + 2] = rv_; LOLD[lane * 4 + 3] = rw_; }
-            } else {
-                double s0 = 0, s1 = 0, y0_ = 0, y1_ = 0;
-                if (vl) {
-                    s0 = uv - LOLD[lane * 4]; s1 = uw - LOLD[lane * 4 + 1];
-                    y0_ = rv_ - LOLD[lane * 4 + 2]; y1_ = rw_ - LOLD[lane * 4 + 3];
-                }
-                double ys, ss;
-                P::sum2(__builtin_fma(s0, y0_, s1 * y1_), __builtin_fma(s0, s0, s1 * s1), ys, ss);
-                if (!(ss <= DBLMIN || ys <= KC(K_MIN_L)) && (ys / ss > KC(K_CBFGS) * nfpr)) {
-                    lb_head = (lb_head + mem - 1) % mem;
-                    if (vl) {
-                        LOLD[lane * 4] = uv; LOLD[lane * 4 + 1] = uw; LOLD[lane * 4 + 2] = rv_; LOLD[lane * 4 + 3] = rw_;
-                        LS[(lb_head * N + lane) * 2] = s0; LS[(lb_head * N + lane) * 2 + 1] = s1;
-                        LY[(lb_head * N + lane) * 2] = y0_; LY[(lb_head * N + lane) * 2 + 1] = y1_;
-                    }
-                    if (lane == 0) LRHO[lb_head] = 1.0 / ys;
-                    lb_gamma = P::uni(ys / dot2r<P, RV>(y0_, y1_, y0_, y1_));
-                    lb_active = (lb_active + 1 < mem) ? lb_active + 1 : mem;
-                }
-            }
+            // ---- L-BFGS buffer update with (state = u, g = gamma*fpr)
+            lb.template update<P>(cx, vl, lane, N, mem, uv, uw, rv_, rw_, nfpr, LS, LY, LOLD, LRHO);
             wave_sync();
             if (iter == 0) {
                 // first iteration: no line search, u <- u_half
@@ -1173,63 +1311,16 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
                 ev = uv; ew = uw; want_grad = true; state = ST_NOLS;
                 continue;
             }
-            // ---- direction d = H * (gamma*fpr): two-loop recursion, newest pair first
-            double q0 = rv_, q1 = rw_;
-            if (LBG) {
-                // pairs come from the workspace record: pair j+1 is requested before pair j is consumed
-                auto pair_at = [&](const double* base, int sl) -> double2 {
-                    return vl ? *reinterpret_cast<const double2*>(base + (sl * N + lane) * 2) : make_double2(0.0, 0.0);
-                };
-                double2 sc = make_double2(0.0, 0.0), yc = sc;
-                if (lb_active > 0) { sc = pair_at(LS, lb_head); yc = pair_at(LY, lb_head); }
-                for (int j = 0; j < lb_active; ++j) {
-                    const int sl = (lb_head + j) % mem;
-                    double2 sn = sc, yn = yc;
-                    if (j + 1 < lb_active) { const int nx = (lb_head + j + 1) % mem; sn = pair_at(LS, nx); yn = pair_at(LY, nx); }
-                    const double al = LRHO[sl] * dot2r<P, RV>(sc.x, sc.y, q0, q1);
-                    if (lane == 0) LALPHA[j] = al;
-                    q0 -= al * yc.x; q1 -= al * yc.y;
-                    sc = sn; yc = yn;  // after the last step (sc, yc) still hold pair lb_active-1
-                }
-                wave_sync();
-                if (lb_active > 0) { q0 *= lb_gamma; q1 *= lb_gamma; }
-                for (int j = lb_active - 1; j >= 0; --j) {
-                    const int sl = (lb_head + j) % mem;
-                    double2 sp = sc, yp = yc;
-                    if (j > 0) { const int pv = (lb_head + j - 1) % mem; sp = pair_at(LS, pv); yp = pair_at(LY, pv); }
-                    const double be = LRHO[sl] * dot2r<P, RV>(yc.x, yc.y, q0, q1);
-                    const double co = LALPHA[j] - be;
-                    q0 += co * sc.x; q1 += co * sc.y;
-                    sc = sp; yc = yp;
-                }
-            } else {
-                for (int j = 0; j < lb_active; ++j) {
-                    const int sl = (lb_head + j) % mem;
-                    const double sj0 = vl ? LS[(sl * N + lane) * 2] : 0.0, sj1 = vl ? LS[(sl * N + lane) * 2 + 1] : 0.0;
-                    const double al = LRHO[sl] * dot2r<P, RV>(sj0, sj1, q0, q1);
-                    if (lane == 0) LALPHA[j] = al;
-                    if (vl) { q0 -= al * LY[(sl * N + lane) * 2]; q1 -= al * LY[(sl * N + lane) * 2 + 1]; }
-                }
-                wave_sync();
-                if (lb_active > 0) { q0 *= lb_gamma; q1 *= lb_gamma; }
-                for (int j = lb_active - 1; j >= 0; --j) {
-                    const int sl = (lb_head + j) % mem;
-                    const double yj0 = vl ? LY[(sl * N + lane) * 2] : 0.0, yj1 = vl ? LY[(sl * N + lane) * 2 + 1] : 0.0;
-                    const double be = LRHO[sl] * dot2r<P, RV>(yj0, yj1, q0, q1);
-                    const double co = LALPHA[j] - be;
-                    if (vl) { q0 += co * LS[(sl * N + lane) * 2]; q1 += co * LS[(sl * N + lane) * 2 + 1]; }
-                }
-            }
-            dv = q0; dw = q1;
+            lb.template direction<P, LBG>(vl, lane, N, mem, rv_, rw_, LS, LY, LRHO, LALPHA, dv, dw);
             // ---- line search on the forward-backward envelope
-            rhs = P::uni((cost - 0.5 * gamma * gg + 0.5 * d2h / gamma) - sigma * nfpr * nfpr);
+            rhs = P::uni(panoc_fbe_rhs(cost, gamma, gg, d2h, sigma, nfpr));
             tau = 1.0; nls = 0;
-            ev = uv - (1.0 - tau) * rv_ - tau * dv; ew = uw - (1.0 - tau) * rw_ - tau * dw;  // u_plus
+            ev = panoc_trial(uv, rv_, dv, tau); ew = panoc_trial(uw, rw_, dw, tau);  // u_plus
             want_grad = true; state = ST_LS;
             continue;
         } else if (state == ST_NOLS) {
             cost = P::uni(o.psi); gv = o.gv; gw = o.gw;
-            envelope_sums(uv, uw);
+            panoc_envelope_sums<P>(kp, vl, uv, uw, gamma, gv, gw, hv, hw, gg, d2h);
 #ifdef MPC_TRACE
             tr_write(-1, 1.0);
 #endif
@@ -1238,11 +1329,11 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
         } else if (state == ST_LS) {
             // (ev, ew) is the trial point u_plus
             cost = P::uni(o.psi); gv = o.gv; gw = o.gw;
-            envelope_sums(ev, ew);
-            const double lhs = cost - 0.5 * gamma * gg + 0.5 * d2h / gamma;
+            panoc_envelope_sums<P>(kp, vl, ev, ew, gamma, gv, gw, hv, hw, gg, d2h);
+            const double lhs = panoc_fbe(cost, gamma, gg, d2h);
             if (lhs > rhs && nls < MAX_LS_IT) {
                 tau = P::uni(tau * 0.5); ++nls;
-                ev = uv - (1.0 - tau) * rv_ - tau * dv; ew = uw - (1.0 - tau) * rw_ - tau * dw;
+                ev = panoc_trial(uv, rv_, dv, tau); ew = panoc_trial(uw, rw_, dw, tau);
                 want_grad = true;
                 continue;
             }
@@ -1265,22 +1356,12 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
             inner_total += num_iter;
             last_fpr = nfpr;
             f_final = P::uni(o.f);
-            // y+ <- y + c (F1(u) - Proj_C(F1(u) + y/c))
-            double dy2l = 0.0, ypa = 0.0, ypb = 0.0;
-            if (vl) {
-                const double za = o.F1a + ya / c, zb = o.F1b + yb / c;
-                ypa = ya + c * (o.F1a - clampd(za, kp.amin, kp.amax));
-                ypb = yb + c * (o.F1b - clampd(zb, -kp.aamax, kp.aamax));
-                dy2l = __builtin_fma(ypa - ya, ypa - ya, (ypb - yb) * (ypb - yb));
-            }
-            dy_norm_plus = P::uni(sqrt(P::template sum<RV>(dy2l)));
+            double ypa, ypb;
+            alm_multiplier_step<P>(kp, vl, o.F1a, o.F1b, ya, yb, c, ypa, ypb, dy_norm_plus);
             f2_norm_plus = P::uni(sqrt(o.nrm2F2));
-            const bool crit1 = alm_iteration > 0 && dy_norm_plus <= c * kp.delta_tol + SMALL_EPS;
-            const bool crit2 = f2_norm_plus <= kp.delta_tol + SMALL_EPS;
-            const bool crit3 = akkt_tol <= kp.tol + SMALL_EPS;
             bool done = false;
             // converged: status = status of the last inner problem; the outer-iteration cap overrides it
-            if ((crit1 && crit2 && crit3) || num_outer == kp.max_outer) {
+            if (alm_exit(cx, kp, alm_iteration, dy_norm_plus, f2_norm_plus, akkt_tol, c) || num_outer == kp.max_outer) {
                 if (num_outer == kp.max_outer) status = 1;
                 done = true;
             } else if (kp.max_ticks > 0 && wall_clock64() - t_start > kp.max_ticks) {
@@ -1294,15 +1375,15 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
                 }
                 break;
             }
-            const bool stall = alm_iteration == 0 || (dy_norm_plus <= kp.suff_decrease * dy_norm + SMALL_EPS &&
-                                                      f2_norm_plus <= kp.suff_decrease * f2_norm + SMALL_EPS);
-            if (!stall) { c = P::uni(c * kp.penalty_update); icm = P::uni(1.0 / fmax(c, 1.0)); }
+            if (!alm_stalled(cx, kp, alm_iteration, dy_norm_plus, dy_norm, f2_norm_plus, f2_norm)) {
+                c = P::uni(c * kp.penalty_update); icm = P::uni(1.0 / fmax(c, 1.0));
+            }
             akkt_tol = P::uni(fmax(akkt_tol * kp.tol_update, kp.tol));
             ++alm_iteration; ++num_outer;
             dy_norm = dy_norm_plus; f2_norm = f2_norm_plus;
             ya = clampd(ypa, -KC(K_YBOUND), KC(K_YBOUND)); yb = clampd(ypb, -KC(K_YBOUND), KC(K_YBOUND));  // y <- Proj_Y(y+)
             // reset the PANOC cache for the next inner problem
-            lb_active = 0; lb_first = true; tau = 1.0; Lip = 0; sigma = 0; gamma = 0; iter = 0;
+            lb.flush(); tau = 1.0; Lip = 0; sigma = 0; gamma = 0; iter = 0;
             num_iter = 0; cont_iters = true; cont_time = true;
             ev = uv; ew = uw; want_grad = true; state = ST_INIT0;
             continue;
@@ -1320,18 +1401,7 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
                 }
             }
             if (!inner_done) {
-                rv_ = uv - hv; rw_ = uw - hw;
-                double rr;
-                P::sum2(__builtin_fma(rv_, rv_, rw_ * rw_), __builtin_fma(gv, rv_, gw * rw_), rr, ip);  // ||gamma fpr||^2, <grad, gamma fpr>
-                nfpr = P::uni(sqrt(rr));
-                bool ex = nfpr < kp.tol;
-                if (ex) {
-                    // AKKT residual || gfpr/gamma + grad - grad_prev || < eps_nu.  grad_prev is the zero vector
-                    // on the first step of an inner problem and the current gradient afterwards.
-                    const double a0 = rv_ / gamma + (iter == 0 ? gv : 0.0), a1 = rw_ / gamma + (iter == 0 ? gw : 0.0);
-                    ex = sqrt(dot2r<P, RV>(a0, a1, a0, a1)) < akkt_tol;
-                }
-                if (ex) {
+                if (panoc_step_residual<P>(cx, kp, vl, uv, uw, hv, hw, gv, gw, gamma, iter, akkt_tol, rv_, rw_, nfpr, ip)) {
                     inner_done = true;
                 } else {
                     lip_it = 0;
@@ -1381,13 +1451,5 @@ __global__ __launch_bounds__(WAVE, 2) void solve_kernel_duo(KParams kp, BatchPtr
     solve_body<NT, SC, LBG, Duo<NT>>(kp, io, B, lds);
 }
 
-#undef GAMMA_L_COEFF
-#undef DELTA_LIP
-#undef EPS_LIP
-#undef LIP_UPD_EPS
-#undef MAX_LIP
-#undef MIN_L
-#undef SMALL_EPS
-#undef DBLMIN
 
 }  // namespace mpcgpu

@@ -1,0 +1,353 @@
+// mpc_team.hpp -- latency path of the batched NMPC solver: ONE problem per WORKGROUP of four wavefronts.
+//
+// The reference calls its solver for one robot at a time (src/interface_mpc.py:82-88, one `solver.run(p)` per tick); a
+// fleet of a few robots is a batch of a few problems.  In that regime the GPU is empty and what counts is how long ONE
+// solve takes.  A PANOC iteration is a chain of ~4 dependent psi evaluations (Lipschitz test at the half step, then line
+// search trials tau = 1, 1/2, 1/4, ...; mpc_kernels.hpp solve_body) -- the chain, not the arithmetic, is the latency.
+// This kernel runs the SAME iteration with the evaluations of one step side by side:
+//   * the four wavefronts are replicas of one state machine (same scalars, same vectors, bit for bit);
+//   * at the start of a step the L-BFGS update and the two-loop direction are computed SPECULATIVELY (they do not depend on
+//     the Lipschitz test; if the test fails the buffer is flushed anyway), then in ONE pass wavefront 0 evaluates psi at the
+//     half step while wavefronts 1..3 evaluate the trial points tau = 1, 1/2, 1/4;
+//   * the first accepted trial in sequential order wins; its wavefront publishes point, gradient and half step through LDS
+//     and every replica adopts them.  No trial accepted: the next four trials, again in one pass (tau down to 2^-10);
+//   * a failed Lipschitz test discards the speculation and the replicas continue with the sequential rule.
+// Every number is computed by the same device functions (eval_point, the step helpers below) on the same inputs as in the
+// one-wavefront kernel, so the results are BITWISE those of solve_kernel_pair (tests/test_gpu_latency.py); the library is
+// built with -ffp-contract=on so that floating-point contraction does not depend on the code around an expression.
+//
+// Also fused here: the parameter compaction (prep_problem) -- one launch per call -- and the LDS carve comes from the
+// configured maxima (general dynamic-obstacle tables), so the host never reads a count back before the launch.
+#pragma once
+#include "mpc_kernels.hpp"
+
+namespace mpcgpu {
+
+constexpr int TEAM_WAVES = 4;
+constexpr int TEAM_XCH = 8;  // doubles per wavefront in the exchange area
+
+enum { TS_INIT0 = 0, TS_INIT1, TS_FIRST, TS_SPEC, TS_LIPSEQ, TS_BATCH, TS_FALLBACK, TS_OUTER };
+
+template <int NT>
+__global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams kp, BatchPtrs io, int B) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    using P = Solo<NT>;
+    constexpr bool SC = false;  // general tables: no batch-wide shape information is needed before the launch
+    constexpr int N = NT, RV = P::RV;
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    const long long t_start = wall_clock64();
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1), mem = kp.mem;
+    double* ws = io.ws + (size_t)b * kp.ws_stride;
+    if (wid == 0) prep_problem(kp, io.p + (size_t)b * kp.np, ws, io.counts, lane);
+    __syncthreads();
+
+    // ---- problem context: tables shared by the four wavefronts, work areas and L-BFGS memory per wavefront
+    Ctx cx;
+    double* mine = lds + wid * kp.l_wstride;
+    {
+        cx.lane = lane; cx.vl = lane < N; cx.il = true; cx.ik = lane % N; cx.isub = lane / N;
+        double* hd = lds + kp.l_hd;
+        if (threadIdx.x < KC_BASE) hd[threadIdx.x] = ws[threadIdx.x];
+        if (threadIdx.x >= WAVE && threadIdx.x < WAVE + 27) hd[KC_BASE + threadIdx.x - WAVE] = KTAB[threadIdx.x - WAVE];
+        cx.hd = hd;
+        auto U = [&](int i) { return uniform(ws[i]); };
+        cx.Ks = (int)U(H_KS); cx.Kf = (int)U(H_KF); cx.Kd = (int)U(H_KD);
+        cx.pad_f = U(H_NPF) > 0.0; cx.pad_d = U(H_NPD) > 0.0;
+        cx.terminal = U(H_QN) != 0.0 || U(H_QTHN) != 0.0;
+        cx.vref = cx.vl ? ws[kp.ws_vref + lane] : 0.0;
+        cx.seg = lds + kp.l_seg; cx.stc = lds + kp.l_stc; cx.fxy = lds + kp.l_fxy;
+        cx.segc = ws + kp.ws_segc;
+        cx.dyn = lds + kp.l_dyn; cx.dync = cx.dyn; cx.qd = cx.dyn;
+        cx.pos = mine + kp.l_pos; cx.H = mine + kp.l_H; cx.W = mine + kp.l_W; cx.part = mine + kp.l_part; cx.stash = mine + kp.l_stash;
+        const int T = WAVE * TEAM_WAVES;
+        for (int i = threadIdx.x; i < N * SEGW; i += T) cx.seg[i] = ws[kp.ws_seg + i];
+        for (int i = threadIdx.x; i < cx.Ks * STCW; i += T) cx.stc[i] = ws[kp.ws_stc + i];
+        for (int i = threadIdx.x; i < cx.Kf * N * 2; i += T) cx.fxy[i] = ws[kp.ws_fxy + i];
+        for (int i = threadIdx.x; i < cx.Kd * N * DYNW; i += T) cx.dyn[i] = ws[kp.ws_dyn + i];
+    }
+    __syncthreads();
+    double* LS = mine + kp.l_S;
+    double* LY = mine + kp.l_Y;
+    double* LRHO = mine + kp.l_rho;
+    double* LALPHA = mine + kp.l_alpha;
+    double* LOLD = mine + kp.l_old;
+    double* XF = lds + kp.l_xch;                          // [TEAM_WAVES][TEAM_XCH]: per-wavefront verdicts of a pass
+    double* XV = XF + TEAM_WAVES * TEAM_XCH;              // [N][6] + 4: the winner's point, gradient, half step and scalars
+    const bool vl = cx.vl;
+    const int MAX_LIP_IT = 10, MAX_LS_IT = 10;
+
+    double uv = 0.0, uw = 0.0, ya = 0.0, yb = 0.0;
+    if (vl) {
+        if (io.u0) { uv = io.u0[(size_t)b * 2 * N + 2 * lane]; uw = io.u0[(size_t)b * 2 * N + 2 * lane + 1]; }
+        if (io.y0) { ya = io.y0[(size_t)b * 2 * N + lane]; yb = io.y0[(size_t)b * 2 * N + N + lane]; }
+    }
+    double c = kp.init_penalty;
+    if (io.c0) { const double c0 = io.c0[b]; if (c0 > 0.0) c = c0; }
+    c = uniform(c);
+    double icm = uniform(1.0 / fmax(c, 1.0));
+    ya = clampd(ya, -KC(K_YBOUND), KC(K_YBOUND)); yb = clampd(yb, -KC(K_YBOUND), KC(K_YBOUND));
+    double gv = 0, gw = 0, hv = 0, hw = 0, rv_ = 0, rw_ = 0, dv = 0, dw = 0;
+    double gamma = 0, Lip = 0, sigma = 0, cost = 0, nfpr = 0, tau = 1, rhs = 0, nh = 1, gg = 0, d2h = 0, ip = 0;
+    double akkt_tol = kp.init_tol;
+    int iter = 0, num_iter = 0, lip_it = 0, nls = 0, t0 = 0;
+    bool cont_iters = true, cont_time = true;
+    PanocLbfgs lb;
+    int alm_iteration = 0, num_outer = 1, inner_total = 0, status = 0;
+    double dy_norm = 0, dy_norm_plus = 0, f2_norm = 0, f2_norm_plus = 0, last_fpr = 0, f_final = 0;
+    int n_eval = 0, n_eval_grad = 0;  // evaluations of the SEQUENTIAL algorithm (the speculative ones are not counted)
+
+    int state = TS_INIT0;
+    double ev = uv, ew = uw;
+    bool want_grad = true;
+    EvalOut o;
+
+    // verdicts of a pass: every wavefront publishes one flag, all read the four of them
+    auto publish = [&](double flag, double* all) {
+        if (lane == 0) XF[wid * TEAM_XCH] = flag;
+        __syncthreads();
+        for (int j = 0; j < TEAM_WAVES; ++j) all[j] = uniform(XF[j * TEAM_XCH]);
+    };
+    // the winning wavefront hands over (point, gradient, half step; cost, ||grad||^2, ||gradient step - half step||^2)
+    auto adopt = [&](int winner, double tcost, double tgg, double td2h, double thv, double thw) {
+        if (wid == winner) {
+            if (vl) {
+                double* r = XV + lane * 6;
+                r[0] = ev; r[1] = ew; r[2] = o.gv; r[3] = o.gw; r[4] = thv; r[5] = thw;
+            }
+            if (lane == 0) { XV[N * 6] = tcost; XV[N * 6 + 1] = tgg; XV[N * 6 + 2] = td2h; }
+        }
+        __syncthreads();
+        if (vl) {
+            const double* r = XV + lane * 6;
+            uv = r[0]; uw = r[1]; gv = r[2]; gw = r[3]; hv = r[4]; hw = r[5];
+        } else {
+            uv = 0.0; uw = 0.0; gv = 0.0; gw = 0.0; hv = 0.0; hw = 0.0;
+        }
+        cost = uniform(XV[N * 6]); gg = uniform(XV[N * 6 + 1]); d2h = uniform(XV[N * 6 + 2]);
+    };
+    // The wall clock differs between wavefronts by a few ticks: wavefront 0 decides for all (two alternating slots, so that a
+    // wavefront that is one barrier behind still reads the verdict it was meant to read).
+    int clock_slot = 0;
+    auto time_left = [&]() -> bool {
+        double* slot = XF + (1 + clock_slot) * TEAM_XCH - 1;
+        clock_slot ^= 1;
+        if (lane == 0 && wid == 0) *slot = (wall_clock64() - t_start) <= kp.max_ticks ? 1.0 : 0.0;
+        __syncthreads();
+        return uniform(*slot) != 0.0;
+    };
+    auto trial_point = [&](double t) { ev = panoc_trial(uv, rv_, dv, t); ew = panoc_trial(uw, rw_, dw, t); };
+
+    for (;;) {
+        eval_point<NT, SC, P>(kp, cx, ev, ew, c, icm, ya, yb, want_grad, state == TS_OUTER, o);
+        bool step_begin = false;
+
+        if (state == TS_INIT0) {
+            ++n_eval; ++n_eval_grad;
+            cost = uniform(o.psi); gv = o.gv; gw = o.gw;
+            double h0, h1;
+            panoc_lip_perturbation<P>(cx, vl, uv, uw, h0, h1, nh);
+            ev = uv + h0; ew = uw + h1; want_grad = true; state = TS_INIT1;
+            continue;
+        } else if (state == TS_INIT1) {
+            ++n_eval; ++n_eval_grad;
+            panoc_lip_estimate<P>(cx, o.gv - gv, o.gw - gw, nh, Lip, gamma, sigma);
+            panoc_envelope_sums<P>(kp, vl, uv, uw, gamma, gv, gw, hv, hw, gg, d2h);
+            step_begin = true;
+        } else if (state == TS_FIRST || state == TS_LIPSEQ) {
+            // psi at the half step, the same point on every wavefront.  TS_FIRST (first step of an inner problem): evaluated
+            // WITH the gradient, because once the Lipschitz test passes this very point becomes the iterate.
+            ++n_eval;
+            const double cost_half = o.psi;
+            if (panoc_lip_test_fails(cx, cost_half, cost, ip, gamma, nfpr) && lip_it < MAX_LIP_IT && Lip < KC(K_MAX_LIP)) {
+                lb.flush();
+                panoc_lip_update<P>(kp, vl, uv, uw, gv, gw, Lip, gamma, hv, hw, rv_, rw_, d2h, nfpr, ip);
+                ++lip_it;
+                ev = hv; ew = hw;  // want_grad stays as it is
+                continue;
+            }
+            sigma = uniform(KC(K_SIGMA) / gamma);
+            lb.template update<P>(cx, vl, lane, N, mem, uv, uw, rv_, rw_, nfpr, LS, LY, LOLD, LRHO);
+            wave_sync();
+            if (state == TS_FIRST) {
+                // no line search on the first step: u <- u_half, whose psi and gradient were just evaluated
+                ++n_eval; ++n_eval_grad;
+                uv = hv; uw = hw;
+                cost = uniform(o.psi); gv = o.gv; gw = o.gw;
+                panoc_envelope_sums<P>(kp, vl, uv, uw, gamma, gv, gw, hv, hw, gg, d2h);
+                ++iter;
+                step_begin = true;
+            } else {
+                lb.template direction<P, false>(vl, lane, N, mem, rv_, rw_, LS, LY, LRHO, LALPHA, dv, dw);
+                rhs = panoc_fbe_rhs(cost, gamma, gg, d2h, sigma, nfpr);
+                t0 = 0;
+                trial_point(exp2(-(double)(t0 + wid)));
+                want_grad = true; state = TS_BATCH;
+                continue;
+            }
+        } else if (state == TS_SPEC) {
+            // wavefront 0: psi at the half step (Lipschitz test); wavefronts 1..3: trials tau = 1, 1/2, 1/4
+            double thv = 0.0, thw = 0.0, tgg = 0.0, td2h = 0.0, flag;
+            if (wid == 0) {
+                flag = (panoc_lip_test_fails(cx, o.psi, cost, ip, gamma, nfpr) && lip_it < MAX_LIP_IT && Lip < KC(K_MAX_LIP)) ? 1.0 : 0.0;
+            } else {
+                panoc_envelope_sums<P>(kp, vl, ev, ew, gamma, o.gv, o.gw, thv, thw, tgg, td2h);
+                flag = panoc_fbe(uniform(o.psi), gamma, tgg, td2h) > rhs ? 0.0 : 1.0;  // 1 = accepted
+            }
+            double all[TEAM_WAVES];
+            publish(flag, all);
+            ++n_eval;
+            if (all[0] != 0.0) {
+                // Lipschitz test failed: the speculative pair and direction are void (the buffer is flushed)
+                lb.flush();
+                panoc_lip_update<P>(kp, vl, uv, uw, gv, gw, Lip, gamma, hv, hw, rv_, rw_, d2h, nfpr, ip);
+                ++lip_it;
+                ev = hv; ew = hw; want_grad = false; state = TS_LIPSEQ;
+                continue;
+            }
+            int winner = 0;
+            for (int j = TEAM_WAVES - 1; j >= 1; --j) if (all[j] != 0.0) winner = j;
+            if (winner) {
+                nls = winner - 1; tau = exp2(-(double)nls);
+                n_eval += nls + 1; n_eval_grad += nls + 1;
+                adopt(winner, uniform(o.psi), tgg, td2h, thv, thw);
+                ++iter;
+                step_begin = true;
+            } else {
+                n_eval += TEAM_WAVES - 1; n_eval_grad += TEAM_WAVES - 1;
+                t0 = TEAM_WAVES - 1;
+                trial_point(exp2(-(double)(t0 + wid)));
+                want_grad = true; state = TS_BATCH;
+                continue;
+            }
+        } else if (state == TS_BATCH) {
+            // trials t0 + wid, tau = 2^-t; t = MAX_LS_IT is taken unconditionally (ls_fallback = 0) or leads to the tau = 0 point
+            double thv, thw, tgg, td2h;
+            panoc_envelope_sums<P>(kp, vl, ev, ew, gamma, o.gv, o.gw, thv, thw, tgg, td2h);
+            const int t = t0 + wid;
+            const bool accepted = !(panoc_fbe(uniform(o.psi), gamma, tgg, td2h) > rhs);
+            const double flag = t > MAX_LS_IT ? 0.0 : (accepted ? 1.0 : (t == MAX_LS_IT ? 2.0 : 0.0));  // 2 = last trial, rejected
+            double all[TEAM_WAVES];
+            publish(flag, all);
+            int winner = -1;
+            for (int j = TEAM_WAVES - 1; j >= 0; --j) if (all[j] != 0.0) winner = j;
+            if (winner >= 0) {
+                nls = t0 + winner; tau = exp2(-(double)nls);
+                n_eval += winner + 1; n_eval_grad += winner + 1;
+                if (all[winner] == 2.0 && kp.ls_fallback == 1) {
+                    // 10 halvings without acceptance, tau = 0 reading: u - gamma*fpr is evaluated and taken
+                    tau = 0.0;
+                    ev = uv - rv_; ew = uw - rw_;
+                    want_grad = true; state = TS_FALLBACK;
+                    continue;
+                }
+                adopt(winner, uniform(o.psi), tgg, td2h, thv, thw);
+                ++iter;
+                step_begin = true;
+            } else {
+                n_eval += TEAM_WAVES; n_eval_grad += TEAM_WAVES;
+                t0 += TEAM_WAVES;
+                trial_point(exp2(-(double)(t0 + wid)));
+                continue;
+            }
+        } else if (state == TS_FALLBACK) {
+            ++n_eval; ++n_eval_grad;
+            uv = ev; uw = ew;
+            cost = uniform(o.psi); gv = o.gv; gw = o.gw;
+            panoc_envelope_sums<P>(kp, vl, uv, uw, gamma, gv, gw, hv, hw, gg, d2h);
+            ++iter;
+            step_begin = true;
+        } else {  // TS_OUTER
+            ++n_eval;
+            inner_total += num_iter;
+            last_fpr = nfpr;
+            f_final = uniform(o.f);
+            double ypa, ypb;
+            alm_multiplier_step<P>(kp, vl, o.F1a, o.F1b, ya, yb, c, ypa, ypb, dy_norm_plus);
+            f2_norm_plus = uniform(sqrt(o.nrm2F2));
+            bool done = false;
+            if (alm_exit(cx, kp, alm_iteration, dy_norm_plus, f2_norm_plus, akkt_tol, c) || num_outer == kp.max_outer) {
+                if (num_outer == kp.max_outer) status = 1;
+                done = true;
+            } else if (kp.max_ticks > 0 && !time_left()) {
+                status = 2;
+                done = true;
+            }
+            if (done) {
+                if (wid == 0 && vl && io.y_out) {
+                    io.y_out[(size_t)b * 2 * N + lane] = ypa;
+                    io.y_out[(size_t)b * 2 * N + N + lane] = ypb;
+                }
+                break;
+            }
+            if (!alm_stalled(cx, kp, alm_iteration, dy_norm_plus, dy_norm, f2_norm_plus, f2_norm)) {
+                c = uniform(c * kp.penalty_update); icm = uniform(1.0 / fmax(c, 1.0));
+            }
+            akkt_tol = uniform(fmax(akkt_tol * kp.tol_update, kp.tol));
+            ++alm_iteration; ++num_outer;
+            dy_norm = dy_norm_plus; f2_norm = f2_norm_plus;
+            ya = clampd(ypa, -KC(K_YBOUND), KC(K_YBOUND)); yb = clampd(ypb, -KC(K_YBOUND), KC(K_YBOUND));
+            lb.flush(); tau = 1.0; Lip = 0; sigma = 0; gamma = 0; iter = 0;
+            num_iter = 0; cont_iters = true; cont_time = true;
+            ev = uv; ew = uw; want_grad = true; state = TS_INIT0;
+            continue;
+        }
+
+        if (step_begin) {
+            bool inner_done = false;
+            if (state != TS_INIT1) {
+                if (cont_iters && cont_time) {
+                    ++num_iter;
+                    cont_iters = num_iter < kp.max_inner;
+                    if (kp.max_ticks > 0) cont_time = time_left();
+                } else {
+                    inner_done = true;
+                }
+            }
+            if (!inner_done) {
+                if (panoc_step_residual<P>(cx, kp, vl, uv, uw, hv, hw, gv, gw, gamma, iter, akkt_tol, rv_, rw_, nfpr, ip)) {
+                    inner_done = true;
+                } else {
+                    lip_it = 0;
+                    if (iter == 0) {
+                        ev = hv; ew = hw; want_grad = true; state = TS_FIRST;
+                    } else {
+                        // speculation: pair update and direction before the Lipschitz test is known
+                        sigma = uniform(KC(K_SIGMA) / gamma);
+                        lb.template update<P>(cx, vl, lane, N, mem, uv, uw, rv_, rw_, nfpr, LS, LY, LOLD, LRHO);
+                        wave_sync();
+                        lb.template direction<P, false>(vl, lane, N, mem, rv_, rw_, LS, LY, LRHO, LALPHA, dv, dw);
+                        rhs = panoc_fbe_rhs(cost, gamma, gg, d2h, sigma, nfpr);
+                        if (wid == 0) { ev = hv; ew = hw; want_grad = false; }
+                        else { trial_point(exp2(-(double)(wid - 1))); want_grad = true; }
+                        state = TS_SPEC;
+                    }
+                    continue;
+                }
+            }
+            status = !cont_iters ? 1 : (!cont_time ? 2 : 0);
+            uv = hv; uw = hw;
+            ev = uv; ew = uw; want_grad = false; state = TS_OUTER;
+        }
+    }
+
+    if (__ballot(vl && !(isfinite(uv) && isfinite(uw))) != 0ull || !isfinite(f_final)) status = 3;
+    if (wid == 0) {
+        if (vl) {
+            io.u[(size_t)b * 2 * N + 2 * lane] = uv;
+            io.u[(size_t)b * 2 * N + 2 * lane + 1] = uw;
+        }
+        if (lane == 0) {
+            io.cost[b] = f_final;
+            io.status[b] = status;
+            if (io.inner_it) io.inner_it[b] = inner_total;
+            if (io.evals) { io.evals[2 * b] = n_eval; io.evals[2 * b + 1] = n_eval_grad; }
+            if (io.outer_it) io.outer_it[b] = num_outer;
+            if (io.fpr) io.fpr[b] = last_fpr;
+            if (io.f2norm) io.f2norm[b] = f2_norm_plus;
+            if (io.ms) io.ms[b] = (double)(wall_clock64() - t_start) * 1e-5;
+        }
+    }
+}
+
+}  // namespace mpcgpu

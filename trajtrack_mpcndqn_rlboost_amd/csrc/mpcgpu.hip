@@ -4,6 +4,7 @@
 // No CPU fallback: every entry point needs a HIP device.
 #include "../../include/mpcgpu.h"
 #include "mpc_kernels.hpp"
+#include "mpc_team.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -40,6 +41,8 @@ struct Handle {
     bool shape_const = true;  // of the batch prepared last
     int last_min_waves = 0;   // launch-bounds variant of the last solve (3 or 4 wavefronts per SIMD)
     int num_cus = 256;
+    int team_max_batch = -1;  // MPCGPU_OPT_TEAM_BATCH: largest batch solved by the latency kernel (-1: 2 x number of CUs)
+    int last_team = 0;        // 1: the last solve ran the latency kernel (one problem per workgroup of four wavefronts)
     int pairing = -1;   // MPCGPU_OPT_PAIRING: -1 automatic, 0 one problem per wavefront, 1 two per wavefront (N_hor = 20)
     int last_pairing = 0;  // layout of the last solve / cost_grad launch
     int trace_cap = 0;  // -DMPC_TRACE builds: PANOC steps recorded per problem (0 = tracing off)
@@ -183,6 +186,36 @@ void fill_lds_layout(KParams& k, int mKs, int mKf, int mKd, bool shape_const, bo
     k.l_total = o;
 }
 
+// LDS carve of the latency kernel (mpc_team.hpp): tables for the CONFIGURED maxima (general dynamic-obstacle records), shared
+// by the four wavefronts of the workgroup; then the exchange area; then one work block per wavefront (positions, stash, hinge
+// matrix / item partials, L-BFGS memory).  Offsets of the work-block fields are those of wavefront 0.
+void fill_team_layout(KParams& k, const mpcgpu_config& c) {
+    const int N = k.N;
+    k.mKs = c.Nstcobs; k.mKf = c.Nother; k.mKd = c.Ndynobs;
+    int o = 0;
+    k.l_seg = o; o += even(N * SEGW);
+    k.l_stc = o; o += k.mKs * STCW;
+    k.l_fxy = o; o += k.mKf * N * 2;
+    k.l_dyn = o; o += even(k.mKd * N * DYNW);
+    k.l_dync = k.l_dyn; k.l_qd = k.l_dyn;
+    k.l_hd = o; o += 64;
+    k.l_xch = o; o += TEAM_WAVES * TEAM_XCH + even(N * 6 + 4);
+    const int base = o;
+    k.l_pos = o; o += N * 2;
+    k.l_stash = o; o += N * 6;
+    const int h_sz = even(k.mKd * N) + even(k.mKd), part_sz = WAVE * PARTW;
+    k.l_H = o; k.l_W = o + even(k.mKd * N); k.l_part = o;
+    o += h_sz > part_sz ? h_sz : part_sz;
+    k.l_S = o; o += k.mem * N * 2;
+    k.l_Y = o; o += k.mem * N * 2;
+    k.l_rho = o; o += even(k.mem);
+    k.l_alpha = o; o += even(k.mem);
+    k.l_old = o; o += N * 4;
+    k.l_wstride = even(o - base);
+    k.l_total = base + TEAM_WAVES * k.l_wstride;
+    k.reserved = 0;
+}
+
 // compaction kernel + LDS layout (from the reserved shape, or from a blocking read-back of the batch's active-row
 // maxima).  Leaves kp ready for a launch on `s`.
 int prepare(Handle* h, int B, const double* d_p, hipStream_t s, BatchPtrs& io, bool allow_reserved) {
@@ -316,6 +349,39 @@ int32_t mpcgpu_solve_batch_dev(void* handle, int32_t B, const double* p, const d
     HIP_OK(h, hipSetDevice(h->device));
     hipStream_t s = pick_stream(h, stream);
     BatchPtrs io{};
+    // Small batches take the latency kernel: one problem per workgroup of four wavefronts, compaction fused, carve from the
+    // configured maxima -- one launch, nothing read back.  Results are bitwise those of the throughput kernel.
+    const int team_cap = h->team_max_batch >= 0 ? h->team_max_batch : 2 * h->num_cus;
+    h->last_team = 0;
+#ifndef MPC_TRACE
+    if (h->kp.N == 20 && B <= team_cap && !h->reserved && !use_duo(h)) {
+        if (int r = ensure(h, h->ws, (size_t)B * h->kp.ws_stride * sizeof(double))) return r;
+        if (int r = ensure(h, h->counts, 4 * sizeof(int))) return r;
+        if (int r = ensure(h, h->evals, (size_t)B * 2 * sizeof(int32_t))) return r;
+        io.p = p; io.ws = (double*)h->ws.ptr; io.counts = nullptr; io.evals = (int32_t*)h->evals.ptr;
+        io.u0 = u0; io.y0 = y0; io.c0 = c0; io.u = u; io.cost = cost; io.status = status; io.inner_it = inner_it;
+        io.outer_it = outer_it; io.fpr = fpr; io.f2norm = f2norm; io.y_out = y_out; io.ms = ms;
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(s, &cap);
+        h->capturing = cap != hipStreamCaptureStatusNone;
+        KParams kt = h->kp;
+        fill_team_layout(kt, h->cfg);
+        const size_t lds_t = kt.l_total * sizeof(double);
+        if (lds_t <= 160 * 1024) {
+            auto kern = solve_kernel_team<20>;
+            if (lds_t > 64 * 1024)
+                HIP_OK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
+            if (!h->capturing) { HIP_OK(h, hipEventRecord(h->ev[0], s)); HIP_OK(h, hipEventRecord(h->ev[1], s)); HIP_OK(h, hipEventRecord(h->ev[2], s)); }
+            hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE * TEAM_WAVES), lds_t, s, kt, io, B);
+            HIP_OK(h, hipGetLastError());
+            if (!h->capturing) HIP_OK(h, hipEventRecord(h->ev[3], s));
+            h->timing_valid = !h->capturing;
+            h->last_B = B; h->last_team = 1; h->last_pairing = 0; h->last_min_waves = 1;
+            h->last_shape[0] = kt.mKs; h->last_shape[1] = kt.mKf; h->last_shape[2] = kt.mKd; h->last_shape[3] = (int)lds_t;
+            return 0;
+        }
+    }
+#endif
     if (int r = prepare(h, B, p, s, io, true)) return r;
     io.u0 = u0; io.y0 = y0; io.c0 = c0; io.u = u; io.cost = cost; io.status = status; io.inner_it = inner_it;
     io.outer_it = outer_it; io.fpr = fpr; io.f2norm = f2norm; io.y_out = y_out; io.ms = ms;
@@ -551,6 +617,10 @@ int32_t mpcgpu_set_option(void* handle, int32_t option, double value) {
             if (value != 0.0 && value != 1.0) return fail(h, -1, "linesearch fallback must be 0 (last trial) or 1 (tau = 0), got %g", value);
             h->kp.ls_fallback = (int)value;
             return 0;
+        case MPCGPU_OPT_TEAM_BATCH:
+            if (value < -1.0 || value != (double)(int)value) return fail(h, -1, "team batch must be -1 (automatic) or a batch size >= 0, got %g", value);
+            h->team_max_batch = (int)value;
+            return 0;
         case MPCGPU_OPT_PAIRING:
             if (value != -1.0 && value != 0.0 && value != 1.0) return fail(h, -1, "pairing must be -1 (automatic), 0 or 1, got %g", value);
             if (value == 1.0 && !duo_available(h)) return fail(h, -1, "two problems per wavefront are compiled for N_hor = 20 only (N_hor = %d)", h->kp.N);
@@ -584,6 +654,11 @@ int32_t mpcgpu_debug_read_trace(void* handle, int32_t B, double* out) {
 int32_t mpcgpu_last_waves_per_simd(void* handle) {
     Handle* h = (Handle*)handle;
     return h ? h->last_min_waves : -1;
+}
+
+int32_t mpcgpu_last_latency_kernel(void* handle) {
+    Handle* h = (Handle*)handle;
+    return h ? h->last_team : -1;
 }
 
 int32_t mpcgpu_last_problems_per_wavefront(void* handle) {

@@ -26,6 +26,7 @@ ABI_VERSION = 2
 _STREAM_OWN = C.c_void_p(-1)      # MPCGPU_STREAM_OWN: the handle's own non-blocking stream
 OPT_LINESEARCH_FALLBACK = 1       # MPCGPU_OPT_LINESEARCH_FALLBACK
 OPT_PAIRING = 2                   # MPCGPU_OPT_PAIRING
+OPT_TEAM_BATCH = 3                # MPCGPU_OPT_TEAM_BATCH
 
 
 def _stream_arg(stream):
@@ -56,7 +57,7 @@ class _CConfig(C.Structure):
 EXPORTS = ("mpcgpu_abi_version", "mpcgpu_create", "mpcgpu_destroy", "mpcgpu_last_error", "mpcgpu_num_params",
            "mpcgpu_solve_batch", "mpcgpu_solve_batch_dev", "mpcgpu_cost_grad_batch", "mpcgpu_last_timing",
            "mpcgpu_last_eval_counts", "mpcgpu_last_shape", "mpcgpu_last_waves_per_simd", "mpcgpu_reserve_shape",
-           "mpcgpu_set_option", "mpcgpu_last_problems_per_wavefront")
+           "mpcgpu_set_option", "mpcgpu_last_problems_per_wavefront", "mpcgpu_last_latency_kernel")
 
 
 def library_path() -> str:
@@ -122,6 +123,8 @@ def load_library(path: Optional[str] = None):
     L.mpcgpu_last_shape.restype = C.c_int32
     L.mpcgpu_last_waves_per_simd.argtypes = [vp]
     L.mpcgpu_last_waves_per_simd.restype = C.c_int32
+    L.mpcgpu_last_latency_kernel.argtypes = [vp]
+    L.mpcgpu_last_latency_kernel.restype = C.c_int32
     L.mpcgpu_last_problems_per_wavefront.argtypes = [vp]
     L.mpcgpu_last_problems_per_wavefront.restype = C.c_int32
     L.mpcgpu_reserve_shape.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
@@ -170,9 +173,11 @@ class BatchSolver:
     """One handle of libmpcgpu.so = one generated solver of the reference, for batches of problems."""
 
     def __init__(self, config: Optional[MpcConfig] = None, device: int = 0, library: Optional[str] = None,
-                 pairing: Optional[int] = None):
+                 pairing: Optional[int] = None, latency_batch: Optional[int] = None):
         """``pairing``: problems per wavefront of the solve kernel -- None = the library's rule (the faster layout: one),
-        1 or 2 to force a layout (MPCGPU_OPT_PAIRING; 2 exists for N_hor = 20; env MPCGPU_PAIRING overrides None)."""
+        1 or 2 to force a layout (MPCGPU_OPT_PAIRING; 2 exists for N_hor = 20; env MPCGPU_PAIRING overrides None).
+        ``latency_batch``: largest batch solved by the latency kernel (MPCGPU_OPT_TEAM_BATCH; None = the library's rule,
+        0 = never; env MPCGPU_TEAM_BATCH overrides None)."""
         self.config = config if config is not None else MpcConfig()
         self._L = load_library(library)
         self._h = C.c_void_p()
@@ -195,6 +200,10 @@ class BatchSolver:
                     "mpcgpu_set_option")
         if pairing is None and os.environ.get("MPCGPU_PAIRING"):
             pairing = int(os.environ["MPCGPU_PAIRING"])
+        if latency_batch is None and os.environ.get("MPCGPU_TEAM_BATCH"):
+            latency_batch = int(os.environ["MPCGPU_TEAM_BATCH"])
+        if latency_batch is not None:
+            self._check(self._L.mpcgpu_set_option(self._h, OPT_TEAM_BATCH, float(latency_batch)), "mpcgpu_set_option")
         if pairing is not None:
             if pairing not in (1, 2):
                 raise MpcGpuError(f"pairing must be 1 or 2 problems per wavefront, got {pairing!r}")
@@ -334,4 +343,5 @@ class BatchSolver:
         self._check(self._L.mpcgpu_last_shape(self._h, *[C.byref(x) for x in v]), "mpcgpu_last_shape")
         return dict(max_static=v[0].value, max_fleet=v[1].value, max_dyn=v[2].value, lds_bytes=v[3].value,
                     waves_per_simd=int(self._L.mpcgpu_last_waves_per_simd(self._h)),
-                    problems_per_wavefront=int(self._L.mpcgpu_last_problems_per_wavefront(self._h)))
+                    problems_per_wavefront=int(self._L.mpcgpu_last_problems_per_wavefront(self._h)),
+                    latency_kernel=bool(self._L.mpcgpu_last_latency_kernel(self._h)))
