@@ -1,11 +1,14 @@
 """DQN collection / learning loop (SB3 semantics of src/test_block_rl.py:68-86).
 CPU: a counting fake environment with the BatchedRaysEnv contract.  GPU: the real HIP environment."""
 import importlib
+import os
+import sys
 
 import numpy as np
 import pytest
 import torch
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dqn_train = importlib.import_module("trajtrack_mpcndqn_rlboost_amd.dqn_train")
 
 
@@ -169,3 +172,72 @@ def test_graph_replayed_update_equals_the_eager_update():
     assert outs[0][2] == outs[1][2] == 2
     assert np.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-7)
     assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_two_graph_update_with_the_rccl_all_reduce_on_the_gpu():
+    """BASELINE.json config 5's update path as it runs on more than one GPU -- graph A (forward, backward, gradient bucket),
+    the flat 1 177-float all-reduce on RCCL (backend "nccl"), graph B (average, clip, Adam) -- executed on the GPU.  With one
+    device visible the process group has a single rank (the collective still goes through RCCL on the device); the result
+    must equal the plain eager update.  Two or more devices: see test_two_rank_training_on_two_gpus."""
+    import torch.distributed as dist
+    dev = "cuda:0"
+    torch.cuda.set_device(0)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(dev))
+    try:
+        def batch(seed, n=32):
+            g = torch.Generator().manual_seed(seed)
+            return {k: v.to(dev) for k, v in dict(obs=torch.rand(n, 46, generator=g) * 2 - 1, actions=torch.randint(0, 9, (n,), generator=g),
+                                                   rewards=torch.randn(n, generator=g), next_obs=torch.rand(n, 46, generator=g) * 2 - 1,
+                                                   dones=(torch.rand(n, generator=g) < 0.1).float()).items()}
+        outs = []
+        for collective in (False, True):
+            torch.manual_seed(0)
+            tr = dqn_train.DqnTrainer(device=dev, target_update_interval=3, force_collective=collective)
+            if collective:
+                tr.enable_graph(32)
+                assert hasattr(tr, "_graph_b")                       # the two-graph structure was captured
+            losses = [float((tr.update_graphed if collective else tr.update)(batch(20 + i))) for i in range(8)]
+            outs.append((torch.cat([p.detach().reshape(-1) for p in tr.q_net.parameters()]).cpu(), losses))
+        assert np.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-7)
+        assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-7)
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_training_on_two_gpus():
+    """tools/train_dqn.py --gpus 2 run directly: it starts the two ranks itself, every update all-reduces the gradient bucket
+    over RCCL, rank 0 prints the JSON line."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip(f"needs 2 GPUs for a two-rank RCCL run, {torch.cuda.device_count()} visible (the single-GPU box); the same "
+                    "update path runs in test_two_graph_update_with_the_rccl_all_reduce_on_the_gpu and, over gloo, in "
+                    "tests/test_dqn_training_gloo.py")
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_dqn.py"), "--gpus", "2", "--envs", "512", "--timesteps",
+                        "40000", "--graph"], capture_output=True, text=True, timeout=900,
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["updates_per_s"] > 0
+
+
+@pytest.mark.gpu
+def test_training_tool_at_the_configured_per_gpu_size():
+    """Config 5, one rank's share: 4096 environments, collection + graph-replayed updates, JSON line at the end."""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_dqn.py"), "--envs", "4096", "--timesteps", "400000",
+                        "--graph"], capture_output=True, text=True, timeout=900,
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    print("\n[config 5, one rank]", json.dumps(line))
+    assert line["n_gpus"] == 1 and line["config"]["envs_per_gpu"] == 4096
+    assert line["value"] > 1e5 and line["updates_per_s"] > 100

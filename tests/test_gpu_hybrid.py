@@ -71,3 +71,34 @@ def test_recorded_run_feeds_the_metrics_class():
     assert avg["clearance"] > 0.5                      # robot radius: nobody touched an obstacle
     assert 60 < avg["finish_time"] < 120 and avg["deviation_distance"][1] < 3.0
     assert avg["smoothness"][0] < 0.2 and avg["computation_time"][0] > 0.0
+
+
+def test_hybrid_loop_at_the_configured_per_gpu_size():
+    """BASELINE.json config 4 is 8192 robots over 8 GPUs = 1024 robots per rank (no collective on the data path): one rank's
+    share for 30 ticks.  Properties: nobody collides, everybody makes progress along the path, the hybrid mode does switch to
+    the DQN's proposal for a part of the fleet, every tick is ONE batched solve; the per-tick breakdown is printed (and kept
+    under profiles/)."""
+    hybrid = importlib.import_module("trajtrack_mpcndqn_rlboost_amd.hybrid")
+    B, T = 1024, 30
+    loop, cfg, q, scenes = _setup(B)
+    run = hybrid.BatchedHybrid(cfg, scenes, q, decision_mode=2)
+    run.profile = True
+    calls0 = run.tracker.solver.calls if hasattr(run.tracker.solver, "calls") else None
+    for _ in range(T):
+        out = run.tick()
+    assert run.t == T
+    assert not out["collided"].any()
+    progress = run.env.path_progress.cpu().numpy()
+    assert progress.min() > 0.5 * T * 0.2 * 0.5          # everybody moved (speed reference 1 m/s, 0.2 s ticks), nobody is stuck at the start
+    x = out["states"][:, 0]
+    assert x.min() > 1.0 and x.max() < 9.0               # 30 ticks: between the start and the box / obstacle region
+    frac = (run.switch_ticks > 0).mean()
+    hist = np.bincount(np.minimum(run.switch_ticks, 10), minlength=11)
+    tot = sum(run.phase_seconds.values())
+    print(f"\n[config 4, one rank] B={B}, {T} ticks, {1e3 * tot / T:.1f} ms per tick; robots that tracked the DQN proposal on some tick: "
+          f"{frac:.3f}; ticks on the proposal per robot (0..9, >=10): {hist.tolist()}")
+    for k, v in run.phase_seconds.items():
+        print(f"    {k:42s} {1e3 * v / T:8.2f} ms/tick  {100 * v / tot:5.1f} %")
+    assert 0.0 <= frac <= 1.0 and run.switch_ticks.max() <= T
+    if calls0 is not None:
+        assert run.tracker.solver.calls - calls0 == T

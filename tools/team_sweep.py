@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Where the latency kernel stops paying: kernel time of the same batch with the latency kernel (one problem per workgroup of
+four wavefronts) and with the throughput kernel (one problem per wavefront), by batch size.  usage: team_sweep.py [family]"""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from trajtrack_mpcndqn_rlboost_amd import MpcConfig, BatchSolver, scenes
+fam = sys.argv[1] if len(sys.argv) > 1 else "passing"
+kw = dict(dyn_clearance=0.1, box_clearance=0.3) if fam == "passing" else {}
+cfg = MpcConfig()
+team, solo = BatchSolver(cfg, latency_batch=1 << 20), BatchSolver(cfg, latency_batch=0)
+print(f"{fam} family, N_hor = 20, 8 dynamic obstacles; kernel ms (best of 3)")
+for B in (64, 256, 512, 768, 1024, 1536, 2048, 4096):
+    p = scenes.make_batch(cfg, B, n_dyn=8, seed=1236, **kw)["p"]
+    t = {}
+    for name, bs in (("latency", team), ("throughput", solo)):
+        best = 1e30
+        for _ in range(3):
+            bs.solve(p)
+            tm = bs.last_timing()
+            best = min(best, tm["solve_ms"] + tm["prep_ms"])
+        t[name] = best
+    print(f"  B={B:5d}: latency kernel {t['latency']:8.2f}   throughput kernel {t['throughput']:8.2f}   ratio {t['throughput'] / t['latency']:.2f}")

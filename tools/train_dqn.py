@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """DQN training on the batched HIP environment (BASELINE.json config 5 in miniature, one GPU per process).
 
-    python tools/train_dqn.py [--envs 4096] [--timesteps 4000000] [--gradient-steps 16] [--batch-size 256]
+    python tools/train_dqn.py [--gpus N] [--envs 4096] [--timesteps 4000000] [--gradient-steps 16] [--batch-size 256]
+
+`--gpus N` without a launcher starts the N ranks itself (fresh child processes of torch.distributed.run, before anything in
+this process touches a GPU); it exits non-zero when fewer than N devices are visible.  Rank 0 ends with ONE JSON line
+(environment steps/s and DDQN updates/s of the whole job, ranks, backend).
 
 Every environment is scene 1 of the reference (src/pkg_dqn/utils/map.py:292-305) with the 'medium' box and a periodic
 obstacle, start pose jittered per environment; the reference path is the straight line start -> goal (an input; the
@@ -9,7 +13,10 @@ reference gets it from A*).  Under torch.distributed (torchrun, backend nccl = R
 environments and the gradients are summed by one flat all-reduce per update.  Prints throughput and the return curve."""
 import argparse
 import importlib
+import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,16 +42,35 @@ def scene(rng):
         start=[0.6, y0, th, 0.0, 0.0], goal=[15.4, 3.5], path=[(0.6, y0), (6.4, 5.4), (9.6, 5.4), (15.4, 3.5)])
 
 
+def self_launch(gpus: int) -> int:
+    if torch.cuda.device_count() < gpus:
+        print(f"train_dqn.py: --gpus {gpus} but only {torch.cuda.device_count()} GPU(s) visible", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--timesteps", type=int, default=4_000_000)
     ap.add_argument("--gradient-steps", type=int, default=16)
     ap.add_argument("--batch-size", type=int, default=256)
     ap.add_argument("--double-q", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="replay the update from a captured HIP graph (single process)")
+    ap.add_argument("--graph", action="store_true", help="replay the update from captured HIP graphs (multi-rank: two graphs around the all-reduce)")
     args = ap.parse_args()
+    if os.environ.get("WORLD_SIZE") is None and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus and (world > 1 or args.gpus > 1):
+        sys.exit(f"train_dqn.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -75,6 +101,16 @@ def main():
         print(f"envs/rank {args.envs} x ranks {world}: {world * stats['timesteps'] / dt:.3e} environment steps/s incl. "
               f"{stats['updates']} updates of batch {args.batch_size} ({stats['updates'] / dt:.0f} updates/s), "
               f"episodes {stats['episodes']}, final mean return {stats['mean_return']:.2f}, success rate {stats['success_rate']:.2f}")
+        print(json.dumps({"metric": "DQN online training: environment steps/s (batched HIP environment + DDQN updates)",
+                          "value": world * stats["timesteps"] / dt, "unit": "environment steps/s", "n_gpus": world,
+                          "rccl_ranks": dist.get_world_size() if world > 1 else 1, "backend": "nccl" if world > 1 else None,
+                          "updates_per_s": stats["updates"] / dt, "gradient_all_reduce_floats": 1177 if world > 1 else 0,
+                          "update_path": "two HIP graphs around one flat RCCL all-reduce" if (args.graph and world > 1) else
+                                         ("one HIP graph" if args.graph else "eager"),
+                          "config": {"workload": "BASELINE.json config 5 (scene 1, medium box, periodic obstacle)",
+                                     "envs_per_gpu": args.envs, "timesteps_per_gpu": int(stats["timesteps"]),
+                                     "batch_size": args.batch_size, "gradient_steps": args.gradient_steps, "double_q": bool(args.double_q)},
+                          "success_rate": stats["success_rate"], "mean_return": stats["mean_return"]}))
     if world > 1:
         dist.destroy_process_group()
 

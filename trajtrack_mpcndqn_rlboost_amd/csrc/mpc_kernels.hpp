@@ -53,8 +53,6 @@ constexpr int SEGW = 9;        // LDS / workspace doubles per reference segment:
                                // bounding circle (cx, cy, R) of ALL segments from this one to the last, + 1 pad: the odd
                                // stride spreads the records of neighbouring steps over all LDS banks (an even stride
                                // gave 3-way conflicts on every segment read: -1.8 % kernel time)
-constexpr int SEGC = 3;        // "cold" per-segment fields (midpoint x, y, half length), only read by the rare per-segment
-                               // pruning pass: they stay in the workspace (L2) and cost no LDS
 constexpr int STCW = 12;       // doubles per static obstacle    (b[4], a0[4], a1[4])
 constexpr int DYNW = 9;        // workspace record per (dyn row, step): cx, cy, cosA, sinA, ihx, ihy, isx, isy, wgt
 constexpr int DYNP = 2;        // shape-constant LDS record per (row, step): cx, cy
@@ -84,7 +82,7 @@ struct KParams {
     // parameter-vector offsets (mpc_generator.py:179-188)
     int r0, c0, os0, od0, qs0, qd0;
     // workspace (global) layout per problem, doubles
-    int ws_stride, ws_vref, ws_seg, ws_segc, ws_stc, ws_fxy, ws_dyn, ws_qd, ws_alpha, ws_lbs, ws_lby, ws_lold;
+    int ws_stride, ws_vref, ws_seg, ws_stc, ws_fxy, ws_dyn, ws_qd, ws_alpha, ws_lbs, ws_lby, ws_lold;
     // LDS layout (doubles), strides use the batch maxima mKs/mKf/mKd
     int mKs, mKf, mKd;
     int reserved;  // 1: the carve comes from mpcgpu_reserve_shape, problems are checked against it on the device
@@ -394,9 +392,6 @@ __device__ __forceinline__ void prep_problem(const KParams& kp, const double* __
         double* sg = ws + kp.ws_seg + SEGW * i;
         sg[0] = s1x; sg[1] = s1y; sg[2] = dx; sg[3] = dy;
         sg[4] = 1.0 / (dx * dx + dy * dy + 1e-16);
-        double* sc = ws + kp.ws_segc + SEGC * i;
-        sc[0] = s1x + 0.5 * dx; sc[1] = s1y + 0.5 * dy;
-        sc[2] = 0.5 * sqrt(dx * dx + dy * dy) * (1.0 + 1e-12);
         // bounding circle of the reference points i..N-1 (every remaining segment lies inside it)
         double xlo = s1x, xhi = s1x, ylo = s1y, yhi = s1y;
         for (int j = i + 1; j < N; ++j) {
@@ -520,7 +515,6 @@ struct Ctx {
     double vref;  // vector lane k: speed reference of step k
     // LDS tables
     double *seg, *stc, *fxy, *dyn, *dync, *qd, *pos, *H, *W, *part, *stash;
-    const double* segc;  // cold segment fields, in the workspace (global memory)
 };
 constexpr int KC_BASE = 32;
 #define KC(i) (cx.hd[KC_BASE + (i)])
@@ -554,7 +548,6 @@ __device__ __forceinline__ void load_problem(const KParams& kp, const double* __
     cx.terminal = U(H_QN) != 0.0 || U(H_QTHN) != 0.0;
     cx.vref = cx.vl ? ws[kp.ws_vref + lane] : 0.0;
     cx.seg = lds + kp.l_seg; cx.stc = lds + kp.l_stc; cx.fxy = lds + kp.l_fxy;
-    cx.segc = ws + kp.ws_segc;
     cx.dyn = lds + kp.l_dyn; cx.dync = lds + kp.l_dync; cx.qd = lds + kp.l_qd; cx.pos = lds + kp.l_pos; cx.H = lds + kp.l_H;
     cx.W = lds + kp.l_W; cx.part = lds + kp.l_part; cx.stash = lds + kp.l_stash;
     // coalesced table copies HBM -> LDS (only the active entries of this problem)
@@ -678,8 +671,8 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         const int k = c_ik;
         px = cx.pos[2 * k]; py = cx.pos[2 * k + 1];
         // reference-path deviation: min over segments i >= k (mpc_generator.py:207,116-130,28-36).
-        // Exact pruning: a segment whose midpoint is farther than sqrt(best) + half its length cannot hold the
-        // minimum (nor tie with it), so its distance is not evaluated; the value and arg-min are unchanged.
+        // Exact pruning: segments inside a circle that is farther from the robot than sqrt(best) cannot hold the minimum
+        // (nor tie with it), so their distances are not evaluated; the value and the arg-min are unchanged.
         double sb = inf;  // upper bound of sqrt(best)
         // (1) the SEG_WIN * LPS segments of this step nearest in index are always evaluated
         int i = k + c_isub;
@@ -698,35 +691,40 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
                 bgy = 2.0 * (wd * dy - wy);
             }
         }
-        // (2) all remaining segments of this lane lie in the bounding circle stored with segment k + SEG_WIN*LPS:
-        //     if that circle is farther than sqrt(best) for every lane, nobody evaluates them
+        // (2) every later segment of this lane lies in the bounding circle stored with segment i (the circle of ALL segments
+        //     from i to the end of the path): while that circle is within sqrt(best) of the robot, segment i is evaluated; as
+        //     soon as it is not, nothing from i on can hold the minimum (nor tie with it) and the lane is done.  The suffix
+        //     circles recede along the path, so a lane leaves after the few segments that are actually near its position.
         bool more = false;
         if (i < N) {
             sb = sqrt(best) * KC(K_SQRT);
-            const double* sg = cx.seg + SEGW * (k + SEG_WIN * LPS);
+            const double* sg = cx.seg + SEGW * i;
             const double bx = px - sg[5], by = py - sg[6], reach = (sb + sg[7]) * KC(K_REACH);
             more = bx * bx + by * by < reach * reach;
         }
         if (P::any(more)) {
-            // (3) rare: per-segment test (midpoint distance vs sqrt(best) + half length), evaluate on demand
+            PROF_COUNT(23);
             MPC_ITEM_LOOP
-            for (; i < N; i += LPS) {
+            while (more) {
                 const double* sg = cx.seg + SEGW * i;
-                const double* sc = cx.segc + SEGC * i;
-                const double mx = px - sc[0], my = py - sc[1], reach = (sb + sc[2]) * KC(K_REACH);
-                if (mx * mx + my * my < reach * reach) {
-                    const double s1x = sg[0], s1y = sg[1], dx = sg[2], dy = sg[3], inv = sg[4];
-                    const double th = ((px - s1x) * dx + (py - s1y) * dy) * inv;
-                    const double t = clampd(th, 0.0, 1.0);
-                    const double wx = s1x + t * dx - px, wy = s1y + t * dy - py;
-                    const double d2 = wx * wx + wy * wy;
-                    if (d2 < best) {
-                        best = d2;
-                        sb = sqrt(d2) * KC(K_SQRT);
-                        const double wd = (th >= 0.0 && th <= 1.0) ? (wx * dx + wy * dy) * inv : 0.0;
-                        bgx = 2.0 * (wd * dx - wx);
-                        bgy = 2.0 * (wd * dy - wy);
-                    }
+                const double s1x = sg[0], s1y = sg[1], dx = sg[2], dy = sg[3], inv = sg[4];
+                const double th = ((px - s1x) * dx + (py - s1y) * dy) * inv;
+                const double t = clampd(th, 0.0, 1.0);
+                const double wx = s1x + t * dx - px, wy = s1y + t * dy - py;
+                const double d2 = wx * wx + wy * wy;
+                if (d2 < best) {
+                    best = d2;
+                    sb = sqrt(d2) * KC(K_SQRT);
+                    const double wd = (th >= 0.0 && th <= 1.0) ? (wx * dx + wy * dy) * inv : 0.0;
+                    bgx = 2.0 * (wd * dx - wx);
+                    bgy = 2.0 * (wd * dy - wy);
+                }
+                i += LPS;
+                more = false;
+                if (i < N) {
+                    const double* sn = cx.seg + SEGW * i;
+                    const double bx = px - sn[5], by = py - sn[6], reach = (sb + sn[7]) * KC(K_REACH);
+                    more = bx * bx + by * by < reach * reach;
                 }
             }
         }

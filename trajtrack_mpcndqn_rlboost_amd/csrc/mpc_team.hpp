@@ -57,7 +57,6 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
         cx.terminal = U(H_QN) != 0.0 || U(H_QTHN) != 0.0;
         cx.vref = cx.vl ? ws[kp.ws_vref + lane] : 0.0;
         cx.seg = lds + kp.l_seg; cx.stc = lds + kp.l_stc; cx.fxy = lds + kp.l_fxy;
-        cx.segc = ws + kp.ws_segc;
         cx.dyn = lds + kp.l_dyn; cx.dync = cx.dyn; cx.qd = cx.dyn;
         cx.pos = mine + kp.l_pos; cx.H = mine + kp.l_H; cx.W = mine + kp.l_W; cx.part = mine + kp.l_part; cx.stash = mine + kp.l_stash;
         const int T = WAVE * TEAM_WAVES;
@@ -101,6 +100,9 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
     double ev = uv, ew = uw;
     bool want_grad = true;
     EvalOut o;
+#ifdef MPC_PROFILE
+    Prof prof; prof.start();  // the phase profiler is a tool of the throughput kernel; here it only keeps the signature
+#endif
 
     // verdicts of a pass: every wavefront publishes one flag, all read the four of them
     auto publish = [&](double flag, double* all) {
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
     auto trial_point = [&](double t) { ev = panoc_trial(uv, rv_, dv, t); ew = panoc_trial(uw, rw_, dw, t); };
 
     for (;;) {
-        eval_point<NT, SC, P>(kp, cx, ev, ew, c, icm, ya, yb, want_grad, state == TS_OUTER, o);
+        eval_point<NT, SC, P>(kp, cx, ev, ew, c, icm, ya, yb, want_grad, state == TS_OUTER, o PROF_PASS);
         bool step_begin = false;
 
         if (state == TS_INIT0) {

@@ -23,9 +23,14 @@ from .dqn import QNetwork
 class DqnTrainer:
     def __init__(self, q_net: Optional[QNetwork] = None, lr: float = 1e-4, gamma: float = 0.98,
                  target_update_interval: int = 10_000, max_grad_norm: float = 10.0, double_q: bool = False,
-                 device: str = "cpu"):
+                 device: str = "cpu", force_collective: bool = False):
+        """``force_collective``: run the gradient all-reduce (and the two-graph replay built around it) even when the process
+        group has ONE rank -- the multi-rank code path, collective included, on a single GPU (tests)."""
         self.q_net = (q_net if q_net is not None else QNetwork()).to(device)
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if force_collective and not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("force_collective needs an initialised process group")
+        self._collective = self.world > 1 or force_collective
         self._params = [p for p in self.q_net.parameters()]
         self._bucket = torch.zeros(sum(p.numel() for p in self._params), dtype=torch.float32, device=device)
         if self.world > 1:
@@ -118,7 +123,7 @@ class DqnTrainer:
                 self._eager_step(self._g_batch)
         torch.cuda.current_stream().wait_stream(side)
         self._graph = torch.cuda.CUDAGraph()
-        if self.world == 1:
+        if not self._collective:
             with torch.cuda.graph(self._graph):
                 self._g_loss.copy_(self._eager_step(self._g_batch))
         else:
@@ -151,7 +156,7 @@ class DqnTrainer:
 
     def _eager_step(self, batch: Dict[str, torch.Tensor]) -> torch.Tensor:
         loss = self._backward(batch)
-        if self.world > 1:
+        if self._collective:
             self._all_reduce_gradients()
         self._apply()
         return loss
@@ -161,7 +166,7 @@ class DqnTrainer:
         for k, v in self._g_batch.items():
             v.copy_(batch[k])
         self._graph.replay()
-        if self.world > 1:
+        if self._collective:
             dist.all_reduce(self._bucket, op=dist.ReduceOp.SUM)
             self._graph_b.replay()
         self.num_updates += 1

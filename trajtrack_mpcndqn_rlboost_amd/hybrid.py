@@ -282,8 +282,23 @@ class BatchedHybrid:
     def _flat(self, obs):
         return self._torch.cat([obs["external"], obs["internal"]], dim=1)
 
+    def _mark(self, name: str) -> None:
+        """Per-tick breakdown (``self.phase_seconds``; enabled by ``self.profile = True``): wall time between marks with the
+        device drained at every mark, so that a phase is charged with the kernels it launched."""
+        if not getattr(self, "profile", False):
+            return
+        import time
+        self._torch.cuda.synchronize()
+        now = time.perf_counter()
+        if not hasattr(self, "phase_seconds"):
+            self.phase_seconds = {}
+        if name != "start":
+            self.phase_seconds[name] = self.phase_seconds.get(name, 0.0) + now - self._last_mark
+        self._last_mark = now
+
     def tick(self) -> Dict[str, np.ndarray]:
         torch, cfg, env, trk = self._torch, self.config, self.env, self.tracker
+        self._mark("start")
         dyn_now = self.dynamic_positions()
         if self.last_dyn is None:
             self.last_dyn = dyn_now
@@ -293,6 +308,7 @@ class BatchedHybrid:
             preds = np.where(has, constant_velocity_prediction(self.last_dyn, dyn_now, steps=cfg.N_hor), 0.0)
         self.last_dyn = dyn_now
         live = ~self.done
+        self._mark("obstacle predictions (host)")
 
         if self.mode == 0:                                   # pure DQN: main.py:139-152
             actions = self.q_net.greedy_actions(self._flat(self.obs))
@@ -305,13 +321,17 @@ class BatchedHybrid:
             env.set_agent_state(st)
             if self.mode == 1:                               # main.py:154-157: env.step(0) "just for ... status"
                 self.obs, _, term, trunc, info = env.step(torch.zeros(self.B, dtype=torch.int32))
+                self._mark("environment kernel")
                 chosen = trk.local_refs()
+                self._mark("local reference (host)")
             else:                                            # main.py:176-214
                 actions = self.q_net.greedy_actions(self._flat(self.obs)).cpu().numpy()
+                self._mark("Q-network")
                 env.state[:, 5] += env.time_step             # step_obstacles()
                 self.obs = env.observe()                     # update_status() + get_observation()
                 term = env.terminated.bool()
                 info = {"success": env.flags[:, 2]}
+                self._mark("environment kernel")
                 rl_ref, _ = rl_reference(env.agent_state.cpu().numpy(), actions, cfg.ts, steps=20, ref_speed=1.0)
                 original = trk.local_refs()
                 proposal = merge_reference(rl_ref[:, :cfg.N_hor], original)
@@ -328,10 +348,12 @@ class BatchedHybrid:
                 self.switch_on = on & live
                 self.switch_ticks += self.switch_on
                 chosen = np.where(self.switch_on[:, None, None], filtered, original)
+                self._mark("RL reference + switch (host)")
             if kmax:
                 trk.set_dynamic_constraints(preds)
             trk.active &= live
             trk.step(refs=chosen)
+            self._mark("parameter assembly + batched MPC solve")
             # get_action returns None once the tracker's own termination test fires (interface_mpc.py:83-85)
             self.done |= live & ~trk.active
         term = term.cpu().numpy().astype(bool)
@@ -341,6 +363,7 @@ class BatchedHybrid:
         self.done |= live & term
         self.steps += live
         self.t += 1
+        self._mark("bookkeeping (host)")
         return dict(done=self.done.copy(), success=self.success.copy(), collided=self.collided.copy(),
                     switch_on=self.switch_on.copy(), states=trk.states.copy())
 
