@@ -77,9 +77,17 @@ def test_selection_rule_and_single_problem_call():
     few = bs.solve(sc["p"][100:108])
     assert np.array_equal(few.solution, big.solution[100:108])
     bs.close()
-    # a horizon without the compiled latency kernel keeps the throughput kernel
-    cfg12 = make_cfg(12, solver_max_inner_iterations=10, solver_max_outer_iterations=2)
-    bs = BatchSolver(cfg12)
-    bs.solve(scenes.make_batch(cfg12, 4, n_dyn=2, seed=1)["p"])
-    assert not bs.last_shape()["latency_kernel"]
-    bs.close()
+
+
+@pytest.mark.parametrize("N,caps", [(40, (500, 10)), (12, (60, 4)), (33, (40, 3))])
+def test_latency_kernel_for_other_horizons(N, caps):
+    """Compiled horizon 40 and the runtime-horizon instantiation (12, 33): bitwise equal to the throughput kernel too."""
+    cfg = make_cfg(N, solver_max_inner_iterations=caps[0], solver_max_outer_iterations=caps[1])
+    B = 12
+    sc = scenes.make_batch(cfg, B, n_dyn=5, seed=40 + N, dyn_clearance=0.1, box_clearance=0.3)
+    fast, seq = BatchSolver(cfg), BatchSolver(cfg, latency_batch=0)
+    for u0 in (None, np.tile([0.6, 0.1], (B, N))):
+        a, b = fast.solve(sc["p"], u0), seq.solve(sc["p"], u0)
+        assert fast.last_shape()["latency_kernel"] and not seq.last_shape()["latency_kernel"]
+        _same(a, b)
+    fast.close(); seq.close()

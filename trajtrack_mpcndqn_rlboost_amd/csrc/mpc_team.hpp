@@ -33,7 +33,7 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
     extern __shared__ __attribute__((aligned(16))) double lds[];
     using P = Solo<NT>;
     constexpr bool SC = false;  // general tables: no batch-wide shape information is needed before the launch
-    constexpr int N = NT, RV = P::RV;
+    const int N = NT ? NT : kp.N;  // compile-time horizon (0 = runtime horizon from KParams)
     const int b = blockIdx.x;
     if (b >= B) return;
     const long long t_start = wall_clock64();
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
     double icm = uniform(1.0 / fmax(c, 1.0));
     ya = clampd(ya, -KC(K_YBOUND), KC(K_YBOUND)); yb = clampd(yb, -KC(K_YBOUND), KC(K_YBOUND));
     double gv = 0, gw = 0, hv = 0, hw = 0, rv_ = 0, rw_ = 0, dv = 0, dw = 0;
-    double gamma = 0, Lip = 0, sigma = 0, cost = 0, nfpr = 0, tau = 1, rhs = 0, nh = 1, gg = 0, d2h = 0, ip = 0;
+    double gamma = 0, Lip = 0, sigma = 0, cost = 0, nfpr = 0, rhs = 0, nh = 1, gg = 0, d2h = 0, ip = 0;
     double akkt_tol = kp.init_tol;
     int iter = 0, num_iter = 0, lip_it = 0, nls = 0, t0 = 0;
     bool cont_iters = true, cont_time = true;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
             int winner = 0;
             for (int j = TEAM_WAVES - 1; j >= 1; --j) if (all[j] != 0.0) winner = j;
             if (winner) {
-                nls = winner - 1; tau = exp2(-(double)nls);
+                nls = winner - 1;
                 n_eval += nls + 1; n_eval_grad += nls + 1;
                 adopt(winner, uniform(o.psi), tgg, td2h, thv, thw);
                 ++iter;
@@ -234,11 +234,10 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
             int winner = -1;
             for (int j = TEAM_WAVES - 1; j >= 0; --j) if (all[j] != 0.0) winner = j;
             if (winner >= 0) {
-                nls = t0 + winner; tau = exp2(-(double)nls);
+                nls = t0 + winner;
                 n_eval += winner + 1; n_eval_grad += winner + 1;
                 if (all[winner] == 2.0 && kp.ls_fallback == 1) {
                     // 10 halvings without acceptance, tau = 0 reading: u - gamma*fpr is evaluated and taken
-                    tau = 0.0;
                     ev = uv - rv_; ew = uw - rw_;
                     want_grad = true; state = TS_FALLBACK;
                     continue;
@@ -289,7 +288,7 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
             ++alm_iteration; ++num_outer;
             dy_norm = dy_norm_plus; f2_norm = f2_norm_plus;
             ya = clampd(ypa, -KC(K_YBOUND), KC(K_YBOUND)); yb = clampd(ypb, -KC(K_YBOUND), KC(K_YBOUND));
-            lb.flush(); tau = 1.0; Lip = 0; sigma = 0; gamma = 0; iter = 0;
+            lb.flush(); Lip = 0; sigma = 0; gamma = 0; iter = 0;
             num_iter = 0; cont_iters = true; cont_time = true;
             ev = uv; ew = uw; want_grad = true; state = TS_INIT0;
             continue;

@@ -353,7 +353,7 @@ int32_t mpcgpu_solve_batch_dev(void* handle, int32_t B, const double* p, const d
     const int team_cap = h->team_max_batch >= 0 ? h->team_max_batch : 3 * h->num_cus;  // measured break-even: ~1000 problems (tools/team_sweep.py)
     h->last_team = 0;
 #ifndef MPC_TRACE
-    if (h->kp.N == 20 && B <= team_cap && !h->reserved && !use_duo(h)) {
+    if (B <= team_cap && !h->reserved && !use_duo(h)) {
         if (int r = ensure(h, h->ws, (size_t)B * h->kp.ws_stride * sizeof(double))) return r;
         if (int r = ensure(h, h->counts, 4 * sizeof(int))) return r;
         if (int r = ensure(h, h->evals, (size_t)B * 2 * sizeof(int32_t))) return r;
@@ -366,12 +366,21 @@ int32_t mpcgpu_solve_batch_dev(void* handle, int32_t B, const double* p, const d
         KParams kt = h->kp;
         fill_team_layout(kt, h->cfg);
         const size_t lds_t = kt.l_total * sizeof(double);
-        if (lds_t <= 160 * 1024) {
-            auto kern = solve_kernel_team<20>;
-            if (lds_t > 64 * 1024)
-                HIP_OK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t));
+        if (lds_t <= 160 * 1024) {   // else (long horizons with many obstacle slots): the throughput kernel below
             if (!h->capturing) { HIP_OK(h, hipEventRecord(h->ev[0], s)); HIP_OK(h, hipEventRecord(h->ev[1], s)); HIP_OK(h, hipEventRecord(h->ev[2], s)); }
-            hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE * TEAM_WAVES), lds_t, s, kt, io, B);
+#define LAUNCH_TEAM(NT)                                                                                              \
+    do {                                                                                                             \
+        auto kern = solve_kernel_team<NT>;                                                                           \
+        if (lds_t > 64 * 1024)                                                                                       \
+            HIP_OK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t)); \
+        hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE * TEAM_WAVES), lds_t, s, kt, io, B);                             \
+    } while (0)
+            switch (h->kp.N) {
+                case 20: LAUNCH_TEAM(20); break;
+                case 40: LAUNCH_TEAM(40); break;
+                default: LAUNCH_TEAM(0); break;
+            }
+#undef LAUNCH_TEAM
             HIP_OK(h, hipGetLastError());
             if (!h->capturing) HIP_OK(h, hipEventRecord(h->ev[3], s));
             h->timing_valid = !h->capturing;
