@@ -9,8 +9,15 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "mpcgpu.h"
+
+static double now_ms(void) {
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return 1e3 * (double)t.tv_sec + 1e-6 * (double)t.tv_nsec;
+}
 
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 4;
@@ -57,9 +64,19 @@ int main(int argc, char** argv) {
         if (status[b] != MPCGPU_CONVERGED || !(u[(size_t)b * n] > 1.0 && u[(size_t)b * n] <= 1.2 + 1e-9) ||
             !(u[(size_t)b * n + 1] > -1e-6 && u[(size_t)b * n + 1] < 1e-6)) bad = 1;
     }
+    /* what one tick of a single-robot user costs: the same call again, timed from host buffers in to results out */
+    double best = 1e30;
+    for (int r = 0; r < 10; ++r) {
+        const double t0 = now_ms();
+        if (mpcgpu_solve_batch(h, B, p, NULL, NULL, NULL, u, cost, status, inner, NULL, NULL, NULL, NULL, NULL) != 0) return 3;
+        const double dt = now_ms() - t0;
+        if (dt < best) best = dt;
+    }
     double prep_ms = 0, solve_ms = 0;
     mpcgpu_last_timing(h, &prep_ms, &solve_ms);
-    printf("kernel time: prep %.3f ms, solve %.3f ms; %d wavefronts per SIMD\n", prep_ms, solve_ms, mpcgpu_last_waves_per_simd(h));
+    printf("kernel time: prep %.3f ms, solve %.3f ms; %d wavefronts per SIMD; latency kernel %d\n", prep_ms, solve_ms,
+           mpcgpu_last_waves_per_simd(h), mpcgpu_last_latency_kernel(h));
+    printf("call (host buffers in, results out), best of 10: %.3f ms for %d problem(s)\n", best, B);
     mpcgpu_destroy(h);
     free(p); free(u); free(cost); free(status); free(inner);
     return bad;

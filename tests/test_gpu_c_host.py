@@ -20,3 +20,10 @@ def test_plain_c_program_solves_through_the_c_abi(tmp_path):
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("problem")]
     assert len(lines) == 6 and all("status 0" in ln for ln in lines)
     assert "wavefronts per SIMD" in out.stdout
+    # the reference's call pattern: ONE problem per call -> the latency kernel; end to end well under a millisecond
+    one = subprocess.run([exe, "1"], capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0, one.stdout + one.stderr
+    print("\n" + one.stdout)
+    assert "latency kernel 1" in one.stdout
+    call_ms = float(one.stdout.split("best of 10:")[1].split("ms")[0])
+    assert call_ms < 0.8, call_ms
