@@ -5,10 +5,12 @@
 
 A step = one pass of the hot path over one batch: B independent cold-start solves (u0 = 0, what every
 reference call site does: src/interface_mpc.py:82 passes initial_guess=None) of the metric configuration
-named in BASELINE.json -- mpc_default.yaml, N_hor = 20, 8 dynamic obstacles -- on B = 32768 robots per GPU,
-with the parameter vectors already resident in HBM.  (A solve takes 0.1-0.2 s of device time and ~4000 run
-concurrently, so a batch of a few thousand spends a fifth of its time in the tail of the last stragglers;
-`--batch` selects other sizes.)
+named in BASELINE.json -- mpc_default.yaml, N_hor = 20, 8 dynamic obstacles -- on B = 65536 robots per GPU,
+with the parameter vectors already resident in HBM.  (A solve takes 0.1-0.2 s of device time and 4096 run
+concurrently; the last problems of a launch finish on a draining GPU, which costs about 0.12 s per launch whatever
+the batch: measured 23.8 / 25.7 / 27.1 / 27.7 thousand solves/s at B = 16384 / 32768 / 65536 / 131072
+(profiles/r02_batch_scaling.txt; round 1 and the first half of round 2 benchmarked B = 32768).  `--batch` selects
+other sizes.)
 
 Multi-GPU (N > 1): one process per GPU; the batch shards across ranks with no data-path collective (weak
 scaling: every rank owns its own B robots); RCCL is used only for the barrier, the max-over-ranks time and
@@ -63,7 +65,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=32768, help="problems per GPU per step")
+    ap.add_argument("--batch", type=int, default=65536, help="problems per GPU per step")
     ap.add_argument("--n-dyn", type=int, default=8)
     ap.add_argument("--horizon", type=int, default=20)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 disables)")

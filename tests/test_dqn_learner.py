@@ -183,8 +183,12 @@ def test_two_graph_update_with_the_rccl_all_reduce_on_the_gpu():
     import torch.distributed as dist
     dev = "cuda:0"
     torch.cuda.set_device(0)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29541")
+    import socket
+    with socket.socket() as sk:                                   # a free port for the one-rank rendezvous
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
     created = not dist.is_initialized()
     if created:
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(dev))
