@@ -159,8 +159,8 @@ int32_t mpcgpu_reserve_shape(void* handle, int32_t max_static, int32_t max_fleet
  *     their results differ by floating-point summation order only.
  *   MPCGPU_OPT_TEAM_BATCH  largest batch that is solved by the LATENCY kernel (csrc/mpc_team.hpp: one problem per workgroup of
  *       four wavefronts that evaluate the Lipschitz test and the line-search trials of a PANOC step side by side; compaction
- *       fused; LDS carve from the configured maxima, nothing read back before the launch).  -1 (default): 3 x the number of
- *       compute units (the measured break-even against the throughput kernel is ~1000 problems); 0 switches it off.  Every horizon
+ *       fused; LDS carve from the configured maxima, nothing read back before the launch).  -1 (default): 4 x the number of
+ *       compute units (the measured break-even against the throughput kernel is 1000-1500 problems); 0 switches it off.  Every horizon
  *       whose carve fits the 160 KiB of a compute unit; results are bitwise those of the throughput kernel.
  */
 enum { MPCGPU_OPT_LINESEARCH_FALLBACK = 1, MPCGPU_OPT_PAIRING = 2, MPCGPU_OPT_TEAM_BATCH = 3 };

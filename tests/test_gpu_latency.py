@@ -67,10 +67,10 @@ def test_latency_kernel_with_short_caps_warm_start_and_multipliers():
 
 def test_selection_rule_and_single_problem_call():
     cfg = make_cfg(20)
-    sc = scenes.make_batch(cfg, 1024, n_dyn=4, seed=3, dyn_clearance=0.1, box_clearance=0.3)
+    sc = scenes.make_batch(cfg, 2048, n_dyn=4, seed=3, dyn_clearance=0.1, box_clearance=0.3)
     bs = BatchSolver(cfg)
     big = bs.solve(sc["p"])
-    assert not bs.last_shape()["latency_kernel"]                  # 1024 > 3 x 256 compute units
+    assert not bs.last_shape()["latency_kernel"]                  # 2048 > 4 x 256 compute units
     one = bs.solve(sc["p"][17])
     assert bs.last_shape()["latency_kernel"]
     assert np.array_equal(one.solution[0], big.solution[17]) and one.status[0] == big.status[17]

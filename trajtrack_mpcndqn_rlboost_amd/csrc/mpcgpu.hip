@@ -41,7 +41,7 @@ struct Handle {
     bool shape_const = true;  // of the batch prepared last
     int last_min_waves = 0;   // launch-bounds variant of the last solve (3 or 4 wavefronts per SIMD)
     int num_cus = 256;
-    int team_max_batch = -1;  // MPCGPU_OPT_TEAM_BATCH: largest batch solved by the latency kernel (-1: 3 x number of CUs)
+    int team_max_batch = -1;  // MPCGPU_OPT_TEAM_BATCH: largest batch solved by the latency kernel (-1: 4 x number of CUs)
     int last_team = 0;        // 1: the last solve ran the latency kernel (one problem per workgroup of four wavefronts)
     int pairing = -1;   // MPCGPU_OPT_PAIRING: -1 automatic, 0 one problem per wavefront, 1 two per wavefront (N_hor = 20)
     int last_pairing = 0;  // layout of the last solve / cost_grad launch
@@ -350,7 +350,7 @@ int32_t mpcgpu_solve_batch_dev(void* handle, int32_t B, const double* p, const d
     BatchPtrs io{};
     // Small batches take the latency kernel: one problem per workgroup of four wavefronts, compaction fused, carve from the
     // configured maxima -- one launch, nothing read back.  Results are bitwise those of the throughput kernel.
-    const int team_cap = h->team_max_batch >= 0 ? h->team_max_batch : 3 * h->num_cus;  // measured break-even: ~1000 problems (tools/team_sweep.py)
+    const int team_cap = h->team_max_batch >= 0 ? h->team_max_batch : 4 * h->num_cus;  // measured break-even: 1000-1500 problems (tools/team_sweep.py)
     h->last_team = 0;
 #ifndef MPC_TRACE
     if (B <= team_cap && !h->reserved && !use_duo(h)) {
