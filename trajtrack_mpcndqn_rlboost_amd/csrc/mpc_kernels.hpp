@@ -339,7 +339,7 @@ __constant__ double KTAB[27] = {
     -2.75573143513906633035e-07, 2.08757232129817482790e-09, -1.13596475577881948265e-11,
     1.0 / 6.0,                 // 12
     1.0 + 1e-9,                // 13: safety factor of the pruning radii
-    1.0 + 1e-12,               // 14: safety factor of sqrt(best)
+    1.0 + 1e-6,                // 14: safety factor of the estimated sqrt(best) (sqrt_upper)
     0.78,                      // 15: |half-step heading increment| up to which the polynomials are used
     1.0 / (1e-6 * 1e-6),       // 16: inverse squared semi-axis of a zero-padded dynamic row: 1/((0+1e-6)^2)
     0.95,                      // 17: gamma = 0.95 / L                               [OpEn PANOC constants from here]
@@ -354,6 +354,12 @@ __constant__ double KTAB[27] = {
     (1.0 - 0.95) / 4.0};       // 26: sigma = (1 - 0.95) / (4 gamma); the division by 4 is exact
 enum { K_SIXTH = 12, K_REACH = 13, K_SQRT = 14, K_SMALL = 15, K_IPAD = 16, K_GAMMA_L = 17, K_DELTA_LIP = 18, K_EPS_LIP = 19,
        K_MAX_LIP = 20, K_MIN_L = 21, K_EPS = 22, K_DBLMIN = 23, K_CBFGS = 24, K_YBOUND = 25, K_SIGMA = 26 };
+
+// Upper bound of sqrt(x) for the pruning radii: the hardware estimate (v_rsq_f64, ~2^-24 relative) inflated by 1e-6 instead of
+// the ~20-instruction correctly rounded square root.  Pruning only needs a radius that is not too SMALL; results do not change.
+__device__ __forceinline__ double sqrt_upper(double x, double inflate) {
+    return x > 0.0 ? x * __builtin_amdgcn_rsq(x) * inflate : 0.0;
+}
 
 // sin / cos on [-pi/4, pi/4] (fdlibm kernel polynomials, error < 1 ulp there)
 __device__ __forceinline__ void sincos_small(double x, const double* k, double& s, double& c) {
@@ -697,7 +703,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         //     circles recede along the path, so a lane leaves after the few segments that are actually near its position.
         bool more = false;
         if (i < N) {
-            sb = sqrt(best) * KC(K_SQRT);
+            sb = sqrt_upper(best, KC(K_SQRT));
             const double* sg = cx.seg + SEGW * i;
             const double bx = px - sg[5], by = py - sg[6], reach = (sb + sg[7]) * KC(K_REACH);
             more = bx * bx + by * by < reach * reach;
@@ -714,7 +720,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
                 const double d2 = wx * wx + wy * wy;
                 if (d2 < best) {
                     best = d2;
-                    sb = sqrt(d2) * KC(K_SQRT);
+                    sb = sqrt_upper(d2, KC(K_SQRT));
                     const double wd = (th >= 0.0 && th <= 1.0) ? (wx * dx + wy * dy) * inv : 0.0;
                     bgx = 2.0 * (wd * dx - wx);
                     bgy = 2.0 * (wd * dy - wy);
@@ -997,12 +1003,17 @@ __device__ __forceinline__ void panoc_lip_perturbation(const Ctx& cx, bool vl, d
     h1 = vl ? ((KC(K_EPS_LIP) * uw > KC(K_DELTA_LIP)) ? KC(K_EPS_LIP) * uw : KC(K_DELTA_LIP)) : 0.0;
     nh = P::uni(sqrt(dot2r<P, P::RV>(h0, h1, h0, h1)));
 }
-// L = ||grad(u + h) - grad(u)|| / ||h||, gamma = 0.95 / L, sigma = 0.05 / (4 gamma)
+// L = ||grad(u + h) - grad(u)|| / ||h||, gamma = 0.95 / L, sigma = 0.05 / (4 gamma).
+// `ig` = 1 / gamma is carried next to gamma: the step used gamma in the denominator six times (envelope of every trial point and of the iterate,
+// sigma, Lipschitz test) and a double-precision division is ~30 VALU instructions on the critical path of a decision; gamma
+// itself changes only when the Lipschitz estimate does (halving gamma doubles ig exactly).
 template <class P>
-__device__ __forceinline__ void panoc_lip_estimate(const Ctx& cx, double d0, double d1, double nh, double& Lip, double& gamma, double& sigma) {
+__device__ __forceinline__ void panoc_lip_estimate(const Ctx& cx, double d0, double d1, double nh, double& Lip, double& gamma, double& ig,
+                                                   double& sigma) {
     Lip = P::uni(sqrt(dot2r<P, P::RV>(d0, d1, d0, d1)) / nh);
     gamma = P::uni(KC(K_GAMMA_L) / fmax(Lip, KC(K_MIN_L)));
-    sigma = P::uni(KC(K_SIGMA) / gamma);
+    ig = P::uni(1.0 / gamma);
+    sigma = P::uni(KC(K_SIGMA) * ig);
 }
 // u_half <- Proj_U(base - gamma * grad); returns this lane's share of ||gradient_step - u_half||^2
 __device__ __forceinline__ double panoc_half_step(const KParams& kp, bool vl, double bv, double bw, double gamma, double g0, double g1,
@@ -1021,24 +1032,24 @@ __device__ __forceinline__ void panoc_envelope_sums(const KParams& kp, bool vl, 
     const double e2 = panoc_half_step(kp, vl, bv, bw, gamma, g0, g1, hv, hw);
     P::sum2(__builtin_fma(g0, g0, g1 * g1), e2, gg, d2h);
 }
-__device__ __forceinline__ double panoc_fbe(double cost, double gamma, double gg, double d2h) {
-    return cost - 0.5 * gamma * gg + 0.5 * d2h / gamma;
+__device__ __forceinline__ double panoc_fbe(double cost, double gamma, double ig, double gg, double d2h) {
+    return cost - 0.5 * gamma * gg + 0.5 * d2h * ig;
 }
-__device__ __forceinline__ double panoc_fbe_rhs(double cost, double gamma, double gg, double d2h, double sigma, double nfpr) {
-    return panoc_fbe(cost, gamma, gg, d2h) - sigma * nfpr * nfpr;
+__device__ __forceinline__ double panoc_fbe_rhs(double cost, double gamma, double ig, double gg, double d2h, double sigma, double nfpr) {
+    return panoc_fbe(cost, gamma, ig, gg, d2h) - sigma * nfpr * nfpr;
 }
 __device__ __forceinline__ double panoc_trial(double u, double r, double d, double tau) { return u - (1.0 - tau) * r - tau * d; }
 // Lipschitz test: psi(u_half) > psi(u) + eps |psi(u)| - <grad, gamma fpr> + (0.95 / (2 gamma)) ||gamma fpr||^2
-__device__ __forceinline__ bool panoc_lip_test_fails(const Ctx& cx, double cost_half, double cost, double ip, double gamma, double nfpr) {
-    const double rhs_lip = cost + KC(K_EPS_LIP) * fabs(cost) - ip + (KC(K_GAMMA_L) / (2.0 * gamma)) * nfpr * nfpr;
+__device__ __forceinline__ bool panoc_lip_test_fails(const Ctx& cx, double cost_half, double cost, double ip, double ig, double nfpr) {
+    const double rhs_lip = cost + KC(K_EPS_LIP) * fabs(cost) - ip + (KC(K_GAMMA_L) * 0.5 * ig) * nfpr * nfpr;
     return cost_half > rhs_lip;
 }
 // L <- 2L, gamma <- gamma / 2, new half step, fpr and the sums that belong to it
 template <class P>
 __device__ __forceinline__ void panoc_lip_update(const KParams& kp, bool vl, double uv, double uw, double gv, double gw, double& Lip,
-                                                 double& gamma, double& hv, double& hw, double& rv, double& rw, double& d2h,
+                                                 double& gamma, double& ig, double& hv, double& hw, double& rv, double& rw, double& d2h,
                                                  double& nfpr, double& ip) {
-    Lip = P::uni(Lip * 2.0); gamma = P::uni(gamma * 0.5);
+    Lip = P::uni(Lip * 2.0); gamma = P::uni(gamma * 0.5); ig = P::uni(ig * 2.0);
     const double e2 = panoc_half_step(kp, vl, uv, uw, gamma, gv, gw, hv, hw);
     rv = uv - hv; rw = uw - hw;
     double rr;
@@ -1087,7 +1098,7 @@ struct PanocLbfgs {
         }
         double ys, ss;
         P::sum2(__builtin_fma(s0, y0_, s1 * y1_), __builtin_fma(s0, s0, s1 * s1), ys, ss);
-        if (!(ss <= KC(K_DBLMIN) || ys <= KC(K_MIN_L)) && (ys / ss > KC(K_CBFGS) * nfpr)) {
+        if (!(ss <= KC(K_DBLMIN) || ys <= KC(K_MIN_L)) && (ys > (KC(K_CBFGS) * nfpr) * ss)) {  // s'y / ||s||^2 > eps ||gamma fpr||, ||s||^2 > 0
             head = (head + mem - 1) % mem;
             if (vl) {
                 LOLD[lane * 4] = uv; LOLD[lane * 4 + 1] = uw; LOLD[lane * 4 + 2] = rv; LOLD[lane * 4 + 3] = rw;
@@ -1238,7 +1249,7 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
     // PANOC cache: vector state u, grad, u_half, gamma*fpr, direction (2 doubles per vector lane each);
     // ||grad||^2 and ||gradient_step - u_half||^2 are carried as scalars (they only enter the envelope)
     double gv = 0, gw = 0, hv = 0, hw = 0, rv_ = 0, rw_ = 0, dv = 0, dw = 0;
-    double gamma = 0, Lip = 0, sigma = 0, cost = 0, nfpr = 0, tau = 1, rhs = 0, nh = 1, gg = 0, d2h = 0;
+    double gamma = 0, ig = 0, Lip = 0, sigma = 0, cost = 0, nfpr = 0, tau = 1, rhs = 0, nh = 1, gg = 0, d2h = 0;
     double ip = 0.0;  // <grad, gamma*fpr> of the current step (Lipschitz test)
     double akkt_tol = kp.init_tol;
     int iter = 0, num_iter = 0, lip_it = 0, nls = 0;
@@ -1284,19 +1295,19 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
             ev = uv + h0; ew = uw + h1; want_grad = true; state = ST_INIT1;
             continue;
         } else if (state == ST_INIT1) {
-            panoc_lip_estimate<P>(cx, o.gv - gv, o.gw - gw, nh, Lip, gamma, sigma);
+            panoc_lip_estimate<P>(cx, o.gv - gv, o.gw - gw, nh, Lip, gamma, ig, sigma);
             panoc_envelope_sums<P>(kp, vl, uv, uw, gamma, gv, gw, hv, hw, gg, d2h);
             step_begin = true;
         } else if (state == ST_LIP) {
             const double cost_half = o.psi;
-            if (panoc_lip_test_fails(cx, cost_half, cost, ip, gamma, nfpr) && lip_it < MAX_LIP_IT && Lip < KC(K_MAX_LIP)) {
+            if (panoc_lip_test_fails(cx, cost_half, cost, ip, ig, nfpr) && lip_it < MAX_LIP_IT && Lip < KC(K_MAX_LIP)) {
                 lb.flush();  // invalidate the L-BFGS buffer
-                panoc_lip_update<P>(kp, vl, uv, uw, gv, gw, Lip, gamma, hv, hw, rv_, rw_, d2h, nfpr, ip);
+                panoc_lip_update<P>(kp, vl, uv, uw, gv, gw, Lip, gamma, ig, hv, hw, rv_, rw_, d2h, nfpr, ip);
                 ++lip_it;
                 ev = hv; ew = hw; want_grad = false;
                 continue;
             }
-            sigma = P::uni(KC(K_SIGMA) / gamma);
+            sigma = P::uni(KC(K_SIGMA) * ig);
 #ifdef MPC_TRACE
             tr_psi_u = cost;
 #endif
@@ -1311,7 +1322,7 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
             }
             lb.template direction<P, LBG>(vl, lane, N, mem, rv_, rw_, LS, LY, LRHO, LALPHA, dv, dw);
             // ---- line search on the forward-backward envelope
-            rhs = P::uni(panoc_fbe_rhs(cost, gamma, gg, d2h, sigma, nfpr));
+            rhs = P::uni(panoc_fbe_rhs(cost, gamma, ig, gg, d2h, sigma, nfpr));
             tau = 1.0; nls = 0;
             ev = panoc_trial(uv, rv_, dv, tau); ew = panoc_trial(uw, rw_, dw, tau);  // u_plus
             want_grad = true; state = ST_LS;
@@ -1328,7 +1339,7 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
             // (ev, ew) is the trial point u_plus
             cost = P::uni(o.psi); gv = o.gv; gw = o.gw;
             panoc_envelope_sums<P>(kp, vl, ev, ew, gamma, gv, gw, hv, hw, gg, d2h);
-            const double lhs = panoc_fbe(cost, gamma, gg, d2h);
+            const double lhs = panoc_fbe(cost, gamma, ig, gg, d2h);
             if (lhs > rhs && nls < MAX_LS_IT) {
                 tau = P::uni(tau * 0.5); ++nls;
                 ev = panoc_trial(uv, rv_, dv, tau); ew = panoc_trial(uw, rw_, dw, tau);
@@ -1381,7 +1392,7 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
             dy_norm = dy_norm_plus; f2_norm = f2_norm_plus;
             ya = clampd(ypa, -KC(K_YBOUND), KC(K_YBOUND)); yb = clampd(ypb, -KC(K_YBOUND), KC(K_YBOUND));  // y <- Proj_Y(y+)
             // reset the PANOC cache for the next inner problem
-            lb.flush(); tau = 1.0; Lip = 0; sigma = 0; gamma = 0; iter = 0;
+            lb.flush(); tau = 1.0; Lip = 0; sigma = 0; gamma = 0; ig = 0; iter = 0;
             num_iter = 0; cont_iters = true; cont_time = true;
             ev = uv; ew = uw; want_grad = true; state = ST_INIT0;
             continue;

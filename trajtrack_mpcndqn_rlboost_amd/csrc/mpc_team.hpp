@@ -87,7 +87,7 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
     double icm = uniform(1.0 / fmax(c, 1.0));
     ya = clampd(ya, -KC(K_YBOUND), KC(K_YBOUND)); yb = clampd(yb, -KC(K_YBOUND), KC(K_YBOUND));
     double gv = 0, gw = 0, hv = 0, hw = 0, rv_ = 0, rw_ = 0, dv = 0, dw = 0;
-    double gamma = 0, Lip = 0, sigma = 0, cost = 0, nfpr = 0, rhs = 0, nh = 1, gg = 0, d2h = 0, ip = 0;
+    double gamma = 0, ig = 0, Lip = 0, sigma = 0, cost = 0, nfpr = 0, rhs = 0, nh = 1, gg = 0, d2h = 0, ip = 0;
     double akkt_tol = kp.init_tol;
     int iter = 0, num_iter = 0, lip_it = 0, nls = 0, t0 = 0;
     bool cont_iters = true, cont_time = true;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
             continue;
         } else if (state == TS_INIT1) {
             ++n_eval; ++n_eval_grad;
-            panoc_lip_estimate<P>(cx, o.gv - gv, o.gw - gw, nh, Lip, gamma, sigma);
+            panoc_lip_estimate<P>(cx, o.gv - gv, o.gw - gw, nh, Lip, gamma, ig, sigma);
             panoc_envelope_sums<P>(kp, vl, uv, uw, gamma, gv, gw, hv, hw, gg, d2h);
             step_begin = true;
         } else if (state == TS_FIRST || state == TS_LIPSEQ) {
@@ -161,14 +161,14 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
             // WITH the gradient, because once the Lipschitz test passes this very point becomes the iterate.
             ++n_eval;
             const double cost_half = o.psi;
-            if (panoc_lip_test_fails(cx, cost_half, cost, ip, gamma, nfpr) && lip_it < MAX_LIP_IT && Lip < KC(K_MAX_LIP)) {
+            if (panoc_lip_test_fails(cx, cost_half, cost, ip, ig, nfpr) && lip_it < MAX_LIP_IT && Lip < KC(K_MAX_LIP)) {
                 lb.flush();
-                panoc_lip_update<P>(kp, vl, uv, uw, gv, gw, Lip, gamma, hv, hw, rv_, rw_, d2h, nfpr, ip);
+                panoc_lip_update<P>(kp, vl, uv, uw, gv, gw, Lip, gamma, ig, hv, hw, rv_, rw_, d2h, nfpr, ip);
                 ++lip_it;
                 ev = hv; ew = hw;  // want_grad stays as it is
                 continue;
             }
-            sigma = uniform(KC(K_SIGMA) / gamma);
+            sigma = uniform(KC(K_SIGMA) * ig);
             lb.template update<P>(cx, vl, lane, N, mem, uv, uw, rv_, rw_, nfpr, LS, LY, LOLD, LRHO);
             wave_sync();
             if (state == TS_FIRST) {
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
                 step_begin = true;
             } else {
                 lb.template direction<P, false>(vl, lane, N, mem, rv_, rw_, LS, LY, LRHO, LALPHA, dv, dw);
-                rhs = panoc_fbe_rhs(cost, gamma, gg, d2h, sigma, nfpr);
+                rhs = panoc_fbe_rhs(cost, gamma, ig, gg, d2h, sigma, nfpr);
                 t0 = 0;
                 trial_point(exp2(-(double)(t0 + wid)));
                 want_grad = true; state = TS_BATCH;
@@ -191,10 +191,10 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
             // wavefront 0: psi at the half step (Lipschitz test); wavefronts 1..3: trials tau = 1, 1/2, 1/4
             double thv = 0.0, thw = 0.0, tgg = 0.0, td2h = 0.0, flag;
             if (wid == 0) {
-                flag = (panoc_lip_test_fails(cx, o.psi, cost, ip, gamma, nfpr) && lip_it < MAX_LIP_IT && Lip < KC(K_MAX_LIP)) ? 1.0 : 0.0;
+                flag = (panoc_lip_test_fails(cx, o.psi, cost, ip, ig, nfpr) && lip_it < MAX_LIP_IT && Lip < KC(K_MAX_LIP)) ? 1.0 : 0.0;
             } else {
                 panoc_envelope_sums<P>(kp, vl, ev, ew, gamma, o.gv, o.gw, thv, thw, tgg, td2h);
-                flag = panoc_fbe(uniform(o.psi), gamma, tgg, td2h) > rhs ? 0.0 : 1.0;  // 1 = accepted
+                flag = panoc_fbe(uniform(o.psi), gamma, ig, tgg, td2h) > rhs ? 0.0 : 1.0;  // 1 = accepted
             }
             double all[TEAM_WAVES];
             publish(flag, all);
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
             if (all[0] != 0.0) {
                 // Lipschitz test failed: the speculative pair and direction are void (the buffer is flushed)
                 lb.flush();
-                panoc_lip_update<P>(kp, vl, uv, uw, gv, gw, Lip, gamma, hv, hw, rv_, rw_, d2h, nfpr, ip);
+                panoc_lip_update<P>(kp, vl, uv, uw, gv, gw, Lip, gamma, ig, hv, hw, rv_, rw_, d2h, nfpr, ip);
                 ++lip_it;
                 ev = hv; ew = hw; want_grad = false; state = TS_LIPSEQ;
                 continue;
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
             double thv, thw, tgg, td2h;
             panoc_envelope_sums<P>(kp, vl, ev, ew, gamma, o.gv, o.gw, thv, thw, tgg, td2h);
             const int t = t0 + wid;
-            const bool accepted = !(panoc_fbe(uniform(o.psi), gamma, tgg, td2h) > rhs);
+            const bool accepted = !(panoc_fbe(uniform(o.psi), gamma, ig, tgg, td2h) > rhs);
             const double flag = t > MAX_LS_IT ? 0.0 : (accepted ? 1.0 : (t == MAX_LS_IT ? 2.0 : 0.0));  // 2 = last trial, rejected
             double all[TEAM_WAVES];
             publish(flag, all);
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
             ++alm_iteration; ++num_outer;
             dy_norm = dy_norm_plus; f2_norm = f2_norm_plus;
             ya = clampd(ypa, -KC(K_YBOUND), KC(K_YBOUND)); yb = clampd(ypb, -KC(K_YBOUND), KC(K_YBOUND));
-            lb.flush(); Lip = 0; sigma = 0; gamma = 0; iter = 0;
+            lb.flush(); Lip = 0; sigma = 0; gamma = 0; ig = 0; iter = 0;
             num_iter = 0; cont_iters = true; cont_time = true;
             ev = uv; ew = uw; want_grad = true; state = TS_INIT0;
             continue;
@@ -314,11 +314,11 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
                         ev = hv; ew = hw; want_grad = true; state = TS_FIRST;
                     } else {
                         // speculation: pair update and direction before the Lipschitz test is known
-                        sigma = uniform(KC(K_SIGMA) / gamma);
+                        sigma = uniform(KC(K_SIGMA) * ig);
                         lb.template update<P>(cx, vl, lane, N, mem, uv, uw, rv_, rw_, nfpr, LS, LY, LOLD, LRHO);
                         wave_sync();
                         lb.template direction<P, false>(vl, lane, N, mem, rv_, rw_, LS, LY, LRHO, LALPHA, dv, dw);
-                        rhs = panoc_fbe_rhs(cost, gamma, gg, d2h, sigma, nfpr);
+                        rhs = panoc_fbe_rhs(cost, gamma, ig, gg, d2h, sigma, nfpr);
                         if (wid == 0) { ev = hv; ew = hw; want_grad = false; }
                         else { trial_point(exp2(-(double)(wid - 1))); want_grad = true; }
                         state = TS_SPEC;
