@@ -1117,31 +1117,58 @@ struct PanocLbfgs {
                                               const double* LRHO, double* LALPHA, double& dv, double& dw) const {
         double q0 = rv, q1 = rw;
         if (LBG) {
-            auto pair_at = [&](const double* base, int sl) -> double2 {
+            // The ring lives in the workspace record (L2, ~700 cycles away).  THREE pairs are kept in flight: pair p travels in
+            // register set p % 3; a set is refilled (pair p + 3 on the way down the buffer, p - 3 on the way back) as soon as
+            // its pair has been consumed, i.e. two recursion steps before it is needed again.  The second loop starts with the
+            // three oldest pairs still in registers.  Same operations in the same order as the plain loops below.
+            auto pair_at = [&](const double* base, int p) -> double2 {
+                int sl = head + p;
+                sl = sl >= mem ? sl - mem : sl;
                 return vl ? *reinterpret_cast<const double2*>(base + (sl * N + lane) * 2) : make_double2(0.0, 0.0);
             };
-            double2 sc = make_double2(0.0, 0.0), yc = sc;
-            if (active > 0) { sc = pair_at(LS, head); yc = pair_at(LY, head); }
-            for (int j = 0; j < active; ++j) {
-                const int sl = (head + j) % mem;
-                double2 sn = sc, yn = yc;
-                if (j + 1 < active) { const int nx = (head + j + 1) % mem; sn = pair_at(LS, nx); yn = pair_at(LY, nx); }
-                const double al = LRHO[sl] * dot2r<P, P::RV>(sc.x, sc.y, q0, q1);
-                if (lane == 0) LALPHA[j] = al;
-                q0 -= al * yc.x; q1 -= al * yc.y;
-                sc = sn; yc = yn;  // after the last step (sc, yc) still hold pair active-1
+            auto rho_at = [&](int p) -> double {
+                int sl = head + p;
+                sl = sl >= mem ? sl - mem : sl;
+                return LRHO[sl];
+            };
+            const double2 z2 = make_double2(0.0, 0.0);
+            double2 sA = z2, yA = z2, sB = z2, yB = z2, sC = z2, yC = z2;
+            if (active > 0) { sA = pair_at(LS, 0); yA = pair_at(LY, 0); }
+            if (active > 1) { sB = pair_at(LS, 1); yB = pair_at(LY, 1); }
+            if (active > 2) { sC = pair_at(LS, 2); yC = pair_at(LY, 2); }
+#define MPC_LB_DOWN(S_, Y_)                                                                          \
+    {                                                                                                \
+        const double al = rho_at(j) * dot2r<P, P::RV>(S_.x, S_.y, q0, q1);                           \
+        if (lane == 0) LALPHA[j] = al;                                                               \
+        q0 -= al * Y_.x; q1 -= al * Y_.y;                                                            \
+        if (j + 3 < active) { S_ = pair_at(LS, j + 3); Y_ = pair_at(LY, j + 3); }                    \
+        ++j;                                                                                         \
+    }
+            int j = 0;
+            while (j < active) {
+                MPC_LB_DOWN(sA, yA)
+                if (j < active) MPC_LB_DOWN(sB, yB)
+                if (j < active) MPC_LB_DOWN(sC, yC)
             }
+#undef MPC_LB_DOWN
             wave_sync();
             if (active > 0) { q0 *= hgamma; q1 *= hgamma; }
-            for (int j = active - 1; j >= 0; --j) {
-                const int sl = (head + j) % mem;
-                double2 sp = sc, yp = yc;
-                if (j > 0) { const int pv = (head + j - 1) % mem; sp = pair_at(LS, pv); yp = pair_at(LY, pv); }
-                const double be = LRHO[sl] * dot2r<P, P::RV>(yc.x, yc.y, q0, q1);
-                const double co = LALPHA[j] - be;
-                q0 += co * sc.x; q1 += co * sc.y;
-                sc = sp; yc = yp;
+#define MPC_LB_UP(S_, Y_)                                                                            \
+    {                                                                                                \
+        const double be = rho_at(j) * dot2r<P, P::RV>(Y_.x, Y_.y, q0, q1);                           \
+        const double co = LALPHA[j] - be;                                                            \
+        q0 += co * S_.x; q1 += co * S_.y;                                                            \
+        if (j >= 3) { S_ = pair_at(LS, j - 3); Y_ = pair_at(LY, j - 3); }                            \
+        --j;                                                                                         \
+    }
+            j = active - 1;
+            int ph = j >= 0 ? j % 3 : 0;  // register set of the oldest pair
+            while (j >= 0) {
+                if (ph == 2) { MPC_LB_UP(sC, yC) ph = 1; if (j < 0) break; }
+                if (ph == 1) { MPC_LB_UP(sB, yB) ph = 0; if (j < 0) break; }
+                MPC_LB_UP(sA, yA) ph = 2;
             }
+#undef MPC_LB_UP
         } else {
             for (int j = 0; j < active; ++j) {
                 const int sl = (head + j) % mem;
