@@ -5,11 +5,11 @@
 
 A step = one pass of the hot path over one batch: B independent cold-start solves (u0 = 0, what every
 reference call site does: src/interface_mpc.py:82 passes initial_guess=None) of the metric configuration
-named in BASELINE.json -- mpc_default.yaml, N_hor = 20, 8 dynamic obstacles -- on B = 65536 robots per GPU,
+named in BASELINE.json -- mpc_default.yaml, N_hor = 20, 8 dynamic obstacles -- on B = 131072 robots per GPU,
 with the parameter vectors already resident in HBM.  (A solve takes 0.1-0.2 s of device time and 4096 run
 concurrently; the last problems of a launch finish on a draining GPU, which costs about 0.12 s per launch whatever
-the batch: measured 23.8 / 25.7 / 27.1 / 27.7 thousand solves/s at B = 16384 / 32768 / 65536 / 131072
-(profiles/r02_batch_scaling.txt; round 1 and the first half of round 2 benchmarked B = 32768).  `--batch` selects
+the batch: measured 24.3 / 27.2 / 28.3 / 29.1 thousand solves/s at B = 16384 / 32768 / 65536 / 131072
+(profiles/r02_batch_scaling.txt; round 1 benchmarked B = 32768: 25.2 thousand then, 27.2 thousand now).  `--batch` selects
 other sizes.)
 
 Multi-GPU (N > 1): one process per GPU; the batch shards across ranks with no data-path collective (weak
@@ -65,7 +65,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=65536, help="problems per GPU per step")
+    ap.add_argument("--batch", type=int, default=131072, help="problems per GPU per step")
     ap.add_argument("--n-dyn", type=int, default=8)
     ap.add_argument("--horizon", type=int, default=20)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 disables)")

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects, on the GPU box, the raw rocprofv3 outputs behind bench.py's roofline object -- every pass on the SAME
-# workload (bench.py defaults: N_hor = 20, 8 dynamic obstacles, B = 65536), one rocprofv3 run per pass (kernel trace and
+# workload (bench.py defaults: N_hor = 20, 8 dynamic obstacles, B = 131072), one rocprofv3 run per pass (kernel trace and
 # counters are never combined; FETCH_SIZE and WRITE_SIZE need a pass each).  Copy the directory to profiles/raw_r02/ and
 # run `python tools/roofline.py rebuild`.
 #   usage: tools/collect_profiles.sh [outdir = gpurun_out/raw_r02] [extra bench.py arguments]

@@ -629,19 +629,22 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     double c0, s0, cm, sm, c2, s2;
     {
         const double hd = 0.5 * ts * w;  // half-step heading increment
-        const bool small = !P::any(fabs(hd) > KC(K_SMALL));
-        if (small) {
+        // The polynomial path runs unconditionally; the test whether it was admissible (it is, unless a trial point lies far
+        // outside the input box) is evaluated next to it instead of in front of it, so that no LDS read + ballot + branch sits
+        // at the head of every evaluation's dependency chain.
+        {
             double sh, ch;
             sincos_small(hd, cx.hd + KC_BASE, sh, ch);
             double er = ch * ch - sh * sh, ei = 2.0 * sh * ch;  // e^{i ts w_k}
-            P::template cprod<RV>(er, ei);                               // prod_{j<=k} e^{i ts w_j}
+            P::template cprod<RV>(er, ei);                          // prod_{j<=k} e^{i ts w_j}
             c2 = HD(H_CTH0) * er - HD(H_STH0) * ei;                      // heading k+1
             s2 = HD(H_CTH0) * ei + HD(H_STH0) * er;
             c0 = shift_up1(c2, lane, HD(H_CTH0));
             s0 = shift_up1(s2, lane, HD(H_STH0));
             cm = c0 * ch - s0 * sh;
             sm = c0 * sh + s0 * ch;
-        } else {  // a trial point far outside the input box: plain sincos of the summed angles
+        }
+        if (P::any(fabs(hd) > KC(K_SMALL))) {  // rare: plain sincos of the summed angles
             const double tw = ts * w;
             const double th1 = HD(H_TH0) + P::template prefix<RV>(tw);
             sincos(th1 - 0.5 * tw, &sm, &cm);
