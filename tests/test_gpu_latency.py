@@ -91,3 +91,29 @@ def test_latency_kernel_for_other_horizons(N, caps):
         assert fast.last_shape()["latency_kernel"] and not seq.last_shape()["latency_kernel"]
         _same(a, b)
     fast.close(); seq.close()
+
+
+@pytest.mark.parametrize("kernel", ["latency", "throughput", "two-per-wavefront"])
+def test_wall_clock_limit_ends_the_solve_with_its_own_status(kernel):
+    """`with_max_duration_micros` (mpc_generator.py:22,287; OpEn: NotConvergedOutOfTime).  The in-kernel limit reads the
+    100 MHz wall clock; in the latency kernel wavefront 0 decides for the whole workgroup (the replicas must never disagree,
+    or the workgroup would hang at a barrier)."""
+    cfg = make_cfg(20, solver_max_duration_micros=3000)          # 3 ms: far below what a cap-limited solve needs
+    B = 24
+    hard = scenes.make_batch(cfg, B, n_dyn=8, seed=11)["p"]
+    kw = dict(latency_batch=0) if kernel == "throughput" else (dict(pairing=2) if kernel == "two-per-wavefront" else {})
+    bs = BatchSolver(cfg, **kw)
+    res = bs.solve(hard)
+    assert bs.last_shape()["latency_kernel"] == (kernel == "latency")
+    assert np.all(res.status == 2), np.bincount(res.status, minlength=5)
+    assert bs.last_timing()["solve_ms"] < 50.0                   # it did stop (a full solve of these takes 40-140 ms)
+    assert np.all(np.isfinite(res.solution)) and np.all(np.isfinite(res.cost))
+    u = res.solution.reshape(B, 20, 2)
+    assert u[..., 0].min() >= cfg.lin_vel_min - 1e-12 and u[..., 0].max() <= cfg.lin_vel_max + 1e-12   # the feasible half step
+    assert np.abs(u[..., 1]).max() <= cfg.ang_vel_max + 1e-12
+    assert np.all(res.solve_time_ms < 50.0) and np.all(res.solve_time_ms > 1.0)
+    bs.close()
+    # no limit: the same problems run to their iteration caps
+    free = BatchSolver(make_cfg(20, solver_max_duration_micros=0, solver_max_inner_iterations=30, solver_max_outer_iterations=2), **kw)
+    assert np.all(free.solve(hard).status == 1)
+    free.close()
