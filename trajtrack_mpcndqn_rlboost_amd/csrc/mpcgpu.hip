@@ -188,7 +188,7 @@ void fill_lds_layout(KParams& k, int mKs, int mKf, int mKd, bool shape_const, bo
 // LDS carve of the latency kernel (mpc_team.hpp): tables for the CONFIGURED maxima (general dynamic-obstacle records), shared
 // by the four wavefronts of the workgroup; then the exchange area; then one work block per wavefront (positions, stash, hinge
 // matrix / item partials, L-BFGS memory).  Offsets of the work-block fields are those of wavefront 0.
-void fill_team_layout(KParams& k, const mpcgpu_config& c) {
+[[maybe_unused]] void fill_team_layout(KParams& k, const mpcgpu_config& c) {  // unused in -DMPC_TRACE builds
     const int N = k.N;
     k.mKs = c.Nstcobs; k.mKf = c.Nother; k.mKd = c.Ndynobs;
     int o = 0;
