@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""GPU-vs-oracle parity summary on seeded scenes (run on the GPU box; output is committed under profiles/)."""
+"""TEST INFRASTRUCTURE (it uses the CPU oracle, hence it lives under tests/): GPU-vs-oracle parity summary on seeded scenes
+(run on the GPU box: python tests/tools/parity_report.py; the output is committed under profiles/)."""
 import os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from trajtrack_mpcndqn_rlboost_amd import MpcConfig, BatchSolver, scenes
 import oracle

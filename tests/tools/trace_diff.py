@@ -3,7 +3,7 @@
 usage: trace_diff.py libA.so libB.so [N] [B]"""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from trajtrack_mpcndqn_rlboost_amd import MpcConfig, BatchSolver, scenes
 import oracle
