@@ -180,7 +180,7 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
                 ++iter;
                 step_begin = true;
             } else {
-                lb.template direction<P, false>(vl, lane, N, mem, rv_, rw_, LS, LY, LRHO, LALPHA, dv, dw);
+                lb.template direction<P, true>(vl, lane, N, mem, rv_, rw_, LS, LY, LRHO, LALPHA, dv, dw);
                 rhs = panoc_fbe_rhs(cost, gamma, ig, gg, d2h, sigma, nfpr);
                 t0 = 0;
                 trial_point(exp2(-(double)(t0 + wid)));
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
                         sigma = uniform(KC(K_SIGMA) * ig);
                         lb.template update<P>(cx, vl, lane, N, mem, uv, uw, rv_, rw_, nfpr, LS, LY, LOLD, LRHO);
                         wave_sync();
-                        lb.template direction<P, false>(vl, lane, N, mem, rv_, rw_, LS, LY, LRHO, LALPHA, dv, dw);
+                        lb.template direction<P, true>(vl, lane, N, mem, rv_, rw_, LS, LY, LRHO, LALPHA, dv, dw);
                         rhs = panoc_fbe_rhs(cost, gamma, ig, gg, d2h, sigma, nfpr);
                         if (wid == 0) { ev = hv; ew = hw; want_grad = false; }
                         else { trial_point(exp2(-(double)(wid - 1))); want_grad = true; }
