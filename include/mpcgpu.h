@@ -124,11 +124,14 @@ int32_t mpcgpu_last_timing(void* handle, double* prep_ms, double* solve_ms);
 
 /* Work counters of the last solve call, per problem: psi evaluations executed and how many of them also produced
  * grad psi (the counts OpEn's generated `cost` / `grad_cost` functions would see, minus the redundant re-evaluation of
- * psi(u) in the Lipschitz update).  Synchronises `stream` (the one the solve was enqueued on).  HOST output pointers. */
+ * psi(u) in the Lipschitz update; the latency kernel reports the counts of the SEQUENTIAL algorithm, not its speculative
+ * evaluations).  Synchronises `stream` (the one the solve was enqueued on).  HOST output pointers. */
 int32_t mpcgpu_last_eval_counts(void* handle, int32_t B, int32_t* n_psi, int32_t* n_grad, void* stream);
 
 /* Batch-wide maxima of active entries seen by the last solve / cost_grad call: static obstacles, fleet
- * entries, dynamic-obstacle entries (sizes the LDS carve), and the LDS bytes per wavefront used. */
+ * entries, dynamic-obstacle entries (sizes the LDS carve), and the LDS bytes per wavefront used.  After a call that ran the
+ * latency kernel (mpcgpu_last_latency_kernel) or under mpcgpu_reserve_shape nothing was read back: the values are the bounds
+ * the carve was sized for (configured maxima / reserved shape) and the LDS bytes of the whole workgroup. */
 int32_t mpcgpu_last_shape(void* handle, int32_t* max_static, int32_t* max_fleet, int32_t* max_dyn,
                           int32_t* lds_bytes);
 
