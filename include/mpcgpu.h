@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MPCGPU_ABI_VERSION 2
+#define MPCGPU_ABI_VERSION 3
 
 /* replaces: the yaml config consumed by MpcModule.build (mpc_generator.py:151-158, config/mpc_default.yaml:7-55)
  * plus the SolverConfiguration of mpc_generator.py:285-293 (opengen defaults quoted there). */

@@ -22,7 +22,7 @@ _LIB = os.environ.get("MPCGPU_LIB", os.path.join(_PKG, "libmpcgpu.so"))  # overr
 
 STATUS_NAMES = ("Converged", "NotConvergedIterations", "NotConvergedOutOfTime", "NotFiniteComputation",
                 "ShapeExceeded")
-ABI_VERSION = 2
+ABI_VERSION = 3
 _STREAM_OWN = C.c_void_p(-1)      # MPCGPU_STREAM_OWN: the handle's own non-blocking stream
 OPT_LINESEARCH_FALLBACK = 1       # MPCGPU_OPT_LINESEARCH_FALLBACK
 OPT_PAIRING = 2                   # MPCGPU_OPT_PAIRING
