@@ -1,7 +1,7 @@
 #!/bin/bash
 # L2 <-> fabric traffic and kernel time of the benchmark batch with 12 and with 16 resident wavefronts per CU (the 148-VGPR
 # build forced by build_ab/three_waves.so = -DMPC_TRY_FOUR_WAVES=0, and the product library).  One rocprofv3 pass per counter.
-#   build first (build container):  cd trajtrack_mpcndqn_rlboost_amd/csrc && make OUT=../../build_ab/three_waves.so EXTRA=-DMPC_TRY_FOUR_WAVES=0
+#   build first (build container):  cd trajtrack_mpcndqn_rlboost_amd/csrc && make OUT=../../build_ab/three_waves.so OBJ=../../build_obj_w12 EXTRA=-DMPC_TRY_FOUR_WAVES=0
 #   usage (GPU box): tools/traffic_ab.sh [outdir = gpurun_out/traffic_ab]
 set -u
 REPO="$(cd "$(dirname "$0")/.." && pwd)"
