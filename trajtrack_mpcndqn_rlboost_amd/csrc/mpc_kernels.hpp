@@ -68,7 +68,8 @@ enum { H_X0 = 0, H_Y0 = 1, H_TH0 = 2, H_XG = 3, H_YG = 4, H_THG = 5, H_VINIT = 6
 enum { H_KS = 18, H_KF = 19, H_KD = 20, H_CTH0 = 21, H_STH0 = 22, H_NPF = 23, H_NPD = 24, H_VAR = 25 /* 1: some dynamic row changes shape over the horizon */,
        H_ENTRY = 26 /* .. +Ndynobs */ };
 // batch-wide reductions written by the compaction kernel
-enum { CNT_KS = 0, CNT_KF = 1, CNT_KD = 2, CNT_VARSHAPE = 3 };
+enum { CNT_KS = 0, CNT_KF = 1, CNT_KD = 2, CNT_VARSHAPE = 3, CNT_ROTATED = 4 /* some active dynamic row is not an axis-aligned ellipse (angle != 0) */,
+       CNT_WORDS = 8 };
 
 struct KParams {
     int N, Nother, Nstcobs, Ndynobs, np, mem;
@@ -450,7 +451,7 @@ __device__ __forceinline__ void prep_problem(const KParams& kp, const double* __
     }
     // ---- dynamic obstacles: lane i checks row i
     int Kd;
-    bool varshape = false;
+    bool varshape = false, rotated = false;
     __shared__ int s_entry[WAVE];  // original row -> entry (or -1 for padded rows)
     {
         bool nz = false;
@@ -459,6 +460,7 @@ __device__ __forceinline__ void prep_problem(const KParams& kp, const double* __
             for (int t = 0; t < 6 * N; ++t) nz |= (q[t] != 0.0);
             for (int k = 1; k < N; ++k)  // semi-axes, angle and alpha constant over the horizon?
                 varshape |= (q[6 * k + 2] != q[2]) | (q[6 * k + 3] != q[3]) | (q[6 * k + 4] != q[4]) | (q[6 * k + 5] != q[5]);
+            for (int k = 0; k < N; ++k) rotated |= nz && (q[6 * k + 4] != 0.0);  // angle 0 <=> cos = 1, sin = 0 exactly
         }
         const unsigned long long m = __ballot(nz);
         Kd = __popcll(m);
@@ -488,7 +490,7 @@ __device__ __forceinline__ void prep_problem(const KParams& kp, const double* __
             if (k == 0) ws[kp.ws_alpha + e] = q[5];
         }
     }
-    const bool any_var = __ballot(varshape) != 0ull;
+    const bool any_var = __ballot(varshape) != 0ull, any_rot = __ballot(rotated) != 0ull;
     if (lane == 0) {
         ws[H_KS] = (double)Ks; ws[H_KF] = (double)Kf; ws[H_KD] = (double)Kd; ws[H_VAR] = any_var ? 1.0 : 0.0;
         if (counts) {
@@ -496,6 +498,7 @@ __device__ __forceinline__ void prep_problem(const KParams& kp, const double* __
             atomicMax(counts + CNT_KF, Kf);
             atomicMax(counts + CNT_KD, Kd);
             if (any_var) atomicMax(counts + CNT_VARSHAPE, 1);
+            if (any_rot) atomicMax(counts + CNT_ROTATED, 1);
         }
     }
 }
@@ -581,7 +584,10 @@ __device__ __forceinline__ void load_problem(const KParams& kp, const double* __
 struct DynItem {
     double a, b, ca, sa, ihx, ihy, isx, isy, wgt;
 };
-template <bool SC>
+// AXIS: every active dynamic row of the batch is an axis-aligned ellipse (angle 0, i.e. cos = 1 and sin = 0 exactly -- what the
+// reference's own prediction feeder produces, src/main.py:77-85): the rotation into the ellipse frame is the identity up to the
+// sign of b.  The general expressions give a = ex and b = -ey EXACTLY in that case (x*1 + y*0), so skipping them changes no bit.
+template <bool SC, bool AXIS = false>
 __device__ __forceinline__ DynItem dyn_item(const Ctx& cx, int i, int k, int N, double px, double py) {
     DynItem d;
     double ex, ey;
@@ -595,15 +601,18 @@ __device__ __forceinline__ DynItem dyn_item(const Ctx& cx, int i, int k, int N, 
         ex = px - e[0]; ey = py - e[1];
         d.ca = e[2]; d.sa = e[3]; d.ihx = e[4]; d.ihy = e[5]; d.isx = e[6]; d.isy = e[7]; d.wgt = e[8];
     }
-    d.a = ex * d.ca + ey * d.sa;
-    d.b = ex * d.sa - ey * d.ca;
+    if (AXIS) { d.a = ex; d.b = -ey; }
+    else {
+        d.a = ex * d.ca + ey * d.sa;
+        d.b = ex * d.sa - ey * d.ca;
+    }
     return d;
 }
 
 // ------------------------------------------------------------------------------------------------
 // psi(u; c, y), f(u), F1, F2 and (optionally) grad psi at the point held by the vector lanes.
 // ------------------------------------------------------------------------------------------------
-template <int NT, bool SC, class P>
+template <int NT, bool SC, class P, bool AXIS = false>
 __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, double v, double w, double c, double icm,
                                            double ya, double yb, bool want_grad, bool want_f, EvalOut& out PROF_ARG) {
     const int N = NT ? NT : kp.N;
@@ -772,7 +781,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         // dynamic ellipses: hard indicator -> H, soft cost with social margin (mpc_generator.py:229-241,38-44,85-95)
         MPC_ITEM_LOOP
         for (int i = c_isub; i < cx.Kd; i += LPS) {
-            const DynItem d = dyn_item<SC>(cx, i, k, N, px, py);
+            const DynItem d = dyn_item<SC, AXIS>(cx, i, k, N, px, py);
             const double a2 = d.a * d.a, b2 = d.b * d.b;
             const double Ih = 1.0 - a2 * d.ihx - b2 * d.ihy;
             anyh |= Ih > 0.0;
@@ -781,8 +790,13 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
             if (Is > 0.0) {
                 cost_l += d.wgt * Is * Is;
                 const double wI = 2.0 * d.wgt * Is;
-                gx += wI * (-2.0 * d.a * d.ca * d.isx - 2.0 * d.b * d.sa * d.isy);
-                gy += wI * (-2.0 * d.a * d.sa * d.isx + 2.0 * d.b * d.ca * d.isy);
+                if (AXIS) {   // the general terms with cos = 1, sin = 0: the products by 1 are exact, those by 0 vanish
+                    gx += wI * (-2.0 * d.a * d.isx);
+                    gy += wI * (2.0 * d.b * d.isy);
+                } else {
+                    gx += wI * (-2.0 * d.a * d.ca * d.isx - 2.0 * d.b * d.sa * d.isy);
+                    gy += wI * (-2.0 * d.a * d.sa * d.isx + 2.0 * d.b * d.ca * d.isy);
+                }
             }
         }
     }
@@ -835,12 +849,17 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
             if (any_h) {
                 MPC_ITEM_LOOP
         for (int i = c_isub; i < cx.Kd; i += LPS) {
-                    const DynItem d = dyn_item<SC>(cx, i, k, N, px, py);
+                    const DynItem d = dyn_item<SC, AXIS>(cx, i, k, N, px, py);
                     const double Ih = 1.0 - d.a * d.a * d.ihx - d.b * d.b * d.ihy;
                     if (Ih > 0.0) {
                         const double wi = cx.W[i];
-                        gx += wi * (-2.0 * d.a * d.ca * d.ihx - 2.0 * d.b * d.sa * d.ihy);
-                        gy += wi * (-2.0 * d.a * d.sa * d.ihx + 2.0 * d.b * d.ca * d.ihy);
+                        if (AXIS) {
+                            gx += wi * (-2.0 * d.a * d.ihx);
+                            gy += wi * (2.0 * d.b * d.ihy);
+                        } else {
+                            gx += wi * (-2.0 * d.a * d.ca * d.ihx - 2.0 * d.b * d.sa * d.ihy);
+                            gy += wi * (-2.0 * d.a * d.sa * d.ihx + 2.0 * d.b * d.ca * d.ihy);
+                        }
                     }
                 }
             }
@@ -939,7 +958,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
 // ------------------------------------------------------------------------------------------------
 // test-hook kernel: one evaluation per problem through eval_point
 // ------------------------------------------------------------------------------------------------
-template <int NT, bool SC, class P>
+template <int NT, bool SC, class P, bool AXIS = false>
 __global__ __launch_bounds__(WAVE) void cost_grad_kernel(KParams kp, BatchPtrs io, const double* __restrict__ u,
                                                          const double* __restrict__ xi, double* psi, double* f,
                                                          double* grad, double* F1, double* F2, int B) {
@@ -959,7 +978,7 @@ __global__ __launch_bounds__(WAVE) void cost_grad_kernel(KParams kp, BatchPtrs i
 #ifdef MPC_PROFILE
     Prof prof; prof.start();
 #endif
-    eval_point<NT, SC, P>(kp, cx, v, w, c, 1.0 / fmax(c, 1.0), ya, yb, true, true, o PROF_PASS);
+    eval_point<NT, SC, P, AXIS>(kp, cx, v, w, c, 1.0 / fmax(c, 1.0), ya, yb, true, true, o PROF_PASS);
     if (lane == 0) {
         if (psi) psi[b] = o.psi;
         if (f) f[b] = o.f;
@@ -1224,7 +1243,7 @@ __device__ __forceinline__ bool alm_stalled(const Ctx& cx, const KParams& kp, in
 
 // The whole ALM / PANOC solve of problem P::problem() on the lanes P gives it.  `lds` is the workgroup's dynamic LDS.
 // The iteration is a small state machine around ONE call site of eval_point.
-template <int NT, bool SC, bool LBG, class P>
+template <int NT, bool SC, bool LBG, class P, bool AXIS = false>
 __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& io, int B, double* lds) {
     const int b = P::problem();
     if (b >= B) return;
@@ -1314,7 +1333,7 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
         PROF_MARK(10 + state);  // solver logic that led to this evaluation (by the state it was issued for)
         PROF_COUNT(16 + state);
         ++n_eval; n_eval_grad += want_grad ? 1 : 0;
-        eval_point<NT, SC, P>(kp, cx, ev, ew, c, icm, ya, yb, want_grad, state == ST_OUTER, o PROF_PASS);
+        eval_point<NT, SC, P, AXIS>(kp, cx, ev, ew, c, icm, ya, yb, want_grad, state == ST_OUTER, o PROF_PASS);
         bool step_begin = false;
 
         if (state == ST_INIT0) {
@@ -1478,10 +1497,10 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
     }
 }
 
-template <int NT, bool SC, bool LBG, int MINW>
+template <int NT, bool SC, bool LBG, int MINW, bool AXIS = false>
 __global__ __launch_bounds__(WAVE, MINW) void solve_kernel_pair(KParams kp, BatchPtrs io, int B) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    solve_body<NT, SC, LBG, Solo<NT>>(kp, io, B, lds);
+    solve_body<NT, SC, LBG, Solo<NT>, AXIS>(kp, io, B, lds);
 }
 // two problems per wavefront (grid = ceil(B / 2)); 2 wavefronts per SIMD = the same 16 resident problems per CU
 template <int NT, bool SC, bool LBG>

@@ -39,6 +39,7 @@ struct Handle {
     int last_shape[4] = {0, 0, 0, 0};
     int last_B = 0;  // batch size of the last solve (for mpcgpu_last_eval_counts)
     bool shape_const = true;  // of the batch prepared last
+    bool axis_aligned = false;  // ... and every active dynamic row of it has angle 0 (known only after a count read-back)
     int last_min_waves = 0;   // launch-bounds variant of the last solve (3 or 4 wavefronts per SIMD)
     int num_cus = 256;
     int team_max_batch = -1;  // MPCGPU_OPT_TEAM_BATCH: largest batch solved by the latency kernel (-1: 4 x number of CUs)
@@ -219,14 +220,14 @@ void fill_lds_layout(KParams& k, int mKs, int mKf, int mKd, bool shape_const, bo
 // maxima).  Leaves kp ready for a launch on `s`.
 int prepare(Handle* h, int B, const double* d_p, hipStream_t s, BatchPtrs& io, bool allow_reserved) {
     if (int r = ensure(h, h->ws, (size_t)B * h->kp.ws_stride * sizeof(double))) return r;
-    if (int r = ensure(h, h->counts, 4 * sizeof(int))) return r;
+    if (int r = ensure(h, h->counts, CNT_WORDS * sizeof(int))) return r;
     io.p = d_p;
     io.ws = (double*)h->ws.ptr;
     io.counts = (int*)h->counts.ptr;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(s, &cap);
     h->capturing = cap != hipStreamCaptureStatusNone;
-    HIP_OK(h, hipMemsetAsync(io.counts, 0, 4 * sizeof(int), s));
+    HIP_OK(h, hipMemsetAsync(io.counts, 0, CNT_WORDS * sizeof(int), s));
     if (!h->capturing) HIP_OK(h, hipEventRecord(h->ev[0], s));
     hipLaunchKernelGGL(prep_kernel, dim3(B), dim3(WAVE), 0, s, h->kp, io, B);
     HIP_OK(h, hipGetLastError());
@@ -235,13 +236,15 @@ int prepare(Handle* h, int B, const double* d_p, hipStream_t s, BatchPtrs& io, b
     if (allow_reserved && h->reserved) {
         mKs = h->res_shape[0]; mKf = h->res_shape[1]; mKd = h->res_shape[2];
         h->shape_const = h->res_shape[3] == 0;
+        h->axis_aligned = false;
         h->kp.reserved = 1;
     } else {
         if (h->capturing) return fail(h, -6, "stream capture needs mpcgpu_reserve_shape: the automatic LDS carve reads the batch's row counts back");
-        HIP_OK(h, hipMemcpyAsync(h->h_counts, io.counts, 4 * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_OK(h, hipMemcpyAsync(h->h_counts, io.counts, CNT_WORDS * sizeof(int), hipMemcpyDeviceToHost, s));
         HIP_OK(h, hipStreamSynchronize(s));
         mKs = h->h_counts[CNT_KS]; mKf = h->h_counts[CNT_KF]; mKd = h->h_counts[CNT_KD];
         h->shape_const = h->h_counts[CNT_VARSHAPE] == 0;
+        h->axis_aligned = h->shape_const && h->h_counts[CNT_ROTATED] == 0;
         h->kp.reserved = 0;
     }
     fill_lds_layout(h->kp, mKs, mKf, mKd, h->shape_const, !LBFGS_IN_WORKSPACE);
@@ -304,7 +307,7 @@ int32_t mpcgpu_create(const mpcgpu_config* cfg, void** handle) {
     CREATE_OK(hipDeviceGetAttribute(&h->num_cus, hipDeviceAttributeMultiprocessorCount, h->device));
     CREATE_OK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     for (auto& ev : h->ev) CREATE_OK(hipEventCreate(&ev));
-    CREATE_OK(hipHostMalloc((void**)&h->h_counts, 4 * sizeof(int), hipHostMallocDefault));
+    CREATE_OK(hipHostMalloc((void**)&h->h_counts, CNT_WORDS * sizeof(int), hipHostMallocDefault));
 #undef CREATE_OK
     *handle = h;
     return 0;
@@ -355,7 +358,7 @@ int32_t mpcgpu_solve_batch_dev(void* handle, int32_t B, const double* p, const d
 #ifndef MPC_TRACE
     if (B <= team_cap && !h->reserved && !use_duo(h)) {
         if (int r = ensure(h, h->ws, (size_t)B * h->kp.ws_stride * sizeof(double))) return r;
-        if (int r = ensure(h, h->counts, 4 * sizeof(int))) return r;
+        if (int r = ensure(h, h->counts, CNT_WORDS * sizeof(int))) return r;
         if (int r = ensure(h, h->evals, (size_t)B * 2 * sizeof(int32_t))) return r;
         io.p = p; io.ws = (double*)h->ws.ptr; io.counts = nullptr; io.evals = (int32_t*)h->evals.ptr;
         io.u0 = u0; io.y0 = y0; io.c0 = c0; io.u = u; io.cost = cost; io.status = status; io.inner_it = inner_it;
@@ -408,9 +411,9 @@ int32_t mpcgpu_solve_batch_dev(void* handle, int32_t B, const double* p, const d
     if (!h->capturing) HIP_OK(h, hipEventRecord(h->ev[2], s));
     const size_t lds = h->kp.l_total * sizeof(double);
     // more than 64 KiB of dynamic LDS (long horizons with many time-varying obstacles) must be opted into per kernel
-#define LAUNCH_PAIR_W(NT, SC, MINW)                                                                                \
+#define LAUNCH_PAIR_WA(NT, SC, MINW, AX)                                                                           \
     do {                                                                                                             \
-        auto kern = solve_kernel_pair<NT, SC, LBFGS_IN_WORKSPACE, MINW>;                                             \
+        auto kern = solve_kernel_pair<NT, SC, LBFGS_IN_WORKSPACE, MINW, AX>;                                         \
         if (lds > 64 * 1024)                                                                                         \
             HIP_OK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
         hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE), lds, s, h->kp, io, B);                                         \
@@ -421,6 +424,12 @@ int32_t mpcgpu_solve_batch_dev(void* handle, int32_t B, const double* p, const d
     // the batch has more problems than the 148-VGPR build can keep resident (12 per CU), the 128-VGPR build (4
     // wavefronts per SIMD, ~20 spilled registers) wins by 9-12 %; a batch that fits anyway, or a bigger carve, runs
     // the build without spills (it is 13 % faster per wavefront).
+    // shape-constant tables whose rows are all axis-aligned (the reference's own prediction feeder): the kernel without the
+    // rotation into the ellipse frame -- the same bits, fewer instructions
+#define LAUNCH_PAIR_W(NT, SC, MINW)                                                                                \
+    do {                                                                                                             \
+        if ((SC) && h->axis_aligned) LAUNCH_PAIR_WA(NT, SC, MINW, (SC)); else LAUNCH_PAIR_WA(NT, SC, MINW, false);  \
+    } while (0)
 #define LAUNCH_PAIR(NT, SC) LAUNCH_PAIR_W(NT, SC, MPC_MIN_WAVES)
     const bool sc = h->shape_const;
     const bool four = MPC_TRY_FOUR_WAVES && lds <= 10 * 1024 && B > 4 * MPC_MIN_WAVES * h->num_cus;
@@ -446,6 +455,7 @@ int32_t mpcgpu_solve_batch_dev(void* handle, int32_t B, const double* p, const d
     }
 #undef LAUNCH_DUO
 #undef LAUNCH_PAIR
+#undef LAUNCH_PAIR_WA
 #undef LAUNCH_PAIR_W
     HIP_OK(h, hipGetLastError());
     if (!h->capturing) HIP_OK(h, hipEventRecord(h->ev[3], s));
@@ -521,14 +531,18 @@ int32_t mpcgpu_cost_grad_batch(void* handle, int32_t B, const double* u, const d
     BatchPtrs io{};
     if (int r = prepare(h, B, (const double*)h->p.ptr, s, io, false)) return r;
     const size_t lds_cg = h->kp.l_total * sizeof(double);
-#define LAUNCH_CG(NT, SC, PP, GRID, LDSB)                                                                           \
+#define LAUNCH_CGA(NT, SC, PP, GRID, LDSB, AX)                                                                      \
     do {                                                                                                             \
-        auto kern = cost_grad_kernel<NT, SC, PP>;                                                                    \
+        auto kern = cost_grad_kernel<NT, SC, PP, AX>;                                                                \
         if ((LDSB) > 64 * 1024)                                                                                      \
             HIP_OK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDSB))); \
         hipLaunchKernelGGL(kern, dim3(GRID), dim3(WAVE), (LDSB), s, h->kp, io, (const double*)h->u.ptr,              \
                            (const double*)h->xi.ptr, (double*)h->psi.ptr, (double*)h->f.ptr, (double*)h->grad.ptr,   \
                            (double*)h->F1.ptr, (double*)h->F2.ptr, B);                                               \
+    } while (0)
+#define LAUNCH_CG(NT, SC, PP, GRID, LDSB)                                                                           \
+    do {                                                                                                             \
+        if ((SC) && h->axis_aligned) LAUNCH_CGA(NT, SC, PP, GRID, LDSB, (SC)); else LAUNCH_CGA(NT, SC, PP, GRID, LDSB, false); \
     } while (0)
 #define LAUNCH_CG1(NT, SC) LAUNCH_CG(NT, SC, Solo<NT>, B, lds_cg)
     if (h->last_pairing) {
@@ -548,6 +562,8 @@ int32_t mpcgpu_cost_grad_batch(void* handle, int32_t B, const double* u, const d
         }
     }
 #undef LAUNCH_CG1
+#undef LAUNCH_CG
+#undef LAUNCH_CGA
 #undef LAUNCH_CG
     HIP_OK(h, hipGetLastError());
     if (psi) HIP_OK(h, hipMemcpyAsync(psi, h->psi.ptr, Bz * 8, hipMemcpyDeviceToHost, s));
