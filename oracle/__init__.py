@@ -38,6 +38,7 @@ class OracleConfig(C.Structure):
         ("init_penalty", C.c_double), ("penalty_update", C.c_double), ("tol_update", C.c_double),
         ("suff_decrease", C.c_double),
         ("max_inner", C.c_int32), ("max_outer", C.c_int32), ("lbfgs_mem", C.c_int32), ("ls_fallback", C.c_int32),
+        ("lbfgs_gram", C.c_int32), ("_reserved", C.c_int32),
         ("max_duration_us", C.c_double),
     ]
 
@@ -45,7 +46,7 @@ class OracleConfig(C.Structure):
     def from_dict(cls, d: dict) -> "OracleConfig":
         cfg = cls()
         for name, _ in cls._fields_:
-            setattr(cfg, name, d.get(name, 0) if name == "ls_fallback" else d[name])
+            setattr(cfg, name, d.get(name, 0) if name in ("ls_fallback", "lbfgs_gram", "_reserved") else d[name])
         return cfg
 
 
@@ -55,13 +56,14 @@ class OracleResult(C.Structure):
         ("penalty", C.c_double), ("solve_time_ms", C.c_double),
         ("status", C.c_int32), ("outer_iters", C.c_int32), ("inner_iters", C.c_int32),
         ("n_cost_evals", C.c_int32), ("n_grad_evals", C.c_int32), ("_pad", C.c_int32),
+        ("lbfgs_dev", C.c_double),
     ]
 
 
 RESULT_DTYPE = np.dtype([
     ("cost", "f8"), ("fpr", "f8"), ("f2_norm", "f8"), ("delta_y_norm", "f8"), ("penalty", "f8"),
     ("solve_time_ms", "f8"), ("status", "i4"), ("outer_iters", "i4"), ("inner_iters", "i4"),
-    ("n_cost_evals", "i4"), ("n_grad_evals", "i4"), ("_pad", "i4")])
+    ("n_cost_evals", "i4"), ("n_grad_evals", "i4"), ("_pad", "i4"), ("lbfgs_dev", "f8")])
 assert RESULT_DTYPE.itemsize == C.sizeof(OracleResult)
 
 

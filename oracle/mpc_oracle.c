@@ -336,13 +336,17 @@ void mpc_oracle_cost_grad(const mpc_oracle_config* cfg, const double* u, double 
 /* ------------------------------------------------------------------------------------------ */
 typedef struct {
     int n, mem, active, first_old;
+    int gram; /* cfg->lbfgs_gram */
     double gamma;
     double s[MEM_MAX + 1][NU_MAX], y[MEM_MAX + 1][NU_MAX];
     double rho[MEM_MAX + 1], alpha[MEM_MAX + 1];
     double old_state[NU_MAX], old_g[NU_MAX];
+    /* Gram form (lbfgs_gram != 0): sy[i][j] = s_i . y_j, yy[i][j] = y_i . y_j of the pairs held, newest at index 0 */
+    double sy[MEM_MAX + 1][MEM_MAX + 1], yy[MEM_MAX + 1][MEM_MAX + 1];
+    double dev_max; /* lbfgs_gram == 2: largest relative deviation of the Gram direction from the two-loop direction */
 } lbfgs_t;
 
-static const double CBFGS_ALPHA = 1.0, CBFGS_EPSILON = 1e-8, SY_EPSILON = 1e-10;
+static const double CBFGS_EPSILON = 1e-8, SY_EPSILON = 1e-10; /* C-BFGS alpha = 1 */
 
 static double dot(const double* a, const double* b, int n) {
     double s = 0.0;
@@ -366,13 +370,27 @@ static void lbfgs_update(lbfgs_t* l, const double* g, const double* state) {
     for (int i = 0; i < n; ++i) { sn[i] = state[i] - l->old_state[i]; yn[i] = g[i] - l->old_g[i]; }
     const double ys = dot(sn, yn, n), ss = dot(sn, sn, n);
     if (ss <= DBL_MIN || ys <= SY_EPSILON) return;                          /* rejected */
-    if (!(ys / ss > CBFGS_EPSILON * pow(norm2(g, n), CBFGS_ALPHA))) return; /* C-BFGS (Li-Fukushima) */
+    /* C-BFGS (Li-Fukushima): s'y / ||s||^2 > eps ||g||^alpha with alpha = 1; ||s||^2 > 0 was checked just above, so the
+     * test is written as a multiplication -- the form the GPU kernel evaluates (mpc_kernels.hpp PanocLbfgs::update) */
+    if (!(ys > (CBFGS_EPSILON * norm2(g, n)) * ss)) return;
     memcpy(l->old_state, state, n * sizeof(double));
     memcpy(l->old_g, g, n * sizeof(double));
     /* rotate right by one: the fresh pair moves to index 0 */
     double ts_[NU_MAX], ty_[NU_MAX];
     memcpy(ts_, sn, n * sizeof(double));
     memcpy(ty_, yn, n * sizeof(double));
+    if (l->gram) {
+        /* Gram matrices follow the rotation; the new row / column 0 holds the products with the pairs that stay */
+        for (int i = m; i > 0; --i)
+            for (int j = m; j > 0; --j) { l->sy[i][j] = l->sy[i - 1][j - 1]; l->yy[i][j] = l->yy[i - 1][j - 1]; }
+        for (int j = 1; j <= m; ++j) {
+            l->sy[0][j] = dot(ts_, l->y[j - 1], n);   /* s_new . y_j */
+            l->sy[j][0] = dot(l->s[j - 1], ty_, n);   /* s_j . y_new */
+            l->yy[0][j] = l->yy[j][0] = dot(ty_, l->y[j - 1], n);
+        }
+        l->sy[0][0] = ys;
+        l->yy[0][0] = dot(ty_, ty_, n);
+    }
     for (int j = m; j > 0; --j) {
         memcpy(l->s[j], l->s[j - 1], n * sizeof(double));
         memcpy(l->y[j], l->y[j - 1], n * sizeof(double));
@@ -385,8 +403,8 @@ static void lbfgs_update(lbfgs_t* l, const double* g, const double* state) {
     l->active = (l->active + 1 < m) ? l->active + 1 : m;
 }
 
-/* two-loop recursion, q <- H q */
-static void lbfgs_apply(lbfgs_t* l, double* q) {
+/* two-loop recursion, q <- H q [crate lbfgs: apply_hessian] */
+static void lbfgs_apply_two_loop(lbfgs_t* l, double* q) {
     const int n = l->n;
     if (l->active == 0) return;
     for (int j = 0; j < l->active; ++j) {
@@ -399,6 +417,50 @@ static void lbfgs_apply(lbfgs_t* l, double* q) {
         const double b = l->rho[j] * dot(l->y[j], q, n);
         for (int i = 0; i < n; ++i) q[i] += (l->alpha[j] - b) * l->s[j][i];
     }
+}
+
+/* The same operator H in Gram form -- what the GPU kernel evaluates (mpc_kernels.hpp PanocLbfgs::direction): the 2m inner
+ * products S'r, Y'r are independent of each other (one matrix-vector pass instead of 2m dependent reductions), the two loops
+ * become scalar recurrences on the cached Gram entries s_i.y_j, y_i.y_j, and the direction is one linear combination
+ *   d = gamma r + sum_p (alpha_p - beta_p) s_p - gamma alpha_p y_p.
+ * Exact-arithmetic identical to the two-loop recursion: with q_p = r - sum_{q<p} alpha_q y_q,
+ *   s_p.q_p = s_p.r - sum_{q<p} alpha_q (s_p.y_q)                                     (first loop, newest pair first)
+ *   y_p.z_p = gamma (y_p.r - sum_q alpha_q (y_p.y_q)) + sum_{q>p} delta_q (s_q.y_p)   (second loop, oldest pair first) */
+static void lbfgs_apply_gram(lbfgs_t* l, double* q) {
+    const int n = l->n, a = l->active;
+    if (a == 0) return;
+    double acc[MEM_MAX + 1], t[MEM_MAX + 1], alpha[MEM_MAX + 1], delta[MEM_MAX + 1];
+    for (int j = 0; j < a; ++j) { acc[j] = dot(l->s[j], q, n); t[j] = dot(l->y[j], q, n); }
+    for (int p = 0; p < a; ++p) {
+        alpha[p] = l->rho[p] * acc[p];
+        for (int j = 0; j < a; ++j) { acc[j] -= alpha[p] * l->sy[j][p]; t[j] -= alpha[p] * l->yy[j][p]; }
+    }
+    for (int j = 0; j < a; ++j) t[j] *= l->gamma;
+    for (int p = a - 1; p >= 0; --p) {
+        delta[p] = alpha[p] - l->rho[p] * t[p];
+        for (int j = 0; j < a; ++j) t[j] += delta[p] * l->sy[p][j];
+    }
+    for (int i = 0; i < n; ++i) {
+        double d = l->gamma * q[i];
+        for (int p = 0; p < a; ++p) d += delta[p] * l->s[p][i];
+        for (int p = 0; p < a; ++p) d += (-(l->gamma * alpha[p])) * l->y[p][i];
+        q[i] = d;
+    }
+}
+
+static void lbfgs_apply(lbfgs_t* l, double* q) {
+    if (l->gram == 1) { lbfgs_apply_gram(l, q); return; }
+    if (l->gram == 2 && l->active > 0) { /* two-loop drives the iteration; the Gram form is evaluated beside it */
+        double g[NU_MAX];
+        memcpy(g, q, l->n * sizeof(double));
+        lbfgs_apply_gram(l, g);
+        lbfgs_apply_two_loop(l, q);
+        double num = 0.0, den = 0.0;
+        for (int i = 0; i < l->n; ++i) { num = fmax(num, fabs(g[i] - q[i])); den = fmax(den, fabs(q[i])); }
+        if (den > 0.0 && num / den > l->dev_max) l->dev_max = num / den;
+        return;
+    }
+    lbfgs_apply_two_loop(l, q);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -630,7 +692,7 @@ static int32_t solve_impl(const mpc_oracle_config* cfg, const double* p, const d
     panoc_t* s = (panoc_t*)calloc(1, sizeof(panoc_t));
     if (!s) return -2;
     s->cfg = cfg; s->p = p; s->n = n;
-    s->lb.n = n; s->lb.mem = cfg->lbfgs_mem;
+    s->lb.n = n; s->lb.mem = cfg->lbfgs_mem; s->lb.gram = cfg->lbfgs_gram; s->lb.dev_max = 0.0;
     s->tol = cfg->tol;
     s->max_us = cfg->max_duration_us;
     s->trace = trace; s->trace_cap = cap; s->trace_n = 0;
@@ -708,6 +770,7 @@ static int32_t solve_impl(const mpc_oracle_config* cfg, const double* p, const d
         res->n_cost_evals = s->n_cost;
         res->n_grad_evals = s->n_grad;
         res->_pad = 0;
+        res->lbfgs_dev = s->lb.dev_max;
     }
     if (n_steps) *n_steps = s->trace_n;
     free(s);

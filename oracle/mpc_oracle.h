@@ -56,6 +56,11 @@ typedef struct mpc_oracle_config {
     int32_t ls_fallback;   /* line search that fails 10 halvings: 0 = the last trial point (tau = 2^-10) is the next iterate
                               [what the published code does: its tau = 0 copy is overwritten by the u_plus swap];
                               1 = tau = 0, i.e. u - gamma*fpr is evaluated and taken */
+    int32_t lbfgs_gram;    /* how H * (gamma fpr) is evaluated: 0 = two-loop recursion [the published crate]; 1 = the Gram form of
+                              the same operator (what the GPU kernel evaluates, mpc_kernels.hpp PanocLbfgs::direction: identical in
+                              exact arithmetic, rounded differently); 2 = two-loop drives the iteration, the Gram form is evaluated
+                              beside it and the largest relative deviation is reported in mpc_oracle_result.lbfgs_dev */
+    int32_t _reserved;
     double max_duration_us; /* 5e6; <=0 disables the wall-clock test */
 } mpc_oracle_config;
 
@@ -89,6 +94,7 @@ typedef struct mpc_oracle_result {
     int32_t n_cost_evals; /* psi evaluations actually executed   */
     int32_t n_grad_evals; /* grad psi evaluations actually executed */
     int32_t _pad;
+    double lbfgs_dev;     /* lbfgs_gram == 2: max over the solve of |d_gram - d_two_loop|_inf / |d_two_loop|_inf */
 } mpc_oracle_result;
 
 /* One solve. u0 / y0 may be NULL (zeros); c0 <= 0 means cfg->init_penalty. y_out may be NULL. */

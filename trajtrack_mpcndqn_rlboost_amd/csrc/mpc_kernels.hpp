@@ -87,7 +87,7 @@ struct KParams {
     // LDS layout (doubles), strides use the batch maxima mKs/mKf/mKd
     int mKs, mKf, mKd;
     int reserved;  // 1: the carve comes from mpcgpu_reserve_shape, problems are checked against it on the device
-    int l_seg, l_stc, l_fxy, l_dyn, l_dync, l_qd, l_pos, l_H, l_W, l_part, l_stash, l_hd, l_S, l_Y, l_rho, l_alpha, l_old, l_total;
+    int l_seg, l_stc, l_fxy, l_dyn, l_dync, l_qd, l_pos, l_H, l_W, l_part, l_stash, l_hd, l_S, l_Y, l_rho, l_alpha, l_old, l_gg, l_total;
     int l_wstride, l_xch;  // team kernel (mpc_team.hpp): doubles per wavefront work block, offset of the exchange area
 };
 
@@ -875,17 +875,20 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     }
 
     PROF_MARK(6);  // phase B
-    // ---- combine the LPS item lanes of each step on its vector lane
-    if (c_il) {
-        double* pp = cx.part + (c_isub * N + c_ik) * PARTW;
+    // ---- combine the LPS item lanes of each step on its vector lane.  Lane k < N is itself the first item lane of step k
+    //      (sub 0): its partial stays in registers, only the lanes of sub >= 1 go through LDS.
+    if (c_il && c_isub > 0) {
+        double* pp = cx.part + ((c_isub - 1) * N + c_ik) * PARTW;
         pp[0] = gx; pp[1] = gy; pp[2] = best; pp[3] = bgx; pp[4] = bgy;
     }
     wave_sync();
     double Gx = Gpx, Gy = Gpy, vcost = 0.0;
     if (c_vl) {
         double bb = inf, wbx = 0.0, wby = 0.0;
-        for (int s = 0; s < LPS; ++s) {
-            const double* pp = cx.part + (s * N + lane) * PARTW;
+        Gx += gx; Gy += gy;
+        if (best < bb) { bb = best; wbx = bgx; wby = bgy; }
+        for (int s = 1; s < LPS; ++s) {
+            const double* pp = cx.part + ((s - 1) * N + lane) * PARTW;
             Gx += pp[0]; Gy += pp[1];
             if (pp[2] < bb) { bb = pp[2]; wbx = pp[3]; wby = pp[4]; }
         }
@@ -1098,6 +1101,19 @@ __device__ __forceinline__ bool panoc_step_residual(const Ctx& cx, const KParams
     return ex;
 }
 
+// Where the L-BFGS state of one problem lives (per wavefront).  LM = [S; Y] as 2 mem rows of N (v, w) pairs, slot-major: in
+// the problem's workspace record (L2-resident global memory) in the throughput kernel, in LDS in the latency kernel and in the
+// L-BFGS-in-LDS build.  GG, LRHO stay in LDS for the whole solve; XA is scratch between two evaluations (it aliases the
+// evaluation's own scratch: positions + stash).
+struct LbMem {
+    double* LM;     // [2 mem + 1][N][2]: rows 0..mem-1 = s of slot 0..mem-1, rows mem..2mem-1 = y, then one row of zeros
+    double* LOLD;   // [N][4]: previous (u, gamma fpr)
+    double* LRHO;   // [mem]
+    double* LALPHA; // [mem]        two-loop form only
+    double* GG;     // [2 mem][mem] Gram form only: rows 0..mem-1: s_i.y_j, rows mem..2mem-1: y_i.y_j (slot indices)
+    double* XA;     // Gram form only: scratch, see PanocLbfgsGram
+};
+
 // L-BFGS buffer of PANOC [crate lbfgs: C-BFGS acceptance]: ring of `mem` pairs (s, y) = (delta u, delta gamma*fpr), newest at
 // `head`; S, Y [mem][N][2], OLD [N][4] = previous (u, gamma*fpr), RHO [mem].
 struct PanocLbfgs {
@@ -1106,8 +1122,8 @@ struct PanocLbfgs {
     double hgamma = 1.0;  // s'y / y'y of the newest pair
     __device__ __forceinline__ void flush() { active = 0; first = true; }
     template <class P>
-    __device__ __forceinline__ void update(const Ctx& cx, bool vl, int lane, int N, int mem, double uv, double uw, double rv, double rw,
-                                           double nfpr, double* LS, double* LY, double* LOLD, double* LRHO) {
+    __device__ __forceinline__ void update_ring(const Ctx& cx, bool vl, int lane, int N, int mem, double uv, double uw, double rv, double rw,
+                                                double nfpr, double* LS, double* LY, double* LOLD, double* LRHO) {
         if (first) {
             first = false;
             if (vl) { LOLD[lane * 4] = uv; LOLD[lane * 4 + 1] = uw; LOLD[lane * 4 + 2] = rv; LOLD[lane * 4 + 3] = rw; }
@@ -1135,8 +1151,8 @@ struct PanocLbfgs {
     // d = H * (gamma*fpr): two-loop recursion, newest pair first.  LBG: S, Y live in the workspace record (global memory):
     // pair j+1 is requested before pair j is consumed.
     template <class P, bool LBG>
-    __device__ __forceinline__ void direction(bool vl, int lane, int N, int mem, double rv, double rw, const double* LS, const double* LY,
-                                              const double* LRHO, double* LALPHA, double& dv, double& dw) const {
+    __device__ __forceinline__ void direction_two_loop(bool vl, int lane, int N, int mem, double rv, double rw, const double* LS, const double* LY,
+                                                       const double* LRHO, double* LALPHA, double& dv, double& dw) const {
         double q0 = rv, q1 = rw;
         if (LBG) {
             // The ring lives in the workspace record (L2, ~700 cycles away).  THREE pairs are kept in flight: pair p travels in
@@ -1211,7 +1227,294 @@ struct PanocLbfgs {
         }
         dv = q0; dw = q1;
     }
+    // the interface the solver kernels use (shared with PanocLbfgsGram)
+    template <class P, int NT, int MEMT>
+    __device__ __forceinline__ void update(const Ctx& cx, const KParams& kp, bool vl, int lane, double uv, double uw, double rv,
+                                           double rw, double nfpr, const LbMem& m, double&) {
+        const int N = NT ? NT : kp.N;
+        update_ring<P>(cx, vl, lane, N, kp.mem, uv, uw, rv, rw, nfpr, m.LM, m.LM + kp.mem * N * 2, m.LOLD, m.LRHO);
+    }
+    template <class P, int NT, int MEMT, bool LBG>
+    __device__ __forceinline__ void direction(const Ctx& cx, const KParams& kp, bool vl, int lane, double rv, double rw, const LbMem& m,
+                                              double, double& dv, double& dw) const {
+        const int N = NT ? NT : kp.N;
+        direction_two_loop<P, LBG>(vl, lane, N, kp.mem, rv, rw, m.LM, m.LM + kp.mem * N * 2, m.LRHO, m.LALPHA, dv, dw);
+    }
 };
+
+// The same buffer and the same operator H as PanocLbfgs, evaluated in GRAM FORM (round 3; oracle: lbfgs_apply_gram, mpc_oracle.c).
+// The two-loop recursion is 2 mem DEPENDENT wave reductions, each waiting for a pair from L2 and using N of 64 lanes.  Here:
+//   pass 1  one matrix-vector pass [S; Y] x over all 64 lanes: lane (row, g) accumulates its share of row . x for
+//           x = gamma fpr and x = y_new (independent FMAs, no reduction; the G partials of a row sit in adjacent lanes);
+//   Gram    the products with y_new are the new column of the cached matrices s_i.y_j, y_i.y_j (LDS);
+//   loops   both loops of the recursion become scalar recurrences on those matrices: the lane of a row carries its own running
+//           product, one v_readlane broadcasts the coefficient of the step, one FMA updates all rows;
+//   pass 2  d = gamma_H r + sum_rows coef[row] * row, again over all lanes (rows split in G2 groups, combined through LDS).
+// Lanes: the s-row of slot l lives in lanes l*G .. l*G+G-1, its y-row 32 lanes higher; a row's total ends in its last lane.
+// Of s_i.y_j only the entries with s_i OLDER than y_j are ever used (first loop: s_p.q_p needs y_q of the newer pairs; second
+// loop: y_p.z needs s_q of the older pairs).  The others -- and the diagonal, which only enters through rho -- are stored as
+// ZERO, so a row's running product stops changing by itself once its turn has passed: no per-step masking or latching.
+// Exact-arithmetic identical to the two-loop recursion; measured against it over whole solves: 5e-12 relative (oracle, mode 2).
+#ifndef MPC_LB_SCHED
+#define MPC_LB_SCHED 2  // pass 1: the scheduler may not pull the LDS operands of more than this many pairs ahead (registers)
+#endif
+#ifndef MPC_LB_BLOCK
+#define MPC_LB_BLOCK 8
+#endif
+#ifndef MPC_LB_PREFETCH1
+#define MPC_LB_PREFETCH1 1  // pass 1: request the rows before the new pair is formed
+#endif
+#ifndef MPC_LB_PREFETCH2
+#define MPC_LB_PREFETCH2 1  // pass 2: request the rows before the recurrences
+#endif
+struct PanocLbfgsGram {
+    int active = 0, head = 0;
+    bool first = true;
+    double hgamma = 1.0;
+    __device__ __forceinline__ void flush() { active = 0; first = true; }
+
+    template <int NT, int MEMT>
+    struct Dims {
+        int N, mem, R, G, CL, G2, CR;
+        __device__ __forceinline__ Dims(const KParams& kp) {
+            N = NT ? NT : kp.N; mem = MEMT ? MEMT : kp.mem;
+            R = 2 * mem; G = (WAVE / 2) / mem; CL = (N + G - 1) / G;   // G >= 2 (mem <= 16): chunks of CL (v, w) pairs
+            G2 = WAVE / N; CR = (R + G2 - 1) / G2;                     // pass 2: G2 groups of CR rows
+        }
+        __device__ __forceinline__ int xa_len() const { return G * CL * 4; }  // (r, y) pairs of every chunk slot, zero padded
+    };
+    // lane -> (y-row?, slot, chunk); lanes whose slot is >= mem compute something that is never read
+    struct Role { int isy, slot, slot_a, g; };
+    template <int NT, int MEMT>
+    static __device__ __forceinline__ Role role(const Dims<NT, MEMT>& D, int lane) {
+        Role r;
+        r.isy = lane >> 5;
+        const int l = lane & 31;
+        r.slot = l / D.G; r.g = l - r.slot * D.G;
+        r.slot_a = r.slot < D.mem ? r.slot : D.mem - 1;
+        return r;
+    }
+
+    // `pr` (out): row lanes: (row of [S; Y]) . (gamma fpr) -- what direction() starts from; it lives only between the two calls
+    template <class P, int NT, int MEMT>
+    __device__ __forceinline__ void update(const Ctx& cx, const KParams& kp, bool vl, int lane, double uv, double uw, double rv,
+                                           double rw, double nfpr, const LbMem& m, double& pr) {
+        const Dims<NT, MEMT> D(kp);
+        const int N = D.N, mem = D.mem;
+        double* LOLD = m.LOLD;
+        if (first) {
+            first = false;
+            if (vl) { LOLD[lane * 4] = uv; LOLD[lane * 4 + 1] = uw; LOLD[lane * 4 + 2] = rv; LOLD[lane * 4 + 3] = rw; }
+            return;
+        }
+        // pass-1 operands of this lane: its row of [S; Y], chunk g of the row's (v, w) pairs -- CL consecutive pairs (the last
+        // chunk runs into the next row, or into the zero row that follows the last one: a finite value times the zero padding
+        // of XA).  The OLD rows do not depend on the new pair: with a compile-time shape they are requested before anything else.
+        asm volatile("" : "+v"(lane));  // opaque: the per-lane addresses are rebuilt here, not hoisted out of the solver loop (and spilled)
+        const Role ro = role(D, lane);
+        const int row_a = ro.isy * mem + ro.slot_a;
+        const double2* mrow = reinterpret_cast<const double2*>(m.LM + (row_a * N + ro.g * D.CL) * 2);
+        constexpr int GT = MEMT ? (WAVE / 2) / (MEMT ? MEMT : 1) : 1;
+        constexpr int CLT = (NT && MEMT && MPC_LB_PREFETCH1) ? (NT + GT - 1) / GT : 0;   // pairs per lane (compile-time shape)
+        constexpr int BL = CLT <= MPC_LB_BLOCK ? CLT : (CLT + 1) / 2;   // held in registers at a time (else two blocks)
+        double2 mq[BL ? BL : 1];
+        if (CLT) {
+#pragma unroll
+            for (int t = 0; t < BL; ++t) mq[t] = mrow[t];
+        }
+        double s0 = 0, s1 = 0, y0_ = 0, y1_ = 0;
+        if (vl) {
+            s0 = uv - LOLD[lane * 4]; s1 = uw - LOLD[lane * 4 + 1];
+            y0_ = rv - LOLD[lane * 4 + 2]; y1_ = rw - LOLD[lane * 4 + 3];
+        }
+        for (int k = lane; k < D.G * D.CL; k += WAVE) {  // slots N .. G*CL-1 pad the last chunk with zeros
+            double2* x = reinterpret_cast<double2*>(m.XA + k * 4);
+            const bool real = vl && k == lane;
+            x[0] = make_double2(real ? rv : 0.0, real ? rw : 0.0); x[1] = make_double2(real ? y0_ : 0.0, real ? y1_ : 0.0);
+        }
+        double ys, ss;
+        P::sum2(__builtin_fma(s0, y0_, s1 * y1_), __builtin_fma(s0, s0, s1 * s1), ys, ss);
+        wave_sync();
+        double ar = 0.0, ay = 0.0;
+        auto mac = [&](const double2 mv, int k) {
+            const double2* x = reinterpret_cast<const double2*>(m.XA + k * 4);
+            const double2 xr = x[0], xy = x[1];
+            ar = __builtin_fma(mv.x, xr.x, ar); ar = __builtin_fma(mv.y, xr.y, ar);
+            ay = __builtin_fma(mv.x, xy.x, ay); ay = __builtin_fma(mv.y, xy.y, ay);
+        };
+        if (CLT) {
+#pragma unroll
+            for (int t = 0; t < BL; ++t) {
+                mac(mq[t], ro.g * CLT + t);
+                if (MPC_LB_SCHED && (t % MPC_LB_SCHED) == MPC_LB_SCHED - 1) __builtin_amdgcn_sched_barrier(0);
+            }
+            if (BL < CLT) {
+#pragma unroll
+                for (int t = 0; t < CLT - BL; ++t) mq[t] = mrow[BL + t];
+#pragma unroll
+                for (int t = 0; t < CLT - BL; ++t) mac(mq[t], ro.g * CLT + BL + t);
+            }
+        } else {
+            for (int t = 0; t < D.CL; ++t) mac(mrow[t], ro.g * D.CL + t);
+        }
+        {   // the G partials of a row are in adjacent lanes: ((g0 + g1) + g2) ends in the row's last lane
+            double tr = ar, ty = ay;
+            for (int i = 1; i < D.G; ++i) { tr = ar + dpp0<DPP_WAVE_SHR1>(tr); ty = ay + dpp0<DPP_WAVE_SHR1>(ty); }
+            ar = tr; ay = ty;
+        }
+        pr = ar;
+        if (!(ss <= KC(K_DBLMIN) || ys <= KC(K_MIN_L)) && (ys > (KC(K_CBFGS) * nfpr) * ss)) {  // s'y / ||s||^2 > eps ||gamma fpr||, ||s||^2 > 0
+            double yy, sr;
+            P::sum2(__builtin_fma(y0_, y0_, y1_ * y1_), __builtin_fma(s0, rv, s1 * rw), yy, sr);
+            const double yr = dot2r<P, P::RV>(y0_, y1_, rv, rw);
+            head = head == 0 ? mem - 1 : head - 1;
+            const int h = head;
+            if (vl) {
+                LOLD[lane * 4] = uv; LOLD[lane * 4 + 1] = uw; LOLD[lane * 4 + 2] = rv; LOLD[lane * 4 + 3] = rw;
+                *reinterpret_cast<double2*>(m.LM + (h * N + lane) * 2) = make_double2(s0, s1);
+                *reinterpret_cast<double2*>(m.LM + ((mem + h) * N + lane) * 2) = make_double2(y0_, y1_);
+            }
+            // Column h of both Gram matrices from the totals of pass 1; row h of s_i.y_j is zero (s_new is newer than every y),
+            // and so is its diagonal.  The rows of slot h itself held the pair that is being replaced: what they contribute is
+            // overwritten right after -- the LDS writes of a wavefront keep their order.
+            if (ro.slot < mem && ro.g == D.G - 1) {
+                if (!ro.isy) {
+                    m.GG[ro.slot * mem + h] = ay;                  // s_q . y_new
+                    if (ro.slot == h) pr = sr;
+                } else {
+                    m.GG[(mem + ro.slot) * mem + h] = ay;          // y_q . y_new
+                    m.GG[(mem + h) * mem + ro.slot] = ay;
+                    if (ro.slot == h) pr = yr;
+                }
+            }
+            wave_sync();
+            if (lane < mem) m.GG[h * mem + lane] = 0.0;
+            if (lane == 0) {
+                m.GG[(mem + h) * mem + h] = yy;
+                m.LRHO[h] = 1.0 / ys;
+            }
+            hgamma = P::uni(ys / yy);
+            active = (active + 1 < mem) ? active + 1 : mem;
+        }
+    }
+
+    template <class P, int NT, int MEMT, bool LBG>
+    __device__ __forceinline__ void direction(const Ctx& cx, const KParams& kp, bool vl, int lane, double rv, double rw, const LbMem& m,
+                                              double pr, double& dv, double& dw) const {
+        if (active == 0) { dv = rv; dw = rw; return; }
+        const Dims<NT, MEMT> D(kp);
+        const int N = D.N, mem = D.mem;
+        asm volatile("" : "+v"(lane));  // opaque, see update()
+        const Role ro = role(D, lane);
+        double* COEF = m.XA + D.xa_len();  // [G2 * CR] coefficients of the rows (zero beyond the active pairs)
+        // pass-2 operands: lane = g2 * N + k2 takes rows g2 * CR .. (the row after the last one is the zero row); they depend on
+        // nothing computed here, so with a compile-time shape they are requested before the recurrences
+        const int g2 = lane / N, k2 = lane - g2 * N;
+        const int g2a = g2 < D.G2 ? g2 : D.G2 - 1;
+        constexpr int CRT0 = (NT && MEMT && MPC_LB_PREFETCH2) ? (2 * MEMT + WAVE / (NT ? NT : 1) - 1) / (WAVE / (NT ? NT : 1)) : 0;
+        constexpr int CRT = CRT0 <= 8 ? CRT0 : 0;  // long horizons: one lane group takes all rows, too many to hold in registers
+        {   // zero materialised here: hoisted out of the solver loop it would sit in a spill slot, and its reload would wait for
+            // the row loads below (scratch and global loads share one counter)
+            double z = 0.0;
+            asm volatile("" : "+v"(z));
+            if (lane < D.G2 * D.CR) COEF[lane] = z;
+        }
+        const double rho_l = m.LRHO[ro.slot_a];
+        const int tl = ro.slot_a * D.G + D.G - 1;  // lane that holds the total of this slot's s-row
+        double2 mq[CRT ? CRT : 1];
+        const double2* mcol = reinterpret_cast<const double2*>(m.LM + (g2a * D.CR * N + k2) * 2);  // + tt * N: row g2a * CR + tt
+        if (CRT) {
+#pragma unroll
+            for (int tt = 0; tt < CRT; ++tt) mq[tt] = mcol[tt * N];
+        }
+        // first loop, newest pair first: alpha_p = rho_p s_p.q_p; every row's product with q advances by -alpha_p (row . y_p)
+        const double* grow = m.GG + (ro.isy * mem + ro.slot_a) * mem;
+        double acc = pr;
+        {
+            int sp = head;
+            double gnext = grow[sp];
+            for (int p = 0; p < active; ++p) {
+                const double gcur = gnext;
+                const int sl = sp * D.G + D.G - 1;
+                sp = sp + 1 >= mem ? 0 : sp + 1;
+                gnext = grow[sp];   // one step ahead of the broadcast that needs it
+                const double al = readlane_d(rho_l * acc, sl);
+                acc = __builtin_fma(-al, gcur, acc);
+            }
+        }
+        // alpha of every slot: final in the lane of its s-row (the later steps multiplied zeros); the y-rows get a copy
+        double al_l = rho_l * acc;
+        {
+            const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(al_l), (unsigned)__double2loint(al_l), false, false);
+            const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(al_l), (unsigned)__double2hiint(al_l), false, false);
+            al_l = __hiloint2double((int)hi[0], (int)lo[0]);  // lanes 0..31 keep theirs, lanes 32..63 receive that of lanes 0..31
+        }
+        // second loop, oldest pair first: beta_p = rho_p y_p.z; the y-rows' products with z advance by delta_p (s_p . y_row)
+        double t = hgamma * acc;
+        {
+            int sp = head + active - 1;
+            sp = __builtin_amdgcn_readfirstlane(sp >= mem ? sp - mem : sp);
+            const double* gcol = m.GG + ro.slot_a;
+            double gnext = gcol[sp * mem];
+            for (int p = active - 1; p >= 0; --p) {
+                const double gcur = gnext;
+                const int sl = 32 + sp * D.G + D.G - 1;
+                sp = __builtin_amdgcn_readfirstlane(sp == 0 ? mem - 1 : sp - 1);
+                gnext = gcol[sp * mem];
+                const double de = readlane_d(__builtin_fma(-rho_l, t, al_l), sl);
+                t = __builtin_fma(de, gcur, t);
+            }
+        }
+        // coefficients of the rows: delta_l for s_l, -gamma_H alpha_l for y_l (slots without a pair keep 0)
+        {
+            int pos = ro.slot - head;
+            pos = pos < 0 ? pos + mem : pos;
+            if (ro.isy && ro.slot < mem && ro.g == D.G - 1 && pos < active) {
+                COEF[ro.slot] = __builtin_fma(-rho_l, t, al_l);
+                COEF[mem + ro.slot] = -(hgamma * al_l);
+            }
+        }
+        wave_sync();
+        double a0 = 0.0, a1 = 0.0;
+        if (CRT) {
+#pragma unroll
+            for (int tt = 0; tt < CRT; ++tt) {
+                const double cf = COEF[g2a * CRT + tt];
+                a0 = __builtin_fma(cf, mq[tt].x, a0); a1 = __builtin_fma(cf, mq[tt].y, a1);
+            }
+        } else {
+            for (int tt = 0; tt < D.CR; ++tt) {
+                const int r2 = g2a * D.CR + tt;
+                const double2 mv = mcol[(r2 <= D.R ? tt : 0) * N];  // rows beyond the zero row do not exist: their coefficient is 0
+                const double cf = COEF[r2];
+                a0 = __builtin_fma(cf, mv.x, a0); a1 = __builtin_fma(cf, mv.y, a1);
+            }
+        }
+        // the partials of groups 1.. travel through the scratch that held the pass-1 operands
+        double2* P2 = reinterpret_cast<double2*>(m.XA);
+        if (g2 >= 1 && g2 < D.G2) P2[(g2 - 1) * N + k2] = make_double2(a0, a1);
+        wave_sync();
+        double d0 = 0.0, d1 = 0.0;
+        if (vl) {
+            d0 = __builtin_fma(hgamma, rv, a0); d1 = __builtin_fma(hgamma, rw, a1);
+            for (int i = 1; i < D.G2; ++i) { const double2 q = P2[(i - 1) * N + lane]; d0 += q.x; d1 += q.y; }
+        }
+        dv = d0; dw = d1;
+    }
+};
+
+// How H * (gamma fpr) is evaluated: 1 = Gram form (PanocLbfgsGram, round 3), 0 = two-loop recursion (PanocLbfgs; the build
+// `make variants` keeps as libmpcgpu_twoloop.so for A/B runs).  Two problems per wavefront (Duo) always take the two-loop form.
+#ifndef MPC_LBFGS_GRAM
+#define MPC_LBFGS_GRAM 1
+#endif
+template <bool DUO> struct LbfgsOf { using type = PanocLbfgsGram; };
+template <> struct LbfgsOf<true> { using type = PanocLbfgs; };
+#if !MPC_LBFGS_GRAM
+template <> struct LbfgsOf<false> { using type = PanocLbfgs; };
+#endif
+// compile-time L-BFGS memory of the kernels with a compile-time horizon (the launcher sends other memories to the generic kernel)
+template <int NT> struct MemOf { static constexpr int value = NT ? 10 : 0; };
 
 // ALM / PM outer step: y+ <- y + c (F1(u) - Proj_C(F1(u) + y/c)); ||y+ - y||
 template <class P>
@@ -1272,14 +1575,19 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
     // L-BFGS memory S, Y [mem][N][2]: in LDS (LBG = false) or in this problem's workspace record, i.e. in the
     // L2-resident HBM workspace (LBG = true: 6.4 KB less LDS per wavefront -> more resident wavefronts; the pairs are
     // streamed once per PANOC iteration, one pair ahead of the dot product that consumes them)
-    double* LS = LBG ? io.ws + (size_t)b * kp.ws_stride + kp.ws_lbs : lds + kp.l_S;
-    double* LY = LBG ? io.ws + (size_t)b * kp.ws_stride + kp.ws_lby : lds + kp.l_Y;
-    double* LRHO = lds + kp.l_rho;  // [mem]
-    double* LALPHA = lds + kp.l_alpha;
+    constexpr int MEMT = MemOf<NT>::value;
+    LbMem lm;
+    lm.LM = LBG ? io.ws + (size_t)b * kp.ws_stride + kp.ws_lbs : lds + kp.l_S;  // [S; Y], contiguous in both layouts
+    lm.LRHO = lds + kp.l_rho;  // [mem]
+    lm.LALPHA = lds + kp.l_alpha;
     // [N][4]: L-BFGS old state (u) and old g (gamma*fpr); read and written once per PANOC iteration by its own lane.
     // It follows S and Y into the workspace record (measured: keeping it in LDS when it still fits is no faster for the
     // benchmark batch and slower for small batches and for N = 40).
-    double* LOLD = LBG ? io.ws + (size_t)b * kp.ws_stride + kp.ws_lold : lds + kp.l_old;
+    lm.LOLD = LBG ? io.ws + (size_t)b * kp.ws_stride + kp.ws_lold : lds + kp.l_old;
+    lm.GG = lds + kp.l_gg;
+    lm.XA = cx.pos;  // scratch between two evaluations: positions + stash are dead there
+    // pass 2 of the Gram form multiplies EVERY row by its coefficient (0 for the slots that hold no pair): the rows must be finite
+    for (int i = lane; i < (2 * mem + 1) * N; i += P::W) reinterpret_cast<double2*>(lm.LM)[i] = make_double2(0.0, 0.0);
     const bool vl = cx.vl;
     const int MAX_LIP_IT = 10, MAX_LS_IT = 10;
 
@@ -1303,7 +1611,7 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
     double akkt_tol = kp.init_tol;
     int iter = 0, num_iter = 0, lip_it = 0, nls = 0;
     bool cont_iters = true, cont_time = true;
-    PanocLbfgs lb;
+    typename LbfgsOf<P::DUO>::type lb;
     // ALM cache
     int alm_iteration = 0, num_outer = 1, inner_total = 0, status = 0;
     double dy_norm = 0, dy_norm_plus = 0, f2_norm = 0, f2_norm_plus = 0, last_fpr = 0, f_final = 0;
@@ -1361,7 +1669,8 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
             tr_psi_u = cost;
 #endif
             // ---- L-BFGS buffer update with (state = u, g = gamma*fpr)
-            lb.template update<P>(cx, vl, lane, N, mem, uv, uw, rv_, rw_, nfpr, LS, LY, LOLD, LRHO);
+            double lb_pr = 0.0;  // products of the rows of [S; Y] with gamma*fpr (Gram form): from update() to direction()
+            lb.template update<P, NT, MEMT>(cx, kp, vl, lane, uv, uw, rv_, rw_, nfpr, lm, lb_pr);
             wave_sync();
             if (iter == 0) {
                 // first iteration: no line search, u <- u_half
@@ -1369,7 +1678,7 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
                 ev = uv; ew = uw; want_grad = true; state = ST_NOLS;
                 continue;
             }
-            lb.template direction<P, LBG>(vl, lane, N, mem, rv_, rw_, LS, LY, LRHO, LALPHA, dv, dw);
+            lb.template direction<P, NT, MEMT, LBG>(cx, kp, vl, lane, rv_, rw_, lm, lb_pr, dv, dw);
             // ---- line search on the forward-backward envelope
             rhs = P::uni(panoc_fbe_rhs(cost, gamma, ig, gg, d2h, sigma, nfpr));
             tau = 1.0; nls = 0;

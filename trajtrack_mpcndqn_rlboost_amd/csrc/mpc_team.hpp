@@ -66,11 +66,15 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
         for (int i = threadIdx.x; i < cx.Kd * N * DYNW; i += T) cx.dyn[i] = ws[kp.ws_dyn + i];
     }
     __syncthreads();
-    double* LS = mine + kp.l_S;
-    double* LY = mine + kp.l_Y;
-    double* LRHO = mine + kp.l_rho;
-    double* LALPHA = mine + kp.l_alpha;
-    double* LOLD = mine + kp.l_old;
+    constexpr int MEMT = MemOf<NT>::value;
+    LbMem lm;
+    lm.LM = mine + kp.l_S;  // [S; Y] contiguous
+    lm.LRHO = mine + kp.l_rho;
+    lm.LALPHA = mine + kp.l_alpha;
+    lm.LOLD = mine + kp.l_old;
+    lm.GG = mine + kp.l_gg;
+    lm.XA = cx.pos;
+    for (int i = lane; i < (2 * mem + 1) * N; i += WAVE) reinterpret_cast<double2*>(lm.LM)[i] = make_double2(0.0, 0.0);
     double* XF = lds + kp.l_xch;                          // [TEAM_WAVES][TEAM_XCH]: per-wavefront verdicts of a pass
     double* XV = XF + TEAM_WAVES * TEAM_XCH;              // [N][6] + 4: the winner's point, gradient, half step and scalars
     const bool vl = cx.vl;
@@ -89,9 +93,9 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
     double gv = 0, gw = 0, hv = 0, hw = 0, rv_ = 0, rw_ = 0, dv = 0, dw = 0;
     double gamma = 0, ig = 0, Lip = 0, sigma = 0, cost = 0, nfpr = 0, rhs = 0, nh = 1, gg = 0, d2h = 0, ip = 0;
     double akkt_tol = kp.init_tol;
-    int iter = 0, num_iter = 0, lip_it = 0, nls = 0, t0 = 0;
+    int iter = 0, num_iter = 0, lip_it = 0, nls = 0, t0 = 0, head_spec = 0;
     bool cont_iters = true, cont_time = true;
-    PanocLbfgs lb;
+    typename LbfgsOf<false>::type lb;
     int alm_iteration = 0, num_outer = 1, inner_total = 0, status = 0;
     double dy_norm = 0, dy_norm_plus = 0, f2_norm = 0, f2_norm_plus = 0, last_fpr = 0, f_final = 0;
     int n_eval = 0, n_eval_grad = 0;  // evaluations of the SEQUENTIAL algorithm (the speculative ones are not counted)
@@ -169,7 +173,8 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
                 continue;
             }
             sigma = uniform(KC(K_SIGMA) * ig);
-            lb.template update<P>(cx, vl, lane, N, mem, uv, uw, rv_, rw_, nfpr, LS, LY, LOLD, LRHO);
+            double lb_pr = 0.0;
+            lb.template update<P, NT, MEMT>(cx, kp, vl, lane, uv, uw, rv_, rw_, nfpr, lm, lb_pr);
             wave_sync();
             if (state == TS_FIRST) {
                 // no line search on the first step: u <- u_half, whose psi and gradient were just evaluated
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
                 ++iter;
                 step_begin = true;
             } else {
-                lb.template direction<P, true>(vl, lane, N, mem, rv_, rw_, LS, LY, LRHO, LALPHA, dv, dw);
+                lb.template direction<P, NT, MEMT, true>(cx, kp, vl, lane, rv_, rw_, lm, lb_pr, dv, dw);
                 rhs = panoc_fbe_rhs(cost, gamma, ig, gg, d2h, sigma, nfpr);
                 t0 = 0;
                 trial_point(exp2(-(double)(t0 + wid)));
@@ -200,8 +205,11 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
             publish(flag, all);
             ++n_eval;
             if (all[0] != 0.0) {
-                // Lipschitz test failed: the speculative pair and direction are void (the buffer is flushed)
+                // Lipschitz test failed: the speculative pair and direction are void (the buffer is flushed).  The ring position
+                // goes back as well: the Gram form sums the rows in slot order, so the bits depend on where the ring stands, and
+                // the one-wavefront kernel never stored this pair.
                 lb.flush();
+                lb.head = head_spec;
                 panoc_lip_update<P>(kp, vl, uv, uw, gv, gw, Lip, gamma, ig, hv, hw, rv_, rw_, d2h, nfpr, ip);
                 ++lip_it;
                 ev = hv; ew = hw; want_grad = false; state = TS_LIPSEQ;
@@ -315,9 +323,11 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
                     } else {
                         // speculation: pair update and direction before the Lipschitz test is known
                         sigma = uniform(KC(K_SIGMA) * ig);
-                        lb.template update<P>(cx, vl, lane, N, mem, uv, uw, rv_, rw_, nfpr, LS, LY, LOLD, LRHO);
+                        head_spec = lb.head;
+                        double lb_pr = 0.0;
+                        lb.template update<P, NT, MEMT>(cx, kp, vl, lane, uv, uw, rv_, rw_, nfpr, lm, lb_pr);
                         wave_sync();
-                        lb.template direction<P, true>(vl, lane, N, mem, rv_, rw_, LS, LY, LRHO, LALPHA, dv, dw);
+                        lb.template direction<P, NT, MEMT, true>(cx, kp, vl, lane, rv_, rw_, lm, lb_pr, dv, dw);
                         rhs = panoc_fbe_rhs(cost, gamma, ig, gg, d2h, sigma, nfpr);
                         if (wid == 0) { ev = hv; ew = hw; want_grad = false; }
                         else { trial_point(exp2(-(double)(wid - 1))); want_grad = true; }

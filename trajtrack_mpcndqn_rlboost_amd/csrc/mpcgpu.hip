@@ -97,7 +97,10 @@ inline int even(int x) { return (x + 1) & ~1; }
 // instructions per solve, but 219 VGPRs and two LDS carves leave 2 wavefronts per SIMD and the kernel turns latency bound;
 // DESIGN.md section 7), so the automatic rule keeps one problem per wavefront and the layout stays an explicit option.
 // The choice never depends on the batch: results must not change with the batch a problem travels in.
-inline bool duo_available(const Handle* h) { return h->kp.N == 20; }
+// The kernels with a compile-time horizon (N_hor = 20, 40: the reference's yaml files) also fix the L-BFGS memory at the
+// reference's 10 (mpc_kernels.hpp MemOf); every other configuration runs the generic kernel.
+inline int compiled_horizon(const Handle* h) { return (h->kp.N == 20 || h->kp.N == 40) && h->kp.mem == 10 ? h->kp.N : 0; }
+inline bool duo_available(const Handle* h) { return compiled_horizon(h) == 20; }
 inline bool use_duo(const Handle* h) { return duo_available(h) && h->pairing == 1; }
 
 // Where the L-BFGS memory (2 x 10 x 2N doubles per problem) lives.  true: in the problem's workspace record (HBM,
@@ -144,8 +147,33 @@ void fill_static_params(Handle* h) {
     k.ws_alpha = o; o += even(c.Ndynobs);
     k.ws_lbs = o; o += c.lbfgs_mem * N * 2;   // L-BFGS memory when it is kept in the workspace (see LBFGS_IN_WORKSPACE)
     k.ws_lby = o; o += c.lbfgs_mem * N * 2;
+    o += N * 2;                               // one row of zeros behind [S; Y] (Gram form: padded row of pass 2)
     k.ws_lold = o; o += N * 4;
     k.ws_stride = (o + 15) & ~15;
+}
+
+// Item-lane partials (eval_point): every item lane beyond the vector lanes parks 5 doubles.  With a compiled horizon that nearly
+// divides the wavefront (N_hor = 20: 60 item lanes) the split is uniform and the last lanes idle -- the rule of eval_point.
+int part_doubles(const KParams& k) {
+    const int N = k.N;
+    const bool compiled = (N == 20 || N == 40) && k.mem == 10;
+    const bool uniform = compiled && (WAVE % N) * 5 <= N;
+    const int item_lanes = uniform ? (WAVE / N) * N : WAVE;
+    return (item_lanes - N) * PARTW;
+}
+// The stash (6 doubles per step) and the positions before it are dead between two evaluations; the Gram form of the L-BFGS step
+// uses them as scratch there: the operands of pass 1 ((r, s, y) pairs of every chunk slot) followed by the row coefficients.
+int stash_doubles(const KParams& k) {
+    const int N = k.N;
+    int need = N * 6;
+    if (MPC_LBFGS_GRAM) {
+        const int R = 2 * k.mem, G = (WAVE / 2) / k.mem, CL = (N + G - 1) / G, G2 = WAVE / N, CR = (R + G2 - 1) / G2;
+        int scratch = even(G * CL * 4) + even(G2 * CR);      // pass-1 operands (r, y) + row coefficients
+        const int p2 = (G2 - 1) * N * 2;                      // partials of pass 2 (they reuse the operand area)
+        if (p2 > scratch) scratch = p2;
+        if (scratch - N * 2 > need) need = scratch - N * 2;
+    }
+    return need;
 }
 
 // LDS carve for the batch maxima (doubles; every offset even => 16-byte aligned).
@@ -167,20 +195,23 @@ void fill_lds_layout(KParams& k, int mKs, int mKf, int mKd, bool shape_const, bo
         k.l_dync = k.l_dyn; k.l_qd = k.l_dyn;
     }
     k.l_pos = o; o += N * 2;
-    k.l_stash = o; o += N * 6;
+    k.l_stash = o; o += stash_doubles(k);
     k.l_hd = o; o += 64;
     // H (hinge matrix, read right after it is written) and the item-lane partials are never live together:
     // LDS operations of the single wave execute in order, so they share one region
-    const int h_sz = even(mKd * N) + even(mKd), part_sz = WAVE * PARTW;
+    const int h_sz = even(mKd * N) + even(mKd), part_sz = part_doubles(k);
     k.l_H = o; k.l_W = o + even(mKd * N); k.l_part = o;
     o += h_sz > part_sz ? h_sz : part_sz;
     k.l_S = k.l_Y = o;
     if (lbfgs_in_lds) {
         k.l_S = o; o += k.mem * N * 2;
-        k.l_Y = o; o += k.mem * N * 2;
+        k.l_Y = o; o += k.mem * N * 2 + N * 2;  // + the zero row
     }
     k.l_rho = o; o += even(k.mem);
-    k.l_alpha = o; o += even(k.mem);
+    k.l_alpha = o;
+    k.l_gg = o;
+    if (MPC_LBFGS_GRAM) o += 2 * k.mem * k.mem;  // Gram matrices s_i.y_j, y_i.y_j (the alpha scratch of the two-loop form is not needed)
+    else o += even(k.mem);
     k.l_old = o;
     if (lbfgs_in_lds) o += N * 4;
     k.l_total = o;
@@ -202,14 +233,16 @@ void fill_lds_layout(KParams& k, int mKs, int mKf, int mKd, bool shape_const, bo
     k.l_xch = o; o += TEAM_WAVES * TEAM_XCH + even(N * 6 + 4);
     const int base = o;
     k.l_pos = o; o += N * 2;
-    k.l_stash = o; o += N * 6;
-    const int h_sz = even(k.mKd * N) + even(k.mKd), part_sz = WAVE * PARTW;
+    k.l_stash = o; o += stash_doubles(k);
+    const int h_sz = even(k.mKd * N) + even(k.mKd), part_sz = part_doubles(k);
     k.l_H = o; k.l_W = o + even(k.mKd * N); k.l_part = o;
     o += h_sz > part_sz ? h_sz : part_sz;
     k.l_S = o; o += k.mem * N * 2;
-    k.l_Y = o; o += k.mem * N * 2;
+    k.l_Y = o; o += k.mem * N * 2 + N * 2;  // + the zero row
     k.l_rho = o; o += even(k.mem);
-    k.l_alpha = o; o += even(k.mem);
+    k.l_alpha = o;
+    k.l_gg = o;
+    if (MPC_LBFGS_GRAM) o += 2 * k.mem * k.mem; else o += even(k.mem);
     k.l_old = o; o += N * 4;
     k.l_wstride = even(o - base);
     k.l_total = base + TEAM_WAVES * k.l_wstride;
@@ -378,7 +411,7 @@ int32_t mpcgpu_solve_batch_dev(void* handle, int32_t B, const double* p, const d
             HIP_OK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t)); \
         hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE * TEAM_WAVES), lds_t, s, kt, io, B);                             \
     } while (0)
-            switch (h->kp.N) {
+            switch (compiled_horizon(h)) {
                 case 20: LAUNCH_TEAM(20); break;
                 case 40: LAUNCH_TEAM(40); break;
                 default: LAUNCH_TEAM(0); break;
@@ -433,7 +466,7 @@ int32_t mpcgpu_solve_batch_dev(void* handle, int32_t B, const double* p, const d
 #define LAUNCH_PAIR(NT, SC) LAUNCH_PAIR_W(NT, SC, MPC_MIN_WAVES)
     const bool sc = h->shape_const;
     const bool four = MPC_TRY_FOUR_WAVES && lds <= 10 * 1024 && B > 4 * MPC_MIN_WAVES * h->num_cus;
-    h->last_min_waves = four && h->kp.N == 20 ? 4 : MPC_MIN_WAVES;
+    h->last_min_waves = four && compiled_horizon(h) == 20 ? 4 : MPC_MIN_WAVES;
 #define LAUNCH_DUO(NT, SC)                                                                                          \
     do {                                                                                                             \
         auto kern = solve_kernel_duo<NT, SC, LBFGS_IN_WORKSPACE>;                                                    \
@@ -445,7 +478,7 @@ int32_t mpcgpu_solve_batch_dev(void* handle, int32_t B, const double* p, const d
         h->last_min_waves = 2;
         if (sc) LAUNCH_DUO(20, true); else LAUNCH_DUO(20, false);
     } else
-    switch (h->kp.N) {
+    switch (compiled_horizon(h)) {
         case 20:
             if (four) { if (sc) LAUNCH_PAIR_W(20, true, 4); else LAUNCH_PAIR_W(20, false, 4); }
             else if (sc) LAUNCH_PAIR(20, true); else LAUNCH_PAIR(20, false);
@@ -549,13 +582,13 @@ int32_t mpcgpu_cost_grad_batch(void* handle, int32_t B, const double* u, const d
         if (h->shape_const) LAUNCH_CG(20, true, Duo<20>, (B + 1) / 2, 2 * lds_cg);
         else LAUNCH_CG(20, false, Duo<20>, (B + 1) / 2, 2 * lds_cg);
     } else if (h->shape_const) {
-        switch (h->kp.N) {
+        switch (compiled_horizon(h)) {
             case 20: LAUNCH_CG1(20, true); break;
             case 40: LAUNCH_CG1(40, true); break;
             default: LAUNCH_CG1(0, true); break;
         }
     } else {
-        switch (h->kp.N) {
+        switch (compiled_horizon(h)) {
             case 20: LAUNCH_CG1(20, false); break;
             case 40: LAUNCH_CG1(40, false); break;
             default: LAUNCH_CG1(0, false); break;
