@@ -5,12 +5,15 @@
 
 A step = one pass of the hot path over one batch: B independent cold-start solves (u0 = 0, what every
 reference call site does: src/interface_mpc.py:82 passes initial_guess=None) of the metric configuration
-named in BASELINE.json -- mpc_default.yaml, N_hor = 20, 8 dynamic obstacles -- on B = 131072 robots per GPU,
-with the parameter vectors already resident in HBM.  (A solve takes 0.1-0.2 s of device time and 4096 run
-concurrently; the last problems of a launch finish on a draining GPU, which costs about 0.12 s per launch whatever
-the batch: measured 24.3 / 27.2 / 28.3 / 29.1 thousand solves/s at B = 16384 / 32768 / 65536 / 131072
-(profiles/r02_batch_scaling.txt; round 1 benchmarked B = 32768: 25.2 thousand then, 27.2 thousand now).  `--batch` selects
-other sizes.)
+named in BASELINE.json -- mpc_default.yaml, N_hor = 20, 8 dynamic obstacles -- on B = 131072 robots per GPU
+(`--batch`; BASELINE.json prescribes no batch, SURVEY.md 8(d) words the metric at 8192 per GPU), with the
+parameter vectors already resident in HBM.  A solve takes 0.1-0.2 s of device time and 4096 run concurrently; the
+last problems of a launch finish on a draining GPU, which costs about 0.1 s per launch whatever the batch.  The
+headline `value` is the plain leg: K launches of the whole shard, one after the other on one stream, each timed by
+HIP events (that duration feeds `roofline`).  `config.batch_sweep` repeats the same workload at the reference
+batches 32768 (round 1's bench batch) and 8192 (the metric batch), the latter also PIPELINED: two half shards on
+two handles / two streams, every launch enqueued without a host synchronisation (mpcgpu_reserve_shape), so that
+the next launch fills the GPU while the previous one drains -- the tail is then paid once per K steps.
 
 Multi-GPU (N > 1): one process per GPU; the batch shards across ranks with no data-path collective (weak
 scaling: every rank owns its own B robots); RCCL is used only for the barrier, the max-over-ranks time and
@@ -23,14 +26,16 @@ child's code.  It exits non-zero when fewer than N devices are present, and when
 
 Rank 0 prints ONE JSON line (contract in the task description) with extra objects:
   roofline      -- dominant kernel (solve_kernel) against the HBM roofline, timed with HIP events on the launch
-                   stream; `secondary` is the bound that actually binds (VALU issue), `flops` the executed f64
-                   flop rate from the in-kernel evaluation counters; PMC-derived fields come from
-                   profiles/r02_roofline_bench.json and are used ONLY when that file was collected on this very
-                   workload (tools/roofline.py rebuilds it from the raw rocprofv3 CSVs).
+                   stream IN THIS RUN; `flops` is the executed f64 flop rate from the in-kernel evaluation counters
+                   of this run.  Everything that comes from a rocprofv3 PMC pass (`traffic`, `secondary`) is read
+                   from profiles/r03_roofline_bench.json -- collected on this very workload, rebuilt from the raw
+                   CSVs by tools/roofline.py -- and is marked `measured_in_run: false`.
   config.convergent -- the same step on the "passing" scene family (same N, obstacle counts and batch; a
-                   collision-free plan exists), where most solves converge: the headline family is the one
-                   SURVEY.md 8(d) prescribes and it is cap-limited (see status_histogram).
-  cpu_baseline  -- the oracle (plain-C restatement, "port") on the host cores, on a bounded sample.
+                   collision-free plan exists), where about half of the solves converge: the headline family is the
+                   one SURVEY.md 8(d) prescribes and it is cap-limited (see status_histogram).
+  config.batch_sweep -- see above.
+  cpu_baseline  -- the oracle (plain-C restatement, "port") on the host cores this process may use, on a bounded
+                   sample.
 """
 from __future__ import annotations
 
@@ -50,7 +55,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VECTOR_PEAK_TF = 78.6   # MI355X vector FP64: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
-ROOFLINE_JSON = os.path.join(ROOT, "profiles", "r02_roofline_bench.json")
+ROOFLINE_JSON = os.path.join(ROOT, "profiles", "r03_roofline_bench.json")
+SWEEP_BATCHES = (32768, 8192)   # reference batches reported next to the headline (round 1's bench batch; SURVEY.md 8(d)'s metric batch)
 
 
 def shard(total: int, rank: int, world: int):
@@ -70,6 +76,7 @@ def parse_args(argv=None):
     ap.add_argument("--horizon", type=int, default=20)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 disables)")
     ap.add_argument("--no-convergent", action="store_true", help="skip the second leg (profiling runs)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the reference-batch legs (profiling runs)")
     return ap.parse_args(argv)
 
 
@@ -115,6 +122,12 @@ class StubSolver:
     def last_shape(self):
         return dict(max_static=0, max_fleet=0, max_dyn=0, lds_bytes=0, waves_per_simd=0)
 
+    def reserve_shape(self, **kw):
+        pass
+
+    def reserve_batch(self, B):
+        pass
+
 
 def main():
     args = parse_args()
@@ -157,17 +170,22 @@ def main():
 
     cfg = MpcConfig(N_hor=args.horizon)
     N, B = cfg.N_hor, args.batch
-    if stub:
-        solver = StubSolver(cfg)
-    else:
+
+    def new_solver():
+        if stub:
+            return StubSolver(cfg)
         from trajtrack_mpcndqn_rlboost_amd import BatchSolver
-        solver = BatchSolver(cfg, device=dev_index)
-    out = dict(u=torch.empty(B, 2 * N, dtype=torch.float64, device=dev),
-               cost=torch.empty(B, dtype=torch.float64, device=dev),
-               status=torch.empty(B, dtype=torch.int32, device=dev),
-               inner_it=torch.empty(B, dtype=torch.int32, device=dev),
-               outer_it=torch.empty(B, dtype=torch.int32, device=dev),
-               f2norm=torch.empty(B, dtype=torch.float64, device=dev))
+        return BatchSolver(cfg, device=dev_index)
+
+    def new_out(b):
+        return dict(u=torch.empty(b, 2 * N, dtype=torch.float64, device=dev),
+                    cost=torch.empty(b, dtype=torch.float64, device=dev),
+                    status=torch.empty(b, dtype=torch.int32, device=dev),
+                    inner_it=torch.empty(b, dtype=torch.int32, device=dev),
+                    outer_it=torch.empty(b, dtype=torch.int32, device=dev),
+                    f2norm=torch.empty(b, dtype=torch.float64, device=dev))
+    solver = new_solver()
+    out = new_out(B)
     stream = None if stub else torch.cuda.current_stream().cuda_stream
 
     def barrier():
@@ -176,24 +194,71 @@ def main():
         if not stub:
             torch.cuda.synchronize()
 
-    def timed_leg(p, steps, warmup):
-        """W untimed + K timed passes over the batch `p`; returns the per-rank elapsed time (max over ranks is taken by
-        the caller), the mean kernel times and the per-problem outcome of the last pass."""
-        for _ in range(warmup):
-            solver.solve_device(p, out, stream=stream)
+    def reserve_like_last(sv, b):
+        """After one automatic call (count read-back): promise exactly the shape it found, so that the timed launches read
+        nothing back -- the same kernel instantiation, no host synchronisation between the compaction and the solve."""
+        sh = sv.last_shape()
+        sv.reserve_shape(max_static=sh["max_static"], max_fleet=sh["max_fleet"], max_dyn=sh["max_dyn"],
+                         var_shape=not sh.get("shape_const", False), axis_aligned=sh.get("axis_aligned", False))
+        sv.reserve_batch(b)
+
+    def timed_leg(p, steps, warmup, sv=None, o=None):
+        """W untimed + K timed passes over the batch `p`, one launch after the other; returns the per-rank elapsed time (max
+        over ranks is taken by the caller), the mean kernel times and the per-problem outcome of the last pass."""
+        sv = sv or solver
+        o = o or out
+        b = int(p.shape[0])
+        sv.release_shape() if hasattr(sv, "release_shape") else None
+        sv.solve_device(p, o, stream=stream)          # automatic rule: finds the batch's shape
+        reserve_like_last(sv, b)
+        for _ in range(max(warmup - 1, 0)):
+            sv.solve_device(p, o, stream=stream)
         barrier()
         k_ms, p_ms = [], []
         t0 = time.perf_counter()
         for _ in range(steps):
-            solver.solve_device(p, out, stream=stream)
-            t = solver.last_timing()          # HIP events recorded on `stream` around the two kernels
+            sv.solve_device(p, o, stream=stream)
+            t = sv.last_timing()          # HIP events recorded on `stream` around the two kernels
             k_ms.append(t["solve_ms"]); p_ms.append(t["prep_ms"])
         barrier()
         mine = time.perf_counter() - t0
-        n_psi, n_grad = solver.last_eval_counts(B, stream)
+        n_psi, n_grad = sv.last_eval_counts(b, stream)
         return dict(elapsed=mine, kernel_ms=float(np.mean(k_ms)), prep_ms=float(np.mean(p_ms)),
-                    status=out["status"].cpu().numpy().copy(), inner=out["inner_it"].cpu().numpy().copy(),
+                    status=o["status"].cpu().numpy().copy(), inner=o["inner_it"].cpu().numpy().copy(),
                     n_psi=n_psi, n_grad=n_grad)
+
+    def pipelined_leg(p, steps, warmup):
+        """The same K passes with the batch split into two half shards on two handles and two streams; nothing is read back
+        and nothing waits on the host inside the timed region, so launch k + 1 of one stream fills the compute units that
+        launch k of the other stream is draining."""
+        b = int(p.shape[0])
+        halves = [p[: b // 2], p[b // 2:]]
+        svs = [new_solver(), new_solver()]
+        outs = [new_out(int(h.shape[0])) for h in halves]
+        if stub:
+            streams = [None, None]
+        else:
+            ts = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+            streams = [t.cuda_stream for t in ts]
+        for sv, h, o, st in zip(svs, halves, outs, streams):
+            sv.solve_device(h, o, stream=st)
+            if not stub:
+                torch.cuda.synchronize()
+            reserve_like_last(sv, int(h.shape[0]))
+        for _ in range(max(warmup - 1, 0)):
+            for sv, h, o, st in zip(svs, halves, outs, streams):
+                sv.solve_device(h, o, stream=st)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            for sv, h, o, st in zip(svs, halves, outs, streams):
+                sv.solve_device(h, o, stream=st)
+        barrier()
+        mine = time.perf_counter() - t0
+        status = np.concatenate([o["status"].cpu().numpy() for o in outs])
+        for sv in svs:
+            sv.close() if hasattr(sv, "close") else None
+        return dict(elapsed=mine, status=status)
 
     def over_ranks(x: float):
         """(max over ranks, list of every rank's value)."""
@@ -215,10 +280,37 @@ def main():
     if not args.no_convergent:
         scc = scenes.make_batch(cfg, B, n_dyn=args.n_dyn, seed=4321 + 7919 * rank, dyn_clearance=0.1, box_clearance=0.3)
         pc = torch.from_numpy(scc["p"]).to(dev)
-        cleg = timed_leg(pc, args.steps, args.warmup)
+        cleg = timed_leg(pc, min(args.steps, 5), min(args.warmup, 1))
         c_elapsed, _ = over_ranks(cleg["elapsed"])
-        conv = dict(leg=cleg, elapsed=c_elapsed)
+        conv = dict(leg=cleg, elapsed=c_elapsed, steps=min(args.steps, 5))
         del pc
+
+    # reference batches of the same workload (the first b problems of this rank's shard): plain launches, and -- for the
+    # metric batch -- the pipelined form.  Bounded step counts: these legs must not dominate the run.
+    sweep = []
+    if not args.no_sweep:
+        side_steps, side_warm = min(args.steps, 5), min(args.warmup, 1)
+        for b in SWEEP_BATCHES:
+            if b >= B:
+                continue
+            pb = p[:b].contiguous()
+            sv, ob = new_solver(), new_out(b)
+            sl = timed_leg(pb, side_steps, side_warm, sv, ob)
+            s_el, _ = over_ranks(sl["elapsed"])
+            item = {"batch_per_gpu": b, "steps": side_steps,
+                    "plain": {"value": world * b * side_steps / s_el, "unit": "solves/s", "ms_per_step": 1e3 * s_el / side_steps,
+                              "kernel_ms": sl["kernel_ms"], "status_histogram": np.bincount(sl["status"], minlength=3).tolist()}}
+            if hasattr(sv, "close"):
+                sv.close()
+            if b == SWEEP_BATCHES[-1]:
+                pl = pipelined_leg(pb, 4 * side_steps, side_warm)
+                p_el, _ = over_ranks(pl["elapsed"])
+                item["pipelined"] = {"value": world * b * 4 * side_steps / p_el, "unit": "solves/s", "steps": 4 * side_steps,
+                                     "ms_per_step": 1e3 * p_el / (4 * side_steps),
+                                     "status_histogram": np.bincount(pl["status"], minlength=3).tolist(),
+                                     "how": "two half shards, two handles, two streams; launches enqueued back to back "
+                                            "(reserved shape: no read-back, no host synchronisation inside the timed region)"}
+            sweep.append(item)
 
     if rank == 0:
         status, inner = leg["status"], leg["inner"]
@@ -245,7 +337,8 @@ def main():
             "per_rank_solves_per_s": [B * args.steps / t for t in per_rank_s],
             "config": {"workload": f"mpc_default.yaml N_hor={N}, {args.n_dyn} dynamic obstacles (r=1.6 m discs crossing "
                                    "the path, SURVEY.md 8(d)), 5 static boxes, cold start u0=0, "
-                                   f"batch={B} robots per GPU (BASELINE.json metric configuration)",
+                                   f"batch={B} robots per GPU; K plain launches on one stream (see batch_sweep for the reference "
+                                   "batches 32768 and 8192 and the pipelined form)",
                        "batch_per_gpu": B, "N_hor": N, "n_dyn": args.n_dyn, "parallelism": f"shard{world}",
                        "mean_inner_iterations": float(inner.mean()),
                        "mean_psi_evaluations": float(n_psi.mean()), "mean_grad_evaluations": float(n_grad.mean()),
@@ -260,12 +353,15 @@ def main():
             line["config"]["convergent"] = {
                 "workload": "same N_hor, obstacle counts and batch; 'passing' family (scenes.make_batch dyn_clearance=0.1, "
                             "box_clearance=0.3): discs and box beside the path, a collision-free plan exists",
-                "value": world * B * args.steps / conv["elapsed"], "unit": "solves/s",
-                "ms_per_step": 1e3 * conv["elapsed"] / args.steps, "kernel_ms": cl["kernel_ms"],
+                "value": world * B * conv["steps"] / conv["elapsed"], "unit": "solves/s", "steps": conv["steps"],
+                "ms_per_step": 1e3 * conv["elapsed"] / conv["steps"], "kernel_ms": cl["kernel_ms"],
                 "status_histogram": np.bincount(cl["status"], minlength=3).tolist(),
                 "converged_fraction": float((cl["status"] == 0).mean()),
                 "mean_inner_iterations": float(cl["inner"].mean()),
-                "mean_psi_evaluations": float(cl["n_psi"].mean())}
+                "mean_psi_evaluations": float(cl["n_psi"].mean()),
+                "converged_solves_per_s": world * int((cl["status"] == 0).sum()) * conv["steps"] / conv["elapsed"]}
+        if sweep:
+            line["config"]["batch_sweep"] = sweep
         if not stub:
             from tools.roofline import flops_per_solve_kernel_launch, load_pmc_for
             pmc = load_pmc_for(ROOFLINE_JSON, N, args.n_dyn, B)
@@ -276,24 +372,29 @@ def main():
                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
                     "kernel": "solve_kernel", "kernel_ms": k_ms, "prep_kernel_ms": leg["prep_ms"],
                     "algorithmic_bytes_per_solve": algo_bytes // B,
+                    "measured_in_run": {"achieved": True, "kernel_ms": True, "frac": True, "flops": True,
+                                        "traffic": False, "wasted_traffic_ratio": False, "traffic_GBps": False,
+                                        "secondary": False},
                     "wasted_traffic_ratio": (pmc["traffic_bytes_per_launch"] / algo_bytes) if pmc else None,
+                    "traffic_GBps": (pmc["traffic_bytes_per_launch"] / (pmc["kernel_avg_ms_kernel_trace"] * 1e-3) / 1e9) if pmc else None,
+                    "traffic_source": (os.path.relpath(ROOFLINE_JSON, ROOT) + ": separate rocprofv3 --pmc passes on this "
+                                       "workload; NOT re-measured in this run") if pmc else None,
                     "note": "state is register/LDS/L2 resident: the kernel is VALU-issue bound (see secondary); traffic = "
                             "L2<->fabric bytes of the kernel's own cold state (L-BFGS ring, spill slots), DESIGN.md section 2",
                     "flops": {"bound": "valu_f64_flops", "achieved": tf, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s",
-                              "frac": tf / FP64_VECTOR_PEAK_TF,
+                              "frac": tf / FP64_VECTOR_PEAK_TF, "measured_in_run": True,
                               "source": "static f64-flop table per evaluation (tools/roofline.py: by horizon and active rows) "
                                         "x the in-kernel psi / grad evaluation counters of this run / this run's kernel time"},
                     "secondary": None}
             if pmc:
-                # VALU issue: instructions per launch from the PMC pass of this workload / THIS run's kernel time, against
+                # VALU issue: instructions per launch from the PMC pass of this workload over THAT pass's kernel time, against
                 # one wave64 instruction per 4 cycles per SIMD
-                peak_ips = 256 * 4 * pmc["clock_GHz"] * 1e9 / 4.0
-                ach_ips = pmc["valu_instructions_per_launch"] / (k_ms * 1e-3)
-                roof["secondary"] = {"bound": "valu_issue", "achieved": ach_ips / 1e9, "peak": peak_ips / 1e9,
-                                     "unit": "G wave-instructions/s", "frac": ach_ips / peak_ips,
+                roof["secondary"] = {"bound": "valu_issue", "measured_in_run": False,
+                                     "frac": pmc["valu_issue_frac_of_peak"],
                                      "valu_busy_frac_pmc": pmc["valu_busy_fraction"],
                                      "resident_waves_per_simd": pmc["resident_waves_per_simd"],
                                      "valu_instructions_per_solve": pmc["valu_instructions_per_launch"] / B,
+                                     "kernel_ms_of_the_pmc_pass": pmc["kernel_avg_ms_kernel_trace"],
                                      "source": os.path.relpath(ROOFLINE_JSON, ROOT)}
             line["roofline"] = roof
         if args.cpu_seconds > 0 and world == 1 and not stub:
@@ -304,12 +405,48 @@ def main():
         dist.destroy_process_group()
 
 
+def host_cores():
+    """What this process may use: scheduler affinity, cgroup CPU quota, and the SMT layout of the machine."""
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:                      # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = fh.read().split()
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, per = float(fq.read()), float(fp.read())
+                if q > 0:
+                    quota = q / per
+        except (OSError, ValueError):
+            pass
+    threads_per_core = None
+    try:
+        sib = cores = None
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.startswith("siblings") and sib is None:
+                    sib = int(ln.split(":")[1])
+                elif ln.startswith("cpu cores") and cores is None:
+                    cores = int(ln.split(":")[1])
+        if sib and cores:
+            threads_per_core = sib // cores
+    except (OSError, ValueError):
+        pass
+    usable = affinity if quota is None else max(1, min(affinity, int(quota + 0.5)))
+    return dict(logical_cpus=os.cpu_count() or 1, affinity=affinity, cgroup_quota_cpus=quota,
+                threads_per_core=threads_per_core, usable=usable)
+
+
 def cpu_baseline(cfg, p_all, budget_s):
-    """The oracle (C restatement of the same algorithm, kind = "port") on all host cores, on the first S
-    problems of the very same workload; S is calibrated so the run takes about `budget_s` seconds."""
+    """The oracle (C restatement of the same algorithm, kind = "port") on the host cores this process may use, on the
+    first S problems of the very same workload; S is calibrated so the run takes about `budget_s` seconds."""
     import oracle
     ocfg = oracle.OracleConfig.from_dict(cfg.solver_dict())
-    cores = os.cpu_count() or 1
+    hc = host_cores()
+    cores = hc["usable"]
     probe = min(len(p_all), max(cores, 32))
     t = time.perf_counter()
     oracle.solve_batch(ocfg, p_all[:probe], nthreads=cores)
@@ -320,7 +457,14 @@ def cpu_baseline(cfg, p_all, budget_s):
     t = time.perf_counter()
     _, _, res, used = oracle.solve_batch(ocfg, p_all[:S], nthreads=cores)
     dt = time.perf_counter() - t
+    smt = hc["threads_per_core"]
     return {"value": S / dt, "unit": "solves/s", "cores": used, "kind": "port",
+            "per_core_solves_per_s": S / dt / used,
+            "host": {"logical_cpus": hc["logical_cpus"], "sched_affinity": hc["affinity"],
+                     "cgroup_quota_cpus": hc["cgroup_quota_cpus"], "threads_per_core": smt,
+                     "note": (f"{used} OpenMP threads = the logical CPUs this process may use; "
+                              + (f"SMT-{smt}: {used // smt if smt else used} physical cores" if smt and smt > 1 else
+                                 "no SMT reported" if smt == 1 else "SMT layout unknown"))},
             "sample": f"first {S} problems of the same batch, OpenMP over problems, {dt:.1f} s wall, "
                       f"mean inner iterations {float(res['inner_iters'].mean()):.0f}"}
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MPCGPU_ABI_VERSION 3
+#define MPCGPU_ABI_VERSION 4
 
 /* replaces: the yaml config consumed by MpcModule.build (mpc_generator.py:151-158, config/mpc_default.yaml:7-55)
  * plus the SolverConfiguration of mpc_generator.py:285-293 (opengen defaults quoted there). */
@@ -102,7 +102,10 @@ int32_t mpcgpu_solve_batch(void* handle, int32_t B, const double* p, const doubl
  * enqueueing the solve kernel (synchronise the stream before reading results).  The LDS carve of the launch is sized
  * from the batch's active-row maxima: without a reservation (mpcgpu_reserve_shape) this call contains one small
  * device->host read of those counts and blocks until the compaction kernel has run; with a reservation nothing is
- * read back, the call never blocks and can be captured into a hipGraph. */
+ * read back and the call never blocks.  It can then be captured into a hipGraph, provided nothing has to be allocated or
+ * opted into inside the capture: size the library's buffers first (mpcgpu_reserve_batch, or one eager call with at least
+ * this batch size) -- a call that would have to grow a buffer or raise a kernel's LDS limit while `stream` is being
+ * captured fails with -6 and a message instead of breaking the capture. */
 int32_t mpcgpu_solve_batch_dev(void* handle, int32_t B, const double* p, const double* u0, const double* y0,
                                const double* c0, double* u, double* cost, int32_t* status, int32_t* inner_it,
                                int32_t* outer_it, double* fpr, double* f2norm, double* y_out, double* ms,
@@ -125,7 +128,8 @@ int32_t mpcgpu_last_timing(void* handle, double* prep_ms, double* solve_ms);
 /* Work counters of the last solve call, per problem: psi evaluations executed and how many of them also produced
  * grad psi (the counts OpEn's generated `cost` / `grad_cost` functions would see, minus the redundant re-evaluation of
  * psi(u) in the Lipschitz update; the latency kernel reports the counts of the SEQUENTIAL algorithm, not its speculative
- * evaluations).  Synchronises `stream` (the one the solve was enqueued on).  HOST output pointers. */
+ * evaluations).  Synchronises the stream the last solve was enqueued on (and `stream`, if it is another one).  HOST output
+ * pointers. */
 int32_t mpcgpu_last_eval_counts(void* handle, int32_t B, int32_t* n_psi, int32_t* n_grad, void* stream);
 
 /* Batch-wide maxima of active entries seen by the last solve / cost_grad call: static obstacles, fleet
@@ -137,13 +141,20 @@ int32_t mpcgpu_last_shape(void* handle, int32_t* max_static, int32_t* max_fleet,
 
 /*
  * Promise upper bounds on the ACTIVE (non-zero) static-obstacle, other-robot and dynamic-obstacle rows of every problem
- * of the following mpcgpu_solve_batch_dev calls, and whether a dynamic row may change (rx, ry, angle, alpha) over the
- * horizon (var_shape != 0).  The LDS carve is then taken from these bounds instead of a read-back (single-robot callers
+ * of the following mpcgpu_solve_batch_dev calls, and what is known about the dynamic rows: var_shape = 1: a row may change
+ * (rx, ry, angle, alpha) over the horizon (general tables); 0: every row keeps them (compact tables); 2: every row keeps them
+ * AND is axis-aligned (angle 0 -- what the reference's own prediction feeder produces, src/main.py:77-85: the kernel without
+ * the rotation into the ellipse frame, the same bits).  The LDS carve is then taken from these bounds instead of a read-back (single-robot callers
  * of the reference reserve the configured maxima: a lone wavefront does not care about the size of its carve).
  * A problem that exceeds the reservation is not solved: status = MPCGPU_SHAPE_EXCEEDED, cost = NaN, u = 0.
  * All three bounds negative = drop the reservation.  Results do not depend on the carve (bitwise).
  */
 int32_t mpcgpu_reserve_shape(void* handle, int32_t max_static, int32_t max_fleet, int32_t max_dyn, int32_t var_shape);
+
+/* Size the library-owned device buffers (workspace records, counters) for batches of up to B problems now, so that later
+ * mpcgpu_solve_batch_dev calls allocate nothing (required before a call is captured into a hipGraph; growth is otherwise
+ * automatic and drains the device first). */
+int32_t mpcgpu_reserve_batch(void* handle, int32_t B);
 
 /*
  * Solver options that are not part of the reference's yaml / SolverConfiguration surface.  They select between readings
@@ -176,6 +187,11 @@ int32_t mpcgpu_last_waves_per_simd(void* handle);
 
 /* 1 when the last solve call ran the latency kernel (MPCGPU_OPT_TEAM_BATCH), else 0. */
 int32_t mpcgpu_last_latency_kernel(void* handle);
+
+/* Dynamic-obstacle tables of the last solve / cost_grad launch, in the coding of mpcgpu_reserve_shape's var_shape: 1 general
+ * (some row changes shape over the horizon, or the latency kernel ran), 0 shape-constant, 2 shape-constant and axis-aligned.
+ * A caller that wants read-back-free launches of the same batches can reserve exactly what the automatic rule found. */
+int32_t mpcgpu_last_table_kind(void* handle);
 
 /* Problems per wavefront of the last solve / cost_grad launch: 1 or 2 (MPCGPU_OPT_PAIRING). */
 int32_t mpcgpu_last_problems_per_wavefront(void* handle);

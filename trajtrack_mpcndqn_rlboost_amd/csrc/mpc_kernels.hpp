@@ -66,7 +66,7 @@ constexpr int SEG_WIN = 2;     // reference segments per item lane that are eval
 enum { H_X0 = 0, H_Y0 = 1, H_TH0 = 2, H_XG = 3, H_YG = 4, H_THG = 5, H_VINIT = 6, H_WINIT = 7, H_QVEL = 9, H_RV = 11, H_RW = 12,
        H_QN = 13, H_QTHN = 14, H_QRPD = 15, H_ACC = 16, H_WACC = 17 };
 enum { H_KS = 18, H_KF = 19, H_KD = 20, H_CTH0 = 21, H_STH0 = 22, H_NPF = 23, H_NPD = 24, H_VAR = 25 /* 1: some dynamic row changes shape over the horizon */,
-       H_ENTRY = 26 /* .. +Ndynobs */ };
+       H_ENTRY = 26 /* .. +Ndynobs (<= 32) */, H_ROT = 60 /* 1: some active dynamic row is rotated (angle != 0) */ };
 // batch-wide reductions written by the compaction kernel
 enum { CNT_KS = 0, CNT_KF = 1, CNT_KD = 2, CNT_VARSHAPE = 3, CNT_ROTATED = 4 /* some active dynamic row is not an axis-aligned ellipse (angle != 0) */,
        CNT_WORDS = 8 };
@@ -493,6 +493,7 @@ __device__ __forceinline__ void prep_problem(const KParams& kp, const double* __
     const bool any_var = __ballot(varshape) != 0ull, any_rot = __ballot(rotated) != 0ull;
     if (lane == 0) {
         ws[H_KS] = (double)Ks; ws[H_KF] = (double)Kf; ws[H_KD] = (double)Kd; ws[H_VAR] = any_var ? 1.0 : 0.0;
+        ws[H_ROT] = any_rot ? 1.0 : 0.0;
         if (counts) {
             atomicMax(counts + CNT_KS, Ks);
             atomicMax(counts + CNT_KF, Kf);
@@ -1242,7 +1243,7 @@ struct PanocLbfgs {
     }
 };
 
-// The same buffer and the same operator H as PanocLbfgs, evaluated in GRAM FORM (round 3; oracle: lbfgs_apply_gram, mpc_oracle.c).
+// The same buffer and the same operator H as PanocLbfgs, evaluated in GRAM FORM (round 3; the CPU checker restates it as lbfgs_apply_gram).
 // The two-loop recursion is 2 mem DEPENDENT wave reductions, each waiting for a pair from L2 and using N of 64 lanes.  Here:
 //   pass 1  one matrix-vector pass [S; Y] x over all 64 lanes: lane (row, g) accumulates its share of row . x for
 //           x = gamma fpr and x = y_new (independent FMAs, no reduction; the G partials of a row sit in adjacent lanes);
@@ -1558,14 +1559,21 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
     // against it: a problem with more active rows than reserved must not touch the tables -- it is reported, not solved.
     if (kp.reserved) {
         const bool over = (int)P::uni(ws[H_KS]) > kp.mKs || (int)P::uni(ws[H_KF]) > kp.mKf || (int)P::uni(ws[H_KD]) > kp.mKd ||
-                          (SC && P::uni(ws[H_VAR]) != 0.0);
+                          (SC && P::uni(ws[H_VAR]) != 0.0) || (AXIS && P::uni(ws[H_ROT]) != 0.0);
         if (over) {
-            if (lane < N) { io.u[(size_t)b * 2 * N + 2 * lane] = 0.0; io.u[(size_t)b * 2 * N + 2 * lane + 1] = 0.0; }
+            const double nan = __builtin_nan("");
+            if (lane < N) {
+                io.u[(size_t)b * 2 * N + 2 * lane] = 0.0; io.u[(size_t)b * 2 * N + 2 * lane + 1] = 0.0;
+                if (io.y_out) { io.y_out[(size_t)b * 2 * N + lane] = nan; io.y_out[(size_t)b * 2 * N + N + lane] = nan; }
+            }
             if (lane == 0) {
-                io.cost[b] = __builtin_nan(""); io.status[b] = 4;
+                io.cost[b] = nan; io.status[b] = 4;
                 if (io.inner_it) io.inner_it[b] = 0;
                 if (io.outer_it) io.outer_it[b] = 0;
                 if (io.evals) { io.evals[2 * b] = 0; io.evals[2 * b + 1] = 0; }
+                if (io.fpr) io.fpr[b] = nan;         // every optional output is written: no stale value of an earlier call survives
+                if (io.f2norm) io.f2norm[b] = nan;
+                if (io.ms) io.ms[b] = 0.0;
             }
             return;
         }

@@ -109,10 +109,14 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
 #endif
 
     // verdicts of a pass: every wavefront publishes one flag, all read the four of them
+    // Two alternating flag banks (like the wall-clock slots below): with ONE barrier per call, a fast wavefront may already
+    // write its flag of pass k + 1 while a slow one still reads the four flags of pass k.
+    int pub_slot = 0;
     auto publish = [&](double flag, double* all) {
-        if (lane == 0) XF[wid * TEAM_XCH] = flag;
+        if (lane == 0) XF[wid * TEAM_XCH + pub_slot] = flag;
         __syncthreads();
-        for (int j = 0; j < TEAM_WAVES; ++j) all[j] = uniform(XF[j * TEAM_XCH]);
+        for (int j = 0; j < TEAM_WAVES; ++j) all[j] = uniform(XF[j * TEAM_XCH + pub_slot]);
+        pub_slot ^= 1;
     };
     // the winning wavefront hands over (point, gradient, half step; cost, ||grad||^2, ||gradient step - half step||^2)
     auto adopt = [&](int winner, double tcost, double tgg, double td2h, double thv, double thw) {

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <unordered_map>
 
 using namespace mpcgpu;
 
@@ -50,7 +51,9 @@ struct Handle {
     // mpcgpu_reserve_shape: upper bounds of active rows promised by the caller -> no count read-back before the launch
     bool capturing = false;  // the launch stream of the current call is being captured into a hipGraph: no event records
     bool reserved = false;
-    int res_shape[4] = {0, 0, 0, 0};  // max static, fleet, dynamic rows; 1 = dynamic rows may change shape over the horizon
+    int res_shape[4] = {0, 0, 0, 0};  // max static, fleet, dynamic rows; 0 = shape-constant rows, 1 = they may change shape, 2 = shape-constant AND axis-aligned
+    hipStream_t last_stream = nullptr;  // launch stream of the last solve (mpcgpu_last_eval_counts waits for it)
+    std::unordered_map<const void*, int> lds_attr;  // kernel -> largest dynamic-LDS size opted into (hipFuncSetAttribute once, not per launch)
 };
 
 int fail(Handle* h, int code, const char* fmt, ...) {
@@ -74,6 +77,9 @@ int fail(Handle* h, int code, const char* fmt, ...) {
 // spelled out because correctness depends on it).  Growth is geometric, so steady-state calls never get here.
 int ensure(Handle* h, DevBuf& b, size_t bytes) {
     if (bytes <= b.cap) return 0;
+    if (h->capturing)
+        return fail(h, -6, "a device buffer must grow to %zu bytes while the stream is being captured: call mpcgpu_reserve_batch "
+                           "(or run one eager call of at least this batch size) before the capture", bytes);
     if (b.ptr) {
         HIP_OK(h, hipDeviceSynchronize());
         HIP_OK(h, hipFree(b.ptr));
@@ -91,6 +97,24 @@ inline hipStream_t pick_stream(Handle* h, void* stream) {
 }
 
 inline int even(int x) { return (x + 1) & ~1; }
+
+// dynamic LDS beyond 64 KiB must be opted into per kernel: once per (handle, kernel, size), never inside a captured region
+int opt_in_lds(Handle* h, const void* kern, size_t bytes) {
+    if (bytes <= 64 * 1024) return 0;
+    auto it = h->lds_attr.find(kern);
+    if (it != h->lds_attr.end() && it->second >= (int)bytes) return 0;
+    if (h->capturing)
+        return fail(h, -6, "this launch needs %zu bytes of dynamic LDS, which has to be opted into outside a stream capture: run one "
+                           "eager call with the same configuration first", bytes);
+    HIP_OK(h, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    h->lds_attr[kern] = (int)bytes;
+    return 0;
+}
+inline bool stream_is_capturing(hipStream_t s) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap);
+    return cap != hipStreamCaptureStatusNone;
+}
 
 // Two problems per wavefront (Duo layout, mpc_kernels.hpp) exist for the compiled horizon N_hor = 20.  Measured on the
 // benchmark batch it is SLOWER than one problem per wavefront (1631 vs 1274 ms for 32 768 solves: 11 % fewer VALU
@@ -257,9 +281,6 @@ int prepare(Handle* h, int B, const double* d_p, hipStream_t s, BatchPtrs& io, b
     io.p = d_p;
     io.ws = (double*)h->ws.ptr;
     io.counts = (int*)h->counts.ptr;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(s, &cap);
-    h->capturing = cap != hipStreamCaptureStatusNone;
     HIP_OK(h, hipMemsetAsync(io.counts, 0, CNT_WORDS * sizeof(int), s));
     if (!h->capturing) HIP_OK(h, hipEventRecord(h->ev[0], s));
     hipLaunchKernelGGL(prep_kernel, dim3(B), dim3(WAVE), 0, s, h->kp, io, B);
@@ -268,8 +289,8 @@ int prepare(Handle* h, int B, const double* d_p, hipStream_t s, BatchPtrs& io, b
     int mKs, mKf, mKd;
     if (allow_reserved && h->reserved) {
         mKs = h->res_shape[0]; mKf = h->res_shape[1]; mKd = h->res_shape[2];
-        h->shape_const = h->res_shape[3] == 0;
-        h->axis_aligned = false;
+        h->shape_const = h->res_shape[3] != 1;
+        h->axis_aligned = h->res_shape[3] == 2;
         h->kp.reserved = 1;
     } else {
         if (h->capturing) return fail(h, -6, "stream capture needs mpcgpu_reserve_shape: the automatic LDS carve reads the batch's row counts back");
@@ -383,6 +404,8 @@ int32_t mpcgpu_solve_batch_dev(void* handle, int32_t B, const double* p, const d
     if (!p || !u || !cost || !status) return fail(h, -1, "p, u, cost and status must not be NULL");
     HIP_OK(h, hipSetDevice(h->device));
     hipStream_t s = pick_stream(h, stream);
+    h->capturing = stream_is_capturing(s);
+    h->last_stream = s;
     BatchPtrs io{};
     // Small batches take the latency kernel: one problem per workgroup of four wavefronts, compaction fused, carve from the
     // configured maxima -- one launch, nothing read back.  Results are bitwise those of the throughput kernel.
@@ -396,19 +419,16 @@ int32_t mpcgpu_solve_batch_dev(void* handle, int32_t B, const double* p, const d
         io.p = p; io.ws = (double*)h->ws.ptr; io.counts = nullptr; io.evals = (int32_t*)h->evals.ptr;
         io.u0 = u0; io.y0 = y0; io.c0 = c0; io.u = u; io.cost = cost; io.status = status; io.inner_it = inner_it;
         io.outer_it = outer_it; io.fpr = fpr; io.f2norm = f2norm; io.y_out = y_out; io.ms = ms;
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        (void)hipStreamIsCapturing(s, &cap);
-        h->capturing = cap != hipStreamCaptureStatusNone;
         KParams kt = h->kp;
         fill_team_layout(kt, h->cfg);
         const size_t lds_t = kt.l_total * sizeof(double);
-        if (lds_t <= 160 * 1024) {   // else (long horizons with many obstacle slots): the throughput kernel below
+        // + 256: prep_problem's static __shared__ table travels on top of the dynamic carve
+        if (lds_t + 256 <= 160 * 1024) {   // else (long horizons with many obstacle slots): the throughput kernel below
             if (!h->capturing) { HIP_OK(h, hipEventRecord(h->ev[0], s)); HIP_OK(h, hipEventRecord(h->ev[1], s)); HIP_OK(h, hipEventRecord(h->ev[2], s)); }
 #define LAUNCH_TEAM(NT)                                                                                              \
     do {                                                                                                             \
         auto kern = solve_kernel_team<NT>;                                                                           \
-        if (lds_t > 64 * 1024)                                                                                       \
-            HIP_OK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_t)); \
+        if (int r_ = opt_in_lds(h, (const void*)kern, lds_t)) return r_;                                             \
         hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE * TEAM_WAVES), lds_t, s, kt, io, B);                             \
     } while (0)
             switch (compiled_horizon(h)) {
@@ -447,8 +467,7 @@ int32_t mpcgpu_solve_batch_dev(void* handle, int32_t B, const double* p, const d
 #define LAUNCH_PAIR_WA(NT, SC, MINW, AX)                                                                           \
     do {                                                                                                             \
         auto kern = solve_kernel_pair<NT, SC, LBFGS_IN_WORKSPACE, MINW, AX>;                                         \
-        if (lds > 64 * 1024)                                                                                         \
-            HIP_OK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
+        if (int r_ = opt_in_lds(h, (const void*)kern, lds)) return r_;                                               \
         hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE), lds, s, h->kp, io, B);                                         \
     } while (0)
     // compile-time horizons for the configurations the reference uses (generic kernel otherwise) x
@@ -470,8 +489,7 @@ int32_t mpcgpu_solve_batch_dev(void* handle, int32_t B, const double* p, const d
 #define LAUNCH_DUO(NT, SC)                                                                                          \
     do {                                                                                                             \
         auto kern = solve_kernel_duo<NT, SC, LBFGS_IN_WORKSPACE>;                                                    \
-        if (2 * lds > 64 * 1024)                                                                                     \
-            HIP_OK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds)));  \
+        if (int r_ = opt_in_lds(h, (const void*)kern, 2 * lds)) return r_;                                           \
         hipLaunchKernelGGL(kern, dim3((B + 1) / 2), dim3(WAVE), 2 * lds, s, h->kp, io, B);                           \
     } while (0)
     if (h->last_pairing) {
@@ -562,13 +580,13 @@ int32_t mpcgpu_cost_grad_batch(void* handle, int32_t B, const double* u, const d
     HIP_OK(h, hipMemcpyAsync(h->u.ptr, u, Bz * n * 8, hipMemcpyHostToDevice, s));
     HIP_OK(h, hipMemcpyAsync(h->xi.ptr, xi, Bz * (n + 1) * 8, hipMemcpyHostToDevice, s));
     BatchPtrs io{};
+    h->capturing = false;
     if (int r = prepare(h, B, (const double*)h->p.ptr, s, io, false)) return r;
     const size_t lds_cg = h->kp.l_total * sizeof(double);
 #define LAUNCH_CGA(NT, SC, PP, GRID, LDSB, AX)                                                                      \
     do {                                                                                                             \
         auto kern = cost_grad_kernel<NT, SC, PP, AX>;                                                                \
-        if ((LDSB) > 64 * 1024)                                                                                      \
-            HIP_OK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDSB))); \
+        if (int r_ = opt_in_lds(h, (const void*)kern, (LDSB))) return r_;                                            \
         hipLaunchKernelGGL(kern, dim3(GRID), dim3(WAVE), (LDSB), s, h->kp, io, (const double*)h->u.ptr,              \
                            (const double*)h->xi.ptr, (double*)h->psi.ptr, (double*)h->f.ptr, (double*)h->grad.ptr,   \
                            (double*)h->F1.ptr, (double*)h->F2.ptr, B);                                               \
@@ -627,8 +645,10 @@ int32_t mpcgpu_last_eval_counts(void* handle, int32_t B, int32_t* n_psi, int32_t
     if (!h) return -1;
     if (B != h->last_B || !h->evals.ptr) return fail(h, -4, "no solve of %d problems precedes this call (last: %d)", B, h->last_B);
     HIP_OK(h, hipSetDevice(h->device));
+    // the counters are written by the solve kernel: wait for the stream THAT launch went to (and for the caller's, if another)
+    HIP_OK(h, hipStreamSynchronize(h->last_stream));
     hipStream_t s = pick_stream(h, stream);
-    HIP_OK(h, hipStreamSynchronize(s));
+    if (s != h->last_stream) HIP_OK(h, hipStreamSynchronize(s));
     int32_t* tmp = new (std::nothrow) int32_t[(size_t)B * 2];
     if (!tmp) return fail(h, -3, "out of host memory");
     hipError_t e = hipMemcpy(tmp, h->evals.ptr, (size_t)B * 2 * sizeof(int32_t), hipMemcpyDeviceToHost);
@@ -659,10 +679,23 @@ int32_t mpcgpu_reserve_shape(void* handle, int32_t max_static, int32_t max_fleet
         return fail(h, -1, "reserved shape (%d, %d, %d) outside the configured maxima (%d, %d, %d)", max_static, max_fleet,
                     max_dyn, c.Nstcobs, c.Nother, c.Ndynobs);
     KParams probe = h->kp;
-    fill_lds_layout(probe, max_static, max_fleet, max_dyn, var_shape == 0, !LBFGS_IN_WORKSPACE);
+    if (var_shape < 0 || var_shape > 2) return fail(h, -1, "var_shape must be 0 (shape-constant rows), 1 (rows may change shape) or 2 (shape-constant, axis-aligned), got %d", var_shape);
+    fill_lds_layout(probe, max_static, max_fleet, max_dyn, var_shape != 1, !LBFGS_IN_WORKSPACE);
     if (probe.l_total * (int)sizeof(double) > 160 * 1024) return fail(h, -5, "reserved LDS carve of %d bytes exceeds 160 KiB", probe.l_total * 8);
-    h->res_shape[0] = max_static; h->res_shape[1] = max_fleet; h->res_shape[2] = max_dyn; h->res_shape[3] = var_shape != 0;
+    h->res_shape[0] = max_static; h->res_shape[1] = max_fleet; h->res_shape[2] = max_dyn; h->res_shape[3] = var_shape;
     h->reserved = true;
+    return 0;
+}
+
+int32_t mpcgpu_reserve_batch(void* handle, int32_t B) {
+    Handle* h = (Handle*)handle;
+    if (!h) return -1;
+    if (B < 0) return fail(h, -1, "B=%d is negative", B);
+    HIP_OK(h, hipSetDevice(h->device));
+    h->capturing = false;
+    if (int r = ensure(h, h->ws, (size_t)B * h->kp.ws_stride * sizeof(double))) return r;
+    if (int r = ensure(h, h->counts, CNT_WORDS * sizeof(int))) return r;
+    if (int r = ensure(h, h->evals, (size_t)B * 2 * sizeof(int32_t))) return r;
     return 0;
 }
 
@@ -716,6 +749,13 @@ int32_t mpcgpu_last_waves_per_simd(void* handle) {
 int32_t mpcgpu_last_latency_kernel(void* handle) {
     Handle* h = (Handle*)handle;
     return h ? h->last_team : -1;
+}
+
+int32_t mpcgpu_last_table_kind(void* handle) {
+    Handle* h = (Handle*)handle;
+    if (!h) return -1;
+    if (h->last_team) return 1;  // the latency kernel always carries the general tables
+    return h->shape_const ? (h->axis_aligned ? 2 : 0) : 1;
 }
 
 int32_t mpcgpu_last_problems_per_wavefront(void* handle) {

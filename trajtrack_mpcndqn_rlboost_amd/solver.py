@@ -22,7 +22,7 @@ _LIB = os.environ.get("MPCGPU_LIB", os.path.join(_PKG, "libmpcgpu.so"))  # overr
 
 STATUS_NAMES = ("Converged", "NotConvergedIterations", "NotConvergedOutOfTime", "NotFiniteComputation",
                 "ShapeExceeded")
-ABI_VERSION = 3
+ABI_VERSION = 4
 _STREAM_OWN = C.c_void_p(-1)      # MPCGPU_STREAM_OWN: the handle's own non-blocking stream
 OPT_LINESEARCH_FALLBACK = 1       # MPCGPU_OPT_LINESEARCH_FALLBACK
 OPT_PAIRING = 2                   # MPCGPU_OPT_PAIRING
@@ -57,7 +57,7 @@ class _CConfig(C.Structure):
 EXPORTS = ("mpcgpu_abi_version", "mpcgpu_create", "mpcgpu_destroy", "mpcgpu_last_error", "mpcgpu_num_params",
            "mpcgpu_solve_batch", "mpcgpu_solve_batch_dev", "mpcgpu_cost_grad_batch", "mpcgpu_last_timing",
            "mpcgpu_last_eval_counts", "mpcgpu_last_shape", "mpcgpu_last_waves_per_simd", "mpcgpu_reserve_shape",
-           "mpcgpu_set_option", "mpcgpu_last_problems_per_wavefront", "mpcgpu_last_latency_kernel")
+           "mpcgpu_set_option", "mpcgpu_last_problems_per_wavefront", "mpcgpu_last_latency_kernel", "mpcgpu_reserve_batch", "mpcgpu_last_table_kind")
 
 
 def library_path() -> str:
@@ -129,6 +129,10 @@ def load_library(path: Optional[str] = None):
     L.mpcgpu_last_problems_per_wavefront.restype = C.c_int32
     L.mpcgpu_reserve_shape.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.mpcgpu_reserve_shape.restype = C.c_int32
+    L.mpcgpu_last_table_kind.argtypes = [vp]
+    L.mpcgpu_last_table_kind.restype = C.c_int32
+    L.mpcgpu_reserve_batch.argtypes = [vp, C.c_int32]
+    L.mpcgpu_reserve_batch.restype = C.c_int32
     L.mpcgpu_set_option.argtypes = [vp, C.c_int32, C.c_double]
     L.mpcgpu_set_option.restype = C.c_int32
     if L.mpcgpu_abi_version() != ABI_VERSION:
@@ -299,15 +303,25 @@ class BatchSolver:
         self._check(rc, "mpcgpu_solve_batch_dev")
 
     def reserve_shape(self, max_static: Optional[int] = None, max_fleet: Optional[int] = None,
-                      max_dyn: Optional[int] = None, var_shape: bool = True):
+                      max_dyn: Optional[int] = None, var_shape: bool = True, axis_aligned: bool = False):
         """Promise upper bounds on the active rows of the following ``solve_device`` batches (``None`` = the
         configured maximum): the launch then needs no count read-back -- it never blocks and can be captured into
-        a hipGraph.  Problems that exceed the reservation come back with status 4 (``ShapeExceeded``)."""
+        a hipGraph (after ``reserve_batch``).  ``var_shape=False``: every dynamic row keeps (rx, ry, angle, alpha) over
+        the horizon (compact tables); with ``axis_aligned=True`` on top: every row has angle 0, what the reference's own
+        prediction feeder produces (src/main.py:77-85).  Problems that break a promise come back with status 4
+        (``ShapeExceeded``)."""
         c = self.config
+        if axis_aligned and var_shape:
+            raise MpcGpuError("axis_aligned=True needs var_shape=False")
         self._check(self._L.mpcgpu_reserve_shape(
             self._h, int(c.Nstcobs if max_static is None else max_static),
             int(c.Nother if max_fleet is None else max_fleet), int(c.Ndynobs if max_dyn is None else max_dyn),
-            1 if var_shape else 0), "mpcgpu_reserve_shape")
+            1 if var_shape else (2 if axis_aligned else 0)), "mpcgpu_reserve_shape")
+
+    def reserve_batch(self, B: int):
+        """Size the library-owned device buffers for batches of up to ``B`` problems now (needed before a
+        ``solve_device`` call is captured into a hipGraph: nothing may be allocated inside a capture)."""
+        self._check(self._L.mpcgpu_reserve_batch(self._h, int(B)), "mpcgpu_reserve_batch")
 
     def release_shape(self):
         self._check(self._L.mpcgpu_reserve_shape(self._h, -1, -1, -1, 0), "mpcgpu_reserve_shape")
@@ -344,4 +358,6 @@ class BatchSolver:
         return dict(max_static=v[0].value, max_fleet=v[1].value, max_dyn=v[2].value, lds_bytes=v[3].value,
                     waves_per_simd=int(self._L.mpcgpu_last_waves_per_simd(self._h)),
                     problems_per_wavefront=int(self._L.mpcgpu_last_problems_per_wavefront(self._h)),
-                    latency_kernel=bool(self._L.mpcgpu_last_latency_kernel(self._h)))
+                    latency_kernel=bool(self._L.mpcgpu_last_latency_kernel(self._h)),
+                    shape_const=int(self._L.mpcgpu_last_table_kind(self._h)) != 1,
+                    axis_aligned=int(self._L.mpcgpu_last_table_kind(self._h)) == 2)
