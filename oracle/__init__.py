@@ -22,6 +22,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "libmpc_oracle.so")
+_OVERRIDE = os.environ.get("MPC_ORACLE_LIB")   # another build of the same source (tests: the address/UB-sanitizer build)
+if _OVERRIDE:
+    _LIB_PATH = _OVERRIDE
 
 STATUS_NAMES = ("Converged", "NotConvergedIterations", "NotConvergedOutOfTime")
 
@@ -70,6 +73,8 @@ assert RESULT_DTYPE.itemsize == C.sizeof(OracleResult)
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (recipe: oracle/Makefile)."""
     src = os.path.join(_HERE, "mpc_oracle.c")
+    if _OVERRIDE:
+        return _LIB_PATH
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _LIB_PATH

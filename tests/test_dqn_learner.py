@@ -245,3 +245,78 @@ def test_training_tool_at_the_configured_per_gpu_size():
     print("\n[config 5, one rank]", json.dumps(line))
     assert line["n_gpus"] == 1 and line["config"]["envs_per_gpu"] == 4096
     assert line["value"] > 1e5 and line["updates_per_s"] > 100
+
+
+def test_resumed_run_equals_the_uninterrupted_run(tmp_path):
+    """Checkpoint / resume (the reference keeps best_model / final_model, src/test_block_rl.py:73-76,89-96; an exact
+    continuation also needs the optimiser, counters, generator, buffer, environment and loop state): 240 steps in one go
+    against 120 steps, save, a NEW learner, load, 120 more -- same weights, same buffer, same counters, bit for bit."""
+    class Env(CountingEnv):
+        def state_dict(self):
+            return dict(t=self.t.clone())
+
+        def load_state_dict(self, d):
+            self.t = d["t"].clone()
+
+    def make():
+        torch.manual_seed(0)
+        return dqn_train.DqnLearner(Env(B=6), buffer_size=4096, learning_starts=24, batch_size=8, train_freq=4,
+                                    gradient_steps=3, target_update_interval=60, seed=3)
+    a = make()
+    sa = a.learn(total_timesteps=240)
+    b = make()
+    b.learn(total_timesteps=240, stop_at=120)
+    assert b.num_timesteps == 120
+    b.save(str(tmp_path / "checkpoint.pt"))
+    b.save_model(str(tmp_path / "best_model.pt"))
+    torch.manual_seed(12345)                   # the restored learner must not depend on the process's global generator state
+    c = dqn_train.DqnLearner(Env(B=6), buffer_size=4096, learning_starts=24, batch_size=8, train_freq=4,
+                             gradient_steps=3, target_update_interval=60, seed=99)
+    c.load(str(tmp_path / "checkpoint.pt"))
+    sc = c.learn(total_timesteps=240)
+    flat = lambda l: torch.cat([p.detach().reshape(-1) for p in l.trainer.q_net.parameters()])   # noqa: E731
+    assert torch.equal(flat(a), flat(c))
+    assert torch.equal(torch.cat([p.reshape(-1) for p in a.trainer.q_net_target.parameters()]),
+                       torch.cat([p.reshape(-1) for p in c.trainer.q_net_target.parameters()]))
+    n = a.buffer.size
+    assert c.buffer.size == n and c.buffer.pos == a.buffer.pos
+    for k in ("obs", "next_obs", "actions", "rewards", "dones"):
+        assert torch.equal(getattr(a.buffer, k)[:n], getattr(c.buffer, k)[:n]), k
+    assert sa["updates"] == sc["updates"] and a.trainer.num_updates == c.trainer.num_updates
+    assert a.trainer.num_target_syncs == c.trainer.num_target_syncs and a.n_calls == c.n_calls
+    assert a.episode_returns == c.episode_returns
+    # the policy file alone restores the network
+    net = dqn_train.DqnTrainer().q_net
+    net.load_state_dict(torch.load(str(tmp_path / "best_model.pt")))
+    assert torch.equal(torch.cat([p.detach().reshape(-1) for p in net.parameters()]), flat(b))
+
+
+@pytest.mark.gpu
+def test_resumed_run_equals_the_uninterrupted_run_on_the_hip_environment(tmp_path):
+    """The same property with the real environment kernel: its state (robot, clocks, observation memory) travels in the
+    checkpoint, the continuation is bitwise the uninterrupted run."""
+    import json
+    rl_env = importlib.import_module("trajtrack_mpcndqn_rlboost_amd.rl_env")
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "env_rays_traces.npz"))
+    specs = json.loads(bytes(fx["specs_json"]).decode())
+    maps = [rl_env.make_map(sp["boundary"], sp["static"], sp["dynamic"], sp["start"], sp["goal"], sp["path"])
+            for sp in specs.values()]
+
+    def make(seed):
+        torch.manual_seed(0)
+        env = rl_env.BatchedRaysEnv([maps[i % 2] for i in range(128)], max_episode_steps=40)
+        return dqn_train.DqnLearner(env, buffer_size=32768, learning_starts=1024, batch_size=32, train_freq=4,
+                                    gradient_steps=4, target_update_interval=2048, seed=seed, track_episodes=False)
+    a = make(7)
+    a.learn(total_timesteps=128 * 100)
+    b = make(7)
+    b.learn(total_timesteps=128 * 100, stop_at=128 * 48)
+    b.save(str(tmp_path / "checkpoint.pt"))
+    c = make(1234)
+    c.load(str(tmp_path / "checkpoint.pt"))
+    c.learn(total_timesteps=128 * 100)
+    flat = lambda l: torch.cat([p.detach().reshape(-1) for p in l.trainer.q_net.parameters()])   # noqa: E731
+    assert torch.equal(flat(a), flat(c))
+    assert torch.equal(a.buffer.obs[:a.buffer.size], c.buffer.obs[:c.buffer.size])
+    assert torch.equal(a.env.state, c.env.state)
+    assert float(a.ep_count) == float(c.ep_count) > 0

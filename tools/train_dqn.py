@@ -2,10 +2,17 @@
 """DQN training on the batched HIP environment (BASELINE.json config 5 in miniature, one GPU per process).
 
     python tools/train_dqn.py [--gpus N] [--envs 4096] [--timesteps 4000000] [--gradient-steps 16] [--batch-size 256]
+                              [--save DIR] [--resume DIR/checkpoint.pt] [--checkpoint-every STEPS]
+
+`--save DIR` writes what the reference's run leaves behind (src/test_block_rl.py:73-76,89-96: EvalCallback's best_model and
+model.save's final_model) -- best_model.pt whenever the mean return of a progress window improves, final_model.pt at the end --
+plus checkpoint.pt (network, target network, Adam moments, counters, generator, replay buffer, environment state) every
+`--checkpoint-every` environment steps; `--resume` continues such a checkpoint exactly where it stopped (rank 0's files; in a
+multi-rank run every rank restores its own `checkpoint.rank<r>.pt`).
 
 `--gpus N` without a launcher starts the N ranks itself (fresh child processes of torch.distributed.run, before anything in
 this process touches a GPU); it exits non-zero when fewer than N devices are visible.  Rank 0 ends with ONE JSON line
-(environment steps/s and DDQN updates/s of the whole job, ranks, backend).
+(environment steps/s and Q-network updates/s of the whole job, ranks, backend; `double_q` says whether they are double-Q updates).
 
 Every environment is scene 1 of the reference (src/pkg_dqn/utils/map.py:292-305) with the 'medium' box and a periodic
 obstacle, start pose jittered per environment; the reference path is the straight line start -> goal (an input; the
@@ -65,6 +72,9 @@ def main():
     ap.add_argument("--batch-size", type=int, default=256)
     ap.add_argument("--double-q", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the update from captured HIP graphs (multi-rank: two graphs around the all-reduce)")
+    ap.add_argument("--save", default=None, help="directory for best_model.pt / final_model.pt / checkpoint.pt")
+    ap.add_argument("--resume", default=None, help="checkpoint.pt of an earlier run with the same arguments")
+    ap.add_argument("--checkpoint-every", type=int, default=0, help="environment steps between checkpoints (0: only at the end)")
     args = ap.parse_args()
     if os.environ.get("WORLD_SIZE") is None and args.gpus > 1:
         sys.exit(self_launch(args.gpus))
@@ -83,7 +93,15 @@ def main():
                                    batch_size=args.batch_size, train_freq=4, gradient_steps=args.gradient_steps,
                                    target_update_interval=200_000, exploration_fraction=0.3, use_graph=args.graph,
                                    track_episodes=False)
+    ck_name = "checkpoint.pt" if rank == 0 else f"checkpoint.rank{rank}.pt"
+    if args.resume:
+        learner.load(args.resume if rank == 0 else os.path.join(os.path.dirname(args.resume), ck_name))
+        if rank == 0:
+            print(f"  resumed at {learner.num_timesteps} environment steps, {learner.trainer.num_updates} updates", flush=True)
+    if args.save:
+        os.makedirs(args.save, exist_ok=True)
     marks, t0 = [], time.perf_counter()
+    best = [-float("inf")]
 
     def progress(lr):
         if lr.num_timesteps // (args.timesteps // 10) > len(marks):
@@ -93,15 +111,29 @@ def main():
             marks.append((lr.num_timesteps, (r - pr) / dn, (ok - pok) / dn, time.perf_counter() - t0, n, r, ok))
             if rank == 0:
                 print(f"  {marks[-1][0]:>9d} steps  mean return {marks[-1][1]:8.2f}  success {marks[-1][2]:.2f}  {marks[-1][3]:6.1f} s", flush=True)
+                if args.save and marks[-1][1] > best[0]:       # EvalCallback(best_model_save_path=...)
+                    best[0] = marks[-1][1]
+                    learner.save_model(os.path.join(args.save, "best_model.pt"))
 
-    stats = learner.learn(args.timesteps, callback=progress)
+    if args.save and args.checkpoint_every > 0:
+        stats = None
+        while learner.num_timesteps < args.timesteps:
+            stats = learner.learn(args.timesteps, callback=progress, stop_at=learner.num_timesteps + args.checkpoint_every)
+            learner.save(os.path.join(args.save, ck_name))
+    else:
+        stats = learner.learn(args.timesteps, callback=progress)
+    if args.save:
+        learner.save(os.path.join(args.save, ck_name))
+        if rank == 0:
+            learner.save_model(os.path.join(args.save, "final_model.pt"))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if rank == 0:
         print(f"envs/rank {args.envs} x ranks {world}: {world * stats['timesteps'] / dt:.3e} environment steps/s incl. "
               f"{stats['updates']} updates of batch {args.batch_size} ({stats['updates'] / dt:.0f} updates/s), "
               f"episodes {stats['episodes']}, final mean return {stats['mean_return']:.2f}, success rate {stats['success_rate']:.2f}")
-        print(json.dumps({"metric": "DQN online training: environment steps/s (batched HIP environment + DDQN updates)",
+        print(json.dumps({"metric": "DQN online training: environment steps/s (batched HIP environment + "
+                                    + ("double-Q" if args.double_q else "DQN") + " updates)",
                           "value": world * stats["timesteps"] / dt, "unit": "environment steps/s", "n_gpus": world,
                           "rccl_ranks": dist.get_world_size() if world > 1 else 1, "backend": "nccl" if world > 1 else None,
                           "updates_per_s": stats["updates"] / dt, "gradient_all_reduce_floats": 1177 if world > 1 else 0,

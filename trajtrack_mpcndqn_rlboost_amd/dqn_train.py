@@ -260,6 +260,9 @@ class DqnLearner:
         self.use_graph = use_graph
         if use_graph:
             self.trainer.enable_graph(batch_size)
+        # state of the collection loop between two learn() calls (a run can be checkpointed and resumed in the middle)
+        self._obs, self._ep_return, self.n_updates = None, None, 0
+        self._last_loss = torch.zeros((), device=self.device)
 
     def act(self, obs_flat: torch.Tensor, epsilon: float) -> torch.Tensor:
         greedy = self.trainer.q_net.greedy_actions(obs_flat)
@@ -268,13 +271,72 @@ class DqnLearner:
         rand = torch.randint(0, 9, (B,), device=self.device, generator=self.gen)
         return torch.where(explore, rand, greedy)
 
-    def learn(self, total_timesteps: int, callback: Optional[Callable[["DqnLearner"], None]] = None) -> Dict[str, float]:
+    # ---- checkpoint / resume: what SB3's model.save / EvalCallback(best_model_save_path) / Algorithm.load do for the
+    # reference (src/test_block_rl.py:73-76,89-96), extended by everything an EXACT continuation needs -- optimiser moments,
+    # counters, random generator, replay buffer, the environments' own state and the observation the loop stands at.
+    def state_dict(self, include_buffer: bool = True) -> Dict:
+        tr = self.trainer
+        d = dict(q_net=tr.q_net.state_dict(), q_net_target=tr.q_net_target.state_dict(), optimizer=tr.optimizer.state_dict(),
+                 num_updates=tr.num_updates, num_target_syncs=getattr(tr, "num_target_syncs", 0),
+                 num_timesteps=self.num_timesteps, n_calls=self.n_calls, n_updates=self.n_updates,
+                 generator=self.gen.get_state(), episode_returns=list(self.episode_returns),
+                 episode_successes=list(self.episode_successes), ep_count=self.ep_count.clone(),
+                 ep_return_sum=self.ep_return_sum.clone(), ep_success_sum=self.ep_success_sum.clone(),
+                 obs=None if self._obs is None else self._obs.clone(),
+                 ep_return=None if self._ep_return is None else self._ep_return.clone())
+        if include_buffer:
+            b, n = self.buffer, self.buffer.size
+            d["buffer"] = dict(pos=b.pos, size=n, obs=b.obs[:n].clone(), next_obs=b.next_obs[:n].clone(),
+                               actions=b.actions[:n].clone(), rewards=b.rewards[:n].clone(), dones=b.dones[:n].clone())
+        if hasattr(self.env, "state_dict"):
+            d["env"] = self.env.state_dict()
+        return d
+
+    def load_state_dict(self, d: Dict) -> None:
+        tr = self.trainer
+        tr.q_net.load_state_dict(d["q_net"]); tr.q_net_target.load_state_dict(d["q_net_target"])
+        tr.optimizer.load_state_dict(d["optimizer"])
+        tr.num_updates, tr.num_target_syncs = d["num_updates"], d["num_target_syncs"]
+        self.num_timesteps, self.n_calls, self.n_updates = d["num_timesteps"], d["n_calls"], d["n_updates"]
+        self.gen.set_state(d["generator"].cpu() if self.gen.device.type == "cpu" else d["generator"])
+        self.episode_returns, self.episode_successes = list(d["episode_returns"]), list(d["episode_successes"])
+        self.ep_count.copy_(d["ep_count"]); self.ep_return_sum.copy_(d["ep_return_sum"]); self.ep_success_sum.copy_(d["ep_success_sum"])
+        self._obs = None if d["obs"] is None else d["obs"].to(self.device)
+        self._ep_return = None if d["ep_return"] is None else d["ep_return"].to(self.device)
+        if "buffer" in d:
+            b, src = self.buffer, d["buffer"]
+            n = src["size"]
+            if n > b.capacity:
+                raise ValueError(f"checkpointed buffer holds {n} transitions, this buffer only {b.capacity}")
+            b.obs[:n], b.next_obs[:n] = src["obs"].to(self.device), src["next_obs"].to(self.device)
+            b.actions[:n], b.rewards[:n], b.dones[:n] = (src[k].to(self.device) for k in ("actions", "rewards", "dones"))
+            b.pos, b.size = src["pos"] % b.capacity, n
+        if "env" in d and hasattr(self.env, "load_state_dict"):
+            self.env.load_state_dict(d["env"])
+
+    def save(self, path: str, include_buffer: bool = True) -> None:
+        torch.save(self.state_dict(include_buffer), path)
+
+    def load(self, path: str) -> None:
+        self.load_state_dict(torch.load(path, map_location=self.device, weights_only=False))
+
+    def save_model(self, path: str) -> None:
+        """The policy alone (the reference's final_model / best_model): the Q-network's weights."""
+        torch.save(self.trainer.q_net.state_dict(), path)
+
+    def learn(self, total_timesteps: int, callback: Optional[Callable[["DqnLearner"], None]] = None,
+              stop_at: Optional[int] = None) -> Dict[str, float]:
+        """Collect and learn until ``total_timesteps`` (the horizon of the exploration schedule) -- or until ``stop_at``, a
+        point to checkpoint at; a later call, also on a learner restored with ``load``, continues exactly there."""
         env, B = self.env, self.env.B
-        obs = flatten_observation(env.reset())
-        ep_return = torch.zeros(B, dtype=torch.float64, device=self.device)
-        last_loss = torch.zeros((), device=self.device)
-        n_updates = 0
-        while self.num_timesteps < total_timesteps:
+        if self._obs is None:
+            self._obs = flatten_observation(env.reset())
+            self._ep_return = torch.zeros(B, dtype=torch.float64, device=self.device)
+        obs, ep_return = self._obs, self._ep_return
+        last_loss = self._last_loss
+        n_updates = self.n_updates
+        end = total_timesteps if stop_at is None else min(stop_at, total_timesteps)
+        while self.num_timesteps < end:
             collected = 0
             for _ in range(self.train_freq):
                 eps = exploration_rate(self.num_timesteps, total_timesteps, *self.eps)
@@ -310,8 +372,10 @@ class DqnLearner:
                     step = self.trainer.update_graphed if self.use_graph else self.trainer.update
                     last_loss = step(self.buffer.sample(self.batch_size, self.gen))
                 n_updates += steps
+            self._obs, self._ep_return, self.n_updates, self._last_loss = obs, ep_return, n_updates, last_loss
             if callback is not None:
                 callback(self)
+        self._obs, self._ep_return, self.n_updates, self._last_loss = obs, ep_return, n_updates, last_loss
         if not self.track_episodes:       # whole-run averages from the device counters
             n = float(self.ep_count)
             return dict(timesteps=self.num_timesteps, updates=n_updates, loss=float(last_loss), episodes=int(n),

@@ -258,6 +258,16 @@ class BatchedRaysEnv:
         self.terminated.copy_(torch.where(mask, self.terminated, kept[2]))
         return self._obs()
 
+    def state_dict(self) -> Dict:
+        """Everything a continuation needs: robot / clock state (incl. the one-step observation memory kept in it) and the
+        observation, reward and flags of the last launch."""
+        return dict(state=self.state.clone(), obs_internal=self.obs_internal.clone(), obs_external=self.obs_external.clone(),
+                    reward=self.reward.clone(), terminated=self.terminated.clone(), truncated=self.truncated.clone())
+
+    def load_state_dict(self, d: Dict) -> None:
+        for k in ("state", "obs_internal", "obs_external", "reward", "terminated", "truncated"):
+            getattr(self, k).copy_(d[k].to(self.device))
+
     def step(self, actions, auto_reset: bool = False):
         """``env.step`` (environment.py:199-213) -> (obs, reward [B], terminated [B] bool, truncated [B] bool, info).
 
