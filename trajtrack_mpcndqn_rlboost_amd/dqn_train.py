@@ -298,7 +298,7 @@ class DqnLearner:
         tr.optimizer.load_state_dict(d["optimizer"])
         tr.num_updates, tr.num_target_syncs = d["num_updates"], d["num_target_syncs"]
         self.num_timesteps, self.n_calls, self.n_updates = d["num_timesteps"], d["n_calls"], d["n_updates"]
-        self.gen.set_state(d["generator"].cpu() if self.gen.device.type == "cpu" else d["generator"])
+        self.gen.set_state(d["generator"].cpu())   # a generator state is a host ByteTensor, also for a device generator
         self.episode_returns, self.episode_successes = list(d["episode_returns"]), list(d["episode_successes"])
         self.ep_count.copy_(d["ep_count"]); self.ep_return_sum.copy_(d["ep_return_sum"]); self.ep_success_sum.copy_(d["ep_success_sum"])
         self._obs = None if d["obs"] is None else d["obs"].to(self.device)
