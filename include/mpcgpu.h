@@ -196,6 +196,77 @@ int32_t mpcgpu_last_table_kind(void* handle);
 /* Problems per wavefront of the last solve / cost_grad launch: 1 or 2 (MPCGPU_OPT_PAIRING). */
 int32_t mpcgpu_last_problems_per_wavefront(void* handle);
 
+/* ------------------------------------------------------------------------------------------------------------------------
+ * Batched tracker harness on the device.  Replaces, for B robots per call and without a
+ * host round trip, what the reference does per robot in Python around every solver.run:
+ *     get_local_ref_traj            src/mpc_traj_tracker/trajectory_generator.py:206-232   (mpcgpu_tracker_window_dev)
+ *     check_termination_condition   trajectory_generator.py:156-162                     \
+ *     run_step: speed rule, parameter assembly   trajectory_generator.py:251-275         |  (mpcgpu_tracker_step_dev)
+ *     run_solver                    trajectory_generator.py:318-323                      |
+ *     run_step: taken states, predicted states   trajectory_generator.py:325-339        /
+ * The parameter vector of mpc_generator.py:179-188 is never materialised: the compaction code of the solver reads the same
+ * parameter indices straight from the tracker's arrays, so the solver sees bitwise the record it would have built from the
+ * assembled vector.  All pointers are DEVICE memory owned by the caller (e.g. torch tensors), float64 / int32 / uint8.
+ */
+typedef struct mpcgpu_tracker {
+    int32_t B;                 /* robots */
+    int32_t ref_cap;           /* rows of every robot's slice of `ref` */
+    int32_t action_steps;      /* inputs applied per tick (config action_steps) */
+    int32_t _pad;
+    double* states;            /* [B][3]  (x, y, theta), in/out */
+    const double* goals;       /* [B][3]  final goals */
+    double* last_actions;      /* [B][2]  in/out */
+    const double* ref;         /* [B][ref_cap][3] global reference trajectories (get_global_ref_traj), padded */
+    const int32_t* ref_len;    /* [B] */
+    int32_t* idx_ref;          /* [B] in/out */
+    const double* stc;         /* [B][Nstcobs * 12]      static half-plane rows (update_static_constraints) */
+    const double* dyn;         /* [B][Ndynobs * 6 * N]   dynamic rows (update_dynamic_constraints) */
+    const double* other;       /* [B][3 * N * Nother] other robots' predictions, or NULL = zeros */
+    double* pred_states;       /* [B][N][3] out */
+    uint8_t* active;           /* [B] in/out: 0 once the termination test has fired */
+    double tuning[10];         /* tuning_params of the work mode (trajectory_generator.py:129-134) */
+    double base_speed;         /* of the work mode */
+    double low_speed;          /* config low_speed */
+    double stc_weight, dyn_weight; /* obstacle weights (trajectory_generator.py:59) */
+} mpcgpu_tracker;
+
+/* refs_out [B][N][3]: every robot's local reference window; idx_ref is advanced like the reference's call does. */
+int32_t mpcgpu_tracker_window_dev(void* handle, const mpcgpu_tracker* t, double* refs_out, void* stream);
+
+/* One control tick: termination test, assembly (compact record, no padded vector), solve, taken / predicted states.
+ * refs [B][N][3]: the reference every robot tracks this tick (get_action(current_ref_traj), src/interface_mpc.py:82-88).
+ * u0 [B][2N] or NULL (cold start, what the reference does).  Outputs as mpcgpu_solve_batch_dev; actions_out [B][2] (may be
+ * NULL) = the applied first input, 0 for robots that are done.  Needs mpcgpu_reserve_shape (no count read-back: the call only
+ * enqueues) and follows the throughput / latency kernel rule of mpcgpu_solve_batch_dev. */
+int32_t mpcgpu_tracker_step_dev(void* handle, const mpcgpu_tracker* t, const double* refs, const double* u0, double* u,
+                                double* cost, int32_t* status, int32_t* inner_it, int32_t* outer_it, double* actions_out,
+                                void* stream);
+
+/* The DQN's proposal for B robots: agent [B][agent_stride] rows starting (x, y, theta, v, w); action [B] (int64, 0..8);
+ * rl_ref [B][steps][2] (src/pkg_dqn/environment/agent.py:86-145, src/main.py:193-202).  limits[8] = acc_max, acc_min,
+ * angacc_max, angacc_min, speed_min, speed_max, angvel_min, angvel_max. */
+int32_t mpcgpu_rl_reference_dev(void* handle, int32_t B, const double* agent, int32_t agent_stride, const int64_t* action,
+                                double ts, int32_t steps, double ref_speed, const double* limits, double* rl_ref, void* stream);
+
+/* HintSwitcher.switch (src/main_pre.py:27-52) for B robots + the reference each tracks this tick: polygons [B][O][V][2] (rings
+ * padded by repeating the last vertex), valid [B][O], states [B][3], original [B][N][3], rl_ref [B][rl_steps][2], live [B] or
+ * NULL; switch_on [B] (uint8) / detach_cnt [B] (int32) in/out; chosen [B][N][3] out (the proposal with the original heading
+ * column where the switch is on -- ref_traj_filter with decay 1, src/main.py:34-41 -- else the original). */
+int32_t mpcgpu_hint_switch_dev(void* handle, int32_t B, int32_t N, int32_t O, int32_t V, const double* polygons,
+                               const uint8_t* valid, const double* states, const double* original, const double* rl_ref,
+                               int32_t rl_steps, const uint8_t* live, double switch_distance, double detach_distance,
+                               double detach_steps, uint8_t* switch_on, int32_t* detach_cnt, double* chosen, void* stream);
+
+/* Test hook: copy the library's workspace records of the last B problems to the host (B x mpcgpu_workspace_stride doubles;
+ * the first mpcgpu_workspace_record doubles of each are the compact problem record, the rest is solver scratch). */
+int32_t mpcgpu_debug_read_workspace(void* handle, int32_t B, double* out);
+int32_t mpcgpu_workspace_stride(void* handle);
+int32_t mpcgpu_workspace_record(void* handle);
+/* Test hooks: run only the compaction kernel on B host parameter vectors / only the tracker's assembly kernel (both fill the
+ * workspace records and return when they are complete). */
+int32_t mpcgpu_debug_prep(void* handle, int32_t B, const double* p);
+int32_t mpcgpu_debug_tracker_assemble(void* handle, const mpcgpu_tracker* t, const double* refs);
+
 #ifdef __cplusplus
 }
 #endif

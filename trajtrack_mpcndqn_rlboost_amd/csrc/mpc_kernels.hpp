@@ -380,7 +380,15 @@ __device__ __forceinline__ void sincos_small(double x, const double* k, double& 
 // one 64-thread block per problem.
 // ------------------------------------------------------------------------------------------------
 // One wavefront compacts problem b (lane = its lane index 0..63).  `counts` may be NULL (no batch maxima wanted).
-__device__ __forceinline__ void prep_problem(const KParams& kp, const double* __restrict__ p, double* __restrict__ ws,
+// The parameter vector is read through `p[i]` of a SOURCE type: ParamVector = the reference's padded vector in memory (the
+// plugin boundary); mpc_tracker.hpp adds a source that maps the same indices onto the device-resident tracker state of a
+// robot, so that a tick of the batched tracker writes this compact record directly -- same code, same arithmetic, same bits.
+struct ParamVector {
+    const double* p;
+    __device__ __forceinline__ double operator[](int i) const { return p[i]; }
+};
+template <class Src>
+__device__ __forceinline__ void prep_problem(const KParams& kp, const Src& p, double* __restrict__ ws,
                                              int* counts, int lane) {
     const int N = kp.N;
 
@@ -435,7 +443,7 @@ __device__ __forceinline__ void prep_problem(const KParams& kp, const double* __
         if (lane < kp.Nother)
             for (int k = 0; k < N; ++k) {
                 const int o = kp.c0 + lane * 3 * N + 3 * k;
-                nz |= (p[o] != 0.0) | (p[o + 1] != 0.0);
+                nz |= (p[o] != 0.0) || (p[o + 1] != 0.0);
             }
         const unsigned long long m = __ballot(nz);
         Kf = __popcll(m);
@@ -456,11 +464,12 @@ __device__ __forceinline__ void prep_problem(const KParams& kp, const double* __
     {
         bool nz = false;
         if (lane < kp.Ndynobs) {
-            const double* q = p + kp.od0 + lane * 6 * N;
-            for (int t = 0; t < 6 * N; ++t) nz |= (q[t] != 0.0);
+            const int q0 = kp.od0 + lane * 6 * N;
+            auto q = [&](int t) { return p[q0 + t]; };
+            for (int t = 0; t < 6 * N; ++t) nz |= (q(t) != 0.0);
             for (int k = 1; k < N; ++k)  // semi-axes, angle and alpha constant over the horizon?
-                varshape |= (q[6 * k + 2] != q[2]) | (q[6 * k + 3] != q[3]) | (q[6 * k + 4] != q[4]) | (q[6 * k + 5] != q[5]);
-            for (int k = 0; k < N; ++k) rotated |= nz && (q[6 * k + 4] != 0.0);  // angle 0 <=> cos = 1, sin = 0 exactly
+                varshape |= (q(6 * k + 2) != q(2)) || (q(6 * k + 3) != q(3)) || (q(6 * k + 4) != q(4)) || (q(6 * k + 5) != q(5));
+            for (int k = 0; k < N; ++k) rotated |= nz && (q(6 * k + 4) != 0.0);  // angle 0 <=> cos = 1, sin = 0 exactly
         }
         const unsigned long long m = __ballot(nz);
         Kd = __popcll(m);
@@ -476,18 +485,18 @@ __device__ __forceinline__ void prep_problem(const KParams& kp, const double* __
             const int i = t / N, k = t - i * N;
             const int e = s_entry[i];
             if (e < 0) continue;
-            const double* q = p + kp.od0 + i * 6 * N + 6 * k;
+            const int q0 = kp.od0 + i * 6 * N + 6 * k;
             double* d = ws + kp.ws_dyn + (e * N + k) * DYNW;
             double sa, ca;
-            sincos(q[4], &sa, &ca);
-            const double rx = q[2], ry = q[3];
-            d[0] = q[0]; d[1] = q[1]; d[2] = ca; d[3] = sa;
+            sincos(p[q0 + 4], &sa, &ca);
+            const double rx = p[q0 + 2], ry = p[q0 + 3];
+            d[0] = p[q0]; d[1] = p[q0 + 1]; d[2] = ca; d[3] = sa;
             d[4] = 1.0 / ((rx + 1e-6) * (rx + 1e-6));
             d[5] = 1.0 / ((ry + 1e-6) * (ry + 1e-6));
             d[6] = 1.0 / ((rx + kp.social + 1e-6) * (rx + kp.social + 1e-6));
             d[7] = 1.0 / ((ry + kp.social + 1e-6) * (ry + kp.social + 1e-6));
-            d[8] = p[kp.qd0 + k] * q[5];  // q_dyn[k] * alpha
-            if (k == 0) ws[kp.ws_alpha + e] = q[5];
+            d[8] = p[kp.qd0 + k] * p[q0 + 5];  // q_dyn[k] * alpha
+            if (k == 0) ws[kp.ws_alpha + e] = p[q0 + 5];
         }
     }
     const bool any_var = __ballot(varshape) != 0ull, any_rot = __ballot(rotated) != 0ull;
@@ -506,7 +515,7 @@ __device__ __forceinline__ void prep_problem(const KParams& kp, const double* __
 __global__ __launch_bounds__(WAVE) void prep_kernel(KParams kp, BatchPtrs io, int B) {
     const int b = blockIdx.x;
     if (b >= B) return;
-    prep_problem(kp, io.p + (size_t)b * kp.np, io.ws + (size_t)b * kp.ws_stride, io.counts, threadIdx.x);
+    prep_problem(kp, ParamVector{io.p + (size_t)b * kp.np}, io.ws + (size_t)b * kp.ws_stride, io.counts, threadIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------

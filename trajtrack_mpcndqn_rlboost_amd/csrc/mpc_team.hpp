@@ -39,7 +39,8 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
     const long long t_start = wall_clock64();
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1), mem = kp.mem;
     double* ws = io.ws + (size_t)b * kp.ws_stride;
-    if (wid == 0) prep_problem(kp, io.p + (size_t)b * kp.np, ws, io.counts, lane);
+    // io.p == NULL: the record was already written by the tracker's assembly kernel (mpc_tracker.hpp)
+    if (wid == 0 && io.p) prep_problem(kp, ParamVector{io.p + (size_t)b * kp.np}, ws, io.counts, lane);
     __syncthreads();
 
     // ---- problem context: tables shared by the four wavefronts, work areas and L-BFGS memory per wavefront

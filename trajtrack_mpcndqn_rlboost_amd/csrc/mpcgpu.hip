@@ -5,6 +5,7 @@
 #include "../../include/mpcgpu.h"
 #include "mpc_kernels.hpp"
 #include "mpc_team.hpp"
+#include "mpc_tracker.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -275,7 +276,19 @@ void fill_lds_layout(KParams& k, int mKs, int mKf, int mKd, bool shape_const, bo
 
 // compaction kernel + LDS layout (from the reserved shape, or from a blocking read-back of the batch's active-row
 // maxima).  Leaves kp ready for a launch on `s`.
-int prepare(Handle* h, int B, const double* d_p, hipStream_t s, BatchPtrs& io, bool allow_reserved) {
+TrackerView tracker_view(const Handle* h, const mpcgpu_tracker* t) {
+    TrackerView v{};
+    v.B = t->B; v.ref_cap = t->ref_cap; v.action_steps = t->action_steps;
+    v.states = t->states; v.goals = t->goals; v.last_actions = t->last_actions; v.ref = t->ref; v.ref_len = t->ref_len;
+    v.idx_ref = t->idx_ref; v.stc = t->stc; v.dyn = t->dyn; v.other = t->other; v.pred_states = t->pred_states; v.active = t->active;
+    for (int i = 0; i < 10; ++i) v.tuning[i] = t->tuning[i];
+    v.base_speed = t->base_speed; v.low_speed = t->low_speed; v.stc_weight = t->stc_weight; v.dyn_weight = t->dyn_weight;
+    return v;
+}
+
+// `trk` != NULL: the compact records come from the tracker's arrays (tracker_assemble_kernel) instead of parameter vectors
+int prepare(Handle* h, int B, const double* d_p, hipStream_t s, BatchPtrs& io, bool allow_reserved,
+            const mpcgpu_tracker* trk = nullptr, const double* refs = nullptr) {
     if (int r = ensure(h, h->ws, (size_t)B * h->kp.ws_stride * sizeof(double))) return r;
     if (int r = ensure(h, h->counts, CNT_WORDS * sizeof(int))) return r;
     io.p = d_p;
@@ -283,7 +296,8 @@ int prepare(Handle* h, int B, const double* d_p, hipStream_t s, BatchPtrs& io, b
     io.counts = (int*)h->counts.ptr;
     HIP_OK(h, hipMemsetAsync(io.counts, 0, CNT_WORDS * sizeof(int), s));
     if (!h->capturing) HIP_OK(h, hipEventRecord(h->ev[0], s));
-    hipLaunchKernelGGL(prep_kernel, dim3(B), dim3(WAVE), 0, s, h->kp, io, B);
+    if (trk) hipLaunchKernelGGL(tracker_assemble_kernel, dim3(B), dim3(WAVE), 0, s, h->kp, tracker_view(h, trk), refs, io.ws, io.counts);
+    else hipLaunchKernelGGL(prep_kernel, dim3(B), dim3(WAVE), 0, s, h->kp, io, B);
     HIP_OK(h, hipGetLastError());
     if (!h->capturing) HIP_OK(h, hipEventRecord(h->ev[1], s));
     int mKs, mKf, mKd;
@@ -393,17 +407,14 @@ int32_t mpcgpu_num_params(void* handle) {
     return h ? h->kp.np : -1;
 }
 
-int32_t mpcgpu_solve_batch_dev(void* handle, int32_t B, const double* p, const double* u0, const double* y0,
-                               const double* c0, double* u, double* cost, int32_t* status, int32_t* inner_it,
-                               int32_t* outer_it, double* fpr, double* f2norm, double* y_out, double* ms,
-                               void* stream) {
-    Handle* h = (Handle*)handle;
-    if (!h) return -1;
-    if (B < 0) return fail(h, -1, "B=%d is negative", B);
-    if (B == 0) return 0;
-    if (!p || !u || !cost || !status) return fail(h, -1, "p, u, cost and status must not be NULL");
-    HIP_OK(h, hipSetDevice(h->device));
-    hipStream_t s = pick_stream(h, stream);
+}  // extern "C"
+
+namespace {
+// One batched solve enqueued on `s`.  The problems come either as parameter vectors `p` (the plugin boundary) or from the
+// device-resident tracker state `trk` + the references `refs` its robots track this tick.
+int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker* trk, const double* refs, const double* u0,
+                     const double* y0, const double* c0, double* u, double* cost, int32_t* status, int32_t* inner_it,
+                     int32_t* outer_it, double* fpr, double* f2norm, double* y_out, double* ms, hipStream_t s) {
     h->capturing = stream_is_capturing(s);
     h->last_stream = s;
     BatchPtrs io{};
@@ -417,6 +428,10 @@ int32_t mpcgpu_solve_batch_dev(void* handle, int32_t B, const double* p, const d
         if (int r = ensure(h, h->counts, CNT_WORDS * sizeof(int))) return r;
         if (int r = ensure(h, h->evals, (size_t)B * 2 * sizeof(int32_t))) return r;
         io.p = p; io.ws = (double*)h->ws.ptr; io.counts = nullptr; io.evals = (int32_t*)h->evals.ptr;
+        if (trk) {   // the records of the latency kernel come from the tracker's arrays: one more (tiny) launch in front of it
+            hipLaunchKernelGGL(tracker_assemble_kernel, dim3(B), dim3(WAVE), 0, s, h->kp, tracker_view(h, trk), refs, io.ws, (int*)nullptr);
+            HIP_OK(h, hipGetLastError());
+        }
         io.u0 = u0; io.y0 = y0; io.c0 = c0; io.u = u; io.cost = cost; io.status = status; io.inner_it = inner_it;
         io.outer_it = outer_it; io.fpr = fpr; io.f2norm = f2norm; io.y_out = y_out; io.ms = ms;
         KParams kt = h->kp;
@@ -446,7 +461,7 @@ int32_t mpcgpu_solve_batch_dev(void* handle, int32_t B, const double* p, const d
         }
     }
 #endif
-    if (int r = prepare(h, B, p, s, io, true)) return r;
+    if (int r = prepare(h, B, p, s, io, true, trk, refs)) return r;
     io.u0 = u0; io.y0 = y0; io.c0 = c0; io.u = u; io.cost = cost; io.status = status; io.inner_it = inner_it;
     io.outer_it = outer_it; io.fpr = fpr; io.f2norm = f2norm; io.y_out = y_out; io.ms = ms;
     if (int r = ensure(h, h->evals, (size_t)B * 2 * sizeof(int32_t))) return r;
@@ -511,6 +526,129 @@ int32_t mpcgpu_solve_batch_dev(void* handle, int32_t B, const double* p, const d
     HIP_OK(h, hipGetLastError());
     if (!h->capturing) HIP_OK(h, hipEventRecord(h->ev[3], s));
     h->timing_valid = !h->capturing;
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int32_t mpcgpu_solve_batch_dev(void* handle, int32_t B, const double* p, const double* u0, const double* y0,
+                               const double* c0, double* u, double* cost, int32_t* status, int32_t* inner_it,
+                               int32_t* outer_it, double* fpr, double* f2norm, double* y_out, double* ms,
+                               void* stream) {
+    Handle* h = (Handle*)handle;
+    if (!h) return -1;
+    if (B < 0) return fail(h, -1, "B=%d is negative", B);
+    if (B == 0) return 0;
+    if (!p || !u || !cost || !status) return fail(h, -1, "p, u, cost and status must not be NULL");
+    HIP_OK(h, hipSetDevice(h->device));
+    return solve_common(h, B, p, nullptr, nullptr, u0, y0, c0, u, cost, status, inner_it, outer_it, fpr, f2norm, y_out, ms,
+                        pick_stream(h, stream));
+}
+
+// ---- batched tracker harness on the device (mpc_tracker.hpp) -------------------------------------------------------------
+namespace {
+int check_tracker(Handle* h, const mpcgpu_tracker* t) {
+    if (!t) return fail(h, -1, "tracker is NULL");
+    if (t->B < 0 || t->ref_cap < 1 || t->action_steps < 1 || t->action_steps > h->kp.N)
+        return fail(h, -1, "tracker: B=%d ref_cap=%d action_steps=%d", t->B, t->ref_cap, t->action_steps);
+    if (!t->states || !t->goals || !t->last_actions || !t->ref || !t->ref_len || !t->idx_ref || !t->stc || !t->dyn || !t->pred_states || !t->active)
+        return fail(h, -1, "tracker: only `other` may be NULL");
+    return 0;
+}
+}  // namespace
+
+int32_t mpcgpu_tracker_window_dev(void* handle, const mpcgpu_tracker* t, double* refs_out, void* stream) {
+    Handle* h = (Handle*)handle;
+    if (!h) return -1;
+    if (int r = check_tracker(h, t)) return r;
+    if (!refs_out) return fail(h, -1, "refs_out is NULL");
+    if (t->B == 0) return 0;
+    HIP_OK(h, hipSetDevice(h->device));
+    HIP_OK(h, launch_tracker_window(tracker_view(h, t), h->kp.N, refs_out, pick_stream(h, stream)));
+    return 0;
+}
+
+int32_t mpcgpu_tracker_step_dev(void* handle, const mpcgpu_tracker* t, const double* refs, const double* u0, double* u,
+                                double* cost, int32_t* status, int32_t* inner_it, int32_t* outer_it, double* actions_out,
+                                void* stream) {
+    Handle* h = (Handle*)handle;
+    if (!h) return -1;
+    if (int r = check_tracker(h, t)) return r;
+    if (!refs || !u || !cost || !status) return fail(h, -1, "refs, u, cost and status must not be NULL");
+    if (t->B == 0) return 0;
+    HIP_OK(h, hipSetDevice(h->device));
+    hipStream_t s = pick_stream(h, stream);
+    if (int r = solve_common(h, t->B, nullptr, t, refs, u0, nullptr, nullptr, u, cost, status, inner_it, outer_it, nullptr, nullptr,
+                             nullptr, nullptr, s)) return r;
+    HIP_OK(h, launch_tracker_apply(tracker_view(h, t), h->kp.N, h->kp.ts, (const double*)u, actions_out, s));
+    return 0;
+}
+
+int32_t mpcgpu_rl_reference_dev(void* handle, int32_t B, const double* agent, int32_t agent_stride, const int64_t* action,
+                                double ts, int32_t steps, double ref_speed, const double* limits, double* rl_ref, void* stream) {
+    Handle* h = (Handle*)handle;
+    if (!h) return -1;
+    if (B < 0 || steps < 1 || agent_stride < 5 || !agent || !action || !limits || !rl_ref) return fail(h, -1, "rl_reference: bad arguments");
+    if (B == 0) return 0;
+    HIP_OK(h, hipSetDevice(h->device));
+    RlLimits lim{limits[0], limits[1], limits[2], limits[3], limits[4], limits[5], limits[6], limits[7]};
+    HIP_OK(h, launch_rl_reference(B, agent, agent_stride, action, ts, steps, ref_speed, lim, rl_ref, pick_stream(h, stream)));
+    return 0;
+}
+
+int32_t mpcgpu_hint_switch_dev(void* handle, int32_t B, int32_t N, int32_t O, int32_t V, const double* polygons,
+                               const uint8_t* valid, const double* states, const double* original, const double* rl_ref,
+                               int32_t rl_steps, const uint8_t* live, double switch_distance, double detach_distance,
+                               double detach_steps, uint8_t* switch_on, int32_t* detach_cnt, double* chosen, void* stream) {
+    Handle* h = (Handle*)handle;
+    if (!h) return -1;
+    if (B < 0 || N < 1 || O < 0 || V < 1 || !states || !original || !rl_ref || !switch_on || !detach_cnt || !chosen || (O > 0 && (!polygons || !valid)))
+        return fail(h, -1, "hint_switch: bad arguments");
+    if (B == 0) return 0;
+    HIP_OK(h, hipSetDevice(h->device));
+    HIP_OK(h, launch_hint_switch(B, N, O, V, polygons, valid, states, original, rl_ref, rl_steps, live, switch_distance, detach_distance,
+                                 detach_steps, switch_on, detach_cnt, chosen, pick_stream(h, stream)));
+    return 0;
+}
+
+// test hook: the tracker's assembly alone (fills the workspace records, nothing is solved)
+int32_t mpcgpu_debug_tracker_assemble(void* handle, const mpcgpu_tracker* t, const double* refs) {
+    Handle* h = (Handle*)handle;
+    if (!h) return -1;
+    if (int r = check_tracker(h, t)) return r;
+    if (!refs) return fail(h, -1, "refs is NULL");
+    HIP_OK(h, hipSetDevice(h->device));
+    h->capturing = false;
+    BatchPtrs io{};
+    if (int r = prepare(h, t->B, nullptr, h->stream, io, false, t, refs)) return r;
+    HIP_OK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int32_t mpcgpu_workspace_stride(void* handle) { Handle* h = (Handle*)handle; return h ? h->kp.ws_stride : -1; }
+int32_t mpcgpu_workspace_record(void* handle) { Handle* h = (Handle*)handle; return h ? h->kp.ws_lbs : -1; }
+
+int32_t mpcgpu_debug_read_workspace(void* handle, int32_t B, double* out) {
+    Handle* h = (Handle*)handle;
+    if (!h || !out || B < 0) return -1;
+    if ((size_t)B * h->kp.ws_stride * sizeof(double) > h->ws.cap) return fail(h, -4, "the workspace holds fewer than %d records", B);
+    HIP_OK(h, hipSetDevice(h->device));
+    HIP_OK(h, hipDeviceSynchronize());
+    HIP_OK(h, hipMemcpy(out, h->ws.ptr, (size_t)B * h->kp.ws_stride * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int32_t mpcgpu_debug_prep(void* handle, int32_t B, const double* p) {
+    Handle* h = (Handle*)handle;
+    if (!h || !p || B <= 0) return -1;
+    HIP_OK(h, hipSetDevice(h->device));
+    h->capturing = false;
+    if (int r = ensure(h, h->p, (size_t)B * h->kp.np * 8)) return r;
+    HIP_OK(h, hipMemcpyAsync(h->p.ptr, p, (size_t)B * h->kp.np * 8, hipMemcpyHostToDevice, h->stream));
+    BatchPtrs io{};
+    if (int r = prepare(h, B, (const double*)h->p.ptr, h->stream, io, false)) return r;
+    HIP_OK(h, hipStreamSynchronize(h->stream));
     return 0;
 }
 

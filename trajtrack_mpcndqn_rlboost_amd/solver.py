@@ -57,7 +57,9 @@ class _CConfig(C.Structure):
 EXPORTS = ("mpcgpu_abi_version", "mpcgpu_create", "mpcgpu_destroy", "mpcgpu_last_error", "mpcgpu_num_params",
            "mpcgpu_solve_batch", "mpcgpu_solve_batch_dev", "mpcgpu_cost_grad_batch", "mpcgpu_last_timing",
            "mpcgpu_last_eval_counts", "mpcgpu_last_shape", "mpcgpu_last_waves_per_simd", "mpcgpu_reserve_shape",
-           "mpcgpu_set_option", "mpcgpu_last_problems_per_wavefront", "mpcgpu_last_latency_kernel", "mpcgpu_reserve_batch", "mpcgpu_last_table_kind")
+           "mpcgpu_set_option", "mpcgpu_last_problems_per_wavefront", "mpcgpu_last_latency_kernel", "mpcgpu_reserve_batch", "mpcgpu_last_table_kind", "mpcgpu_tracker_window_dev",
+           "mpcgpu_tracker_step_dev", "mpcgpu_rl_reference_dev", "mpcgpu_hint_switch_dev", "mpcgpu_debug_read_workspace",
+           "mpcgpu_workspace_stride", "mpcgpu_workspace_record", "mpcgpu_debug_prep", "mpcgpu_debug_tracker_assemble")
 
 
 def library_path() -> str:
@@ -71,6 +73,16 @@ def build_library(force: bool = False) -> str:
         cmd.append("-B")
     subprocess.check_call(cmd)
     return _LIB
+
+
+class CTracker(C.Structure):
+    """``mpcgpu_tracker`` (include/mpcgpu.h): device view of the tracker state of B robots."""
+    _fields_ = [("B", C.c_int32), ("ref_cap", C.c_int32), ("action_steps", C.c_int32), ("_pad", C.c_int32),
+                ("states", C.c_void_p), ("goals", C.c_void_p), ("last_actions", C.c_void_p), ("ref", C.c_void_p),
+                ("ref_len", C.c_void_p), ("idx_ref", C.c_void_p), ("stc", C.c_void_p), ("dyn", C.c_void_p),
+                ("other", C.c_void_p), ("pred_states", C.c_void_p), ("active", C.c_void_p),
+                ("tuning", C.c_double * 10), ("base_speed", C.c_double), ("low_speed", C.c_double),
+                ("stc_weight", C.c_double), ("dyn_weight", C.c_double)]
 
 
 _libs = {}
@@ -129,6 +141,26 @@ def load_library(path: Optional[str] = None):
     L.mpcgpu_last_problems_per_wavefront.restype = C.c_int32
     L.mpcgpu_reserve_shape.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.mpcgpu_reserve_shape.restype = C.c_int32
+    tp = C.POINTER(CTracker)
+    L.mpcgpu_tracker_window_dev.argtypes = [vp, tp, vp, vp]
+    L.mpcgpu_tracker_window_dev.restype = C.c_int32
+    L.mpcgpu_tracker_step_dev.argtypes = [vp, tp] + [vp] * 8 + [vp]
+    L.mpcgpu_tracker_step_dev.restype = C.c_int32
+    L.mpcgpu_rl_reference_dev.argtypes = [vp, C.c_int32, vp, C.c_int32, vp, C.c_double, C.c_int32, C.c_double, dp, vp, vp]
+    L.mpcgpu_rl_reference_dev.restype = C.c_int32
+    L.mpcgpu_hint_switch_dev.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, C.c_int32, vp,
+                                         C.c_double, C.c_double, C.c_double, vp, vp, vp, vp]
+    L.mpcgpu_hint_switch_dev.restype = C.c_int32
+    L.mpcgpu_debug_read_workspace.argtypes = [vp, C.c_int32, dp]
+    L.mpcgpu_debug_read_workspace.restype = C.c_int32
+    L.mpcgpu_workspace_stride.argtypes = [vp]
+    L.mpcgpu_workspace_stride.restype = C.c_int32
+    L.mpcgpu_workspace_record.argtypes = [vp]
+    L.mpcgpu_workspace_record.restype = C.c_int32
+    L.mpcgpu_debug_prep.argtypes = [vp, C.c_int32, dp]
+    L.mpcgpu_debug_prep.restype = C.c_int32
+    L.mpcgpu_debug_tracker_assemble.argtypes = [vp, tp, vp]
+    L.mpcgpu_debug_tracker_assemble.restype = C.c_int32
     L.mpcgpu_last_table_kind.argtypes = [vp]
     L.mpcgpu_last_table_kind.restype = C.c_int32
     L.mpcgpu_reserve_batch.argtypes = [vp, C.c_int32]
@@ -322,6 +354,53 @@ class BatchSolver:
         """Size the library-owned device buffers for batches of up to ``B`` problems now (needed before a
         ``solve_device`` call is captured into a hipGraph: nothing may be allocated inside a capture)."""
         self._check(self._L.mpcgpu_reserve_batch(self._h, int(B)), "mpcgpu_reserve_batch")
+
+    # -- batched tracker harness on the device (include/mpcgpu.h: mpcgpu_tracker_*; device_tracker.DeviceTracker) ------------
+    def tracker_window(self, view: "CTracker", refs_out, stream: Optional[int] = None):
+        self._check(self._L.mpcgpu_tracker_window_dev(self._h, C.byref(view), C.c_void_p(refs_out.data_ptr()), _stream_arg(stream)),
+                    "mpcgpu_tracker_window_dev")
+
+    def tracker_step(self, view: "CTracker", refs, out: dict, initial_guess=None, stream: Optional[int] = None):
+        """One tick of all robots: termination test, assembly (compact record, no padded vector), solve, taken / predicted
+        states.  ``out``: ``u [B,2N], cost [B], status [B]`` and optionally ``inner_it, outer_it, actions [B,2]``."""
+        def ptr(t):
+            return None if t is None else C.c_void_p(t.data_ptr())
+        self._check(self._L.mpcgpu_tracker_step_dev(self._h, C.byref(view), ptr(refs), ptr(initial_guess), ptr(out["u"]),
+                                                    ptr(out["cost"]), ptr(out["status"]), ptr(out.get("inner_it")),
+                                                    ptr(out.get("outer_it")), ptr(out.get("actions")), _stream_arg(stream)),
+                    "mpcgpu_tracker_step_dev")
+
+    def rl_reference(self, agent, action, ts: float, steps: int, ref_speed: float, limits, rl_ref, stream: Optional[int] = None):
+        lim = (C.c_double * 8)(*[float(v) for v in limits])
+        self._check(self._L.mpcgpu_rl_reference_dev(self._h, int(agent.shape[0]), C.c_void_p(agent.data_ptr()), int(agent.stride(0)),
+                                                    C.c_void_p(action.data_ptr()), float(ts), int(steps), float(ref_speed), lim,
+                                                    C.c_void_p(rl_ref.data_ptr()), _stream_arg(stream)), "mpcgpu_rl_reference_dev")
+
+    def hint_switch(self, polygons, valid, states, original, rl_ref, live, distances, switch_on, detach_cnt, chosen,
+                    stream: Optional[int] = None):
+        B, N = int(original.shape[0]), int(original.shape[1])
+        O, V = int(polygons.shape[1]), int(polygons.shape[2])
+        self._check(self._L.mpcgpu_hint_switch_dev(
+            self._h, B, N, O, V, C.c_void_p(polygons.data_ptr()), C.c_void_p(valid.data_ptr()), C.c_void_p(states.data_ptr()),
+            C.c_void_p(original.data_ptr()), C.c_void_p(rl_ref.data_ptr()), int(rl_ref.shape[1]),
+            None if live is None else C.c_void_p(live.data_ptr()), float(distances[0]), float(distances[1]), float(distances[2]),
+            C.c_void_p(switch_on.data_ptr()), C.c_void_p(detach_cnt.data_ptr()), C.c_void_p(chosen.data_ptr()), _stream_arg(stream)),
+            "mpcgpu_hint_switch_dev")
+
+    def debug_workspace(self, B: int):
+        """Test hook: (records [B, stride], length of the compact record at the start of each)."""
+        stride, rec = int(self._L.mpcgpu_workspace_stride(self._h)), int(self._L.mpcgpu_workspace_record(self._h))
+        out = np.empty((B, stride))
+        self._check(self._L.mpcgpu_debug_read_workspace(self._h, B, _dp(out)), "mpcgpu_debug_read_workspace")
+        return out, rec
+
+    def debug_prep(self, p):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        self._check(self._L.mpcgpu_debug_prep(self._h, int(p.shape[0]), _dp(p)), "mpcgpu_debug_prep")
+
+    def debug_tracker_assemble(self, view: "CTracker", refs):
+        self._check(self._L.mpcgpu_debug_tracker_assemble(self._h, C.byref(view), C.c_void_p(refs.data_ptr())),
+                    "mpcgpu_debug_tracker_assemble")
 
     def release_shape(self):
         self._check(self._L.mpcgpu_reserve_shape(self._h, -1, -1, -1, 0), "mpcgpu_reserve_shape")
