@@ -7,6 +7,7 @@ sys.path.insert(0, ROOT)
 from trajtrack_mpcndqn_rlboost_amd import MpcConfig
 from trajtrack_mpcndqn_rlboost_amd.dqn import QNetwork
 hybrid = importlib.import_module("trajtrack_mpcndqn_rlboost_amd.hybrid")
+device_hybrid = importlib.import_module("trajtrack_mpcndqn_rlboost_amd.device_hybrid")
 metrics = importlib.import_module("trajtrack_mpcndqn_rlboost_amd.metrics")
 
 
@@ -39,7 +40,10 @@ if __name__ == "__main__":
     cfg = MpcConfig(os.path.join(ROOT, "config", "mpc_longiter.yaml"))
     for mode, name in ((1, "pure MPC"), (2, "hybrid"), (0, "pure DQN")):
         rng = np.random.default_rng(3 + 1000 * rank)
-        run = hybrid.BatchedHybrid(cfg, [scene(rng) for _ in range(B)], q, decision_mode=mode, device=dev)
+        # modes 1 and 2: the whole tick on the device (HYBRID_HOST_TICK=1 selects the host loop for comparison)
+        on_device = mode != 0 and not os.environ.get("HYBRID_HOST_TICK")
+        cls = device_hybrid.DeviceHybrid if on_device else hybrid.BatchedHybrid
+        run = cls(cfg, [scene(rng) for _ in range(B)], q, decision_mode=mode, device=dev)
         t0 = time.perf_counter()
         out = run.run(steps, record=True)
         dt = time.perf_counter() - t0

@@ -428,10 +428,6 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
         if (int r = ensure(h, h->counts, CNT_WORDS * sizeof(int))) return r;
         if (int r = ensure(h, h->evals, (size_t)B * 2 * sizeof(int32_t))) return r;
         io.p = p; io.ws = (double*)h->ws.ptr; io.counts = nullptr; io.evals = (int32_t*)h->evals.ptr;
-        if (trk) {   // the records of the latency kernel come from the tracker's arrays: one more (tiny) launch in front of it
-            hipLaunchKernelGGL(tracker_assemble_kernel, dim3(B), dim3(WAVE), 0, s, h->kp, tracker_view(h, trk), refs, io.ws, (int*)nullptr);
-            HIP_OK(h, hipGetLastError());
-        }
         io.u0 = u0; io.y0 = y0; io.c0 = c0; io.u = u; io.cost = cost; io.status = status; io.inner_it = inner_it;
         io.outer_it = outer_it; io.fpr = fpr; io.f2norm = f2norm; io.y_out = y_out; io.ms = ms;
         KParams kt = h->kp;
@@ -439,7 +435,12 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
         const size_t lds_t = kt.l_total * sizeof(double);
         // + 256: prep_problem's static __shared__ table travels on top of the dynamic carve
         if (lds_t + 256 <= 160 * 1024) {   // else (long horizons with many obstacle slots): the throughput kernel below
-            if (!h->capturing) { HIP_OK(h, hipEventRecord(h->ev[0], s)); HIP_OK(h, hipEventRecord(h->ev[1], s)); HIP_OK(h, hipEventRecord(h->ev[2], s)); }
+            if (!h->capturing) HIP_OK(h, hipEventRecord(h->ev[0], s));
+            if (trk) {   // the records of the latency kernel come from the tracker's arrays: one more (tiny) launch in front of it
+                hipLaunchKernelGGL(tracker_assemble_kernel, dim3(B), dim3(WAVE), 0, s, h->kp, tracker_view(h, trk), refs, io.ws, (int*)nullptr);
+                HIP_OK(h, hipGetLastError());
+            }
+            if (!h->capturing) { HIP_OK(h, hipEventRecord(h->ev[1], s)); HIP_OK(h, hipEventRecord(h->ev[2], s)); }
 #define LAUNCH_TEAM(NT)                                                                                              \
     do {                                                                                                             \
         auto kern = solve_kernel_team<NT>;                                                                           \
