@@ -185,7 +185,8 @@ int32_t mpcgpu_set_option(void* handle, int32_t option, double value);
  * bitwise identical results. */
 int32_t mpcgpu_last_waves_per_simd(void* handle);
 
-/* 1 when the last solve call ran the latency kernel (MPCGPU_OPT_TEAM_BATCH), else 0. */
+/* Wavefronts per problem of the latency kernel when the last solve call ran it (MPCGPU_OPT_TEAM_BATCH): 4, or 2 for batches
+ * between two and four problems per compute unit; 0 = the throughput kernel ran. */
 int32_t mpcgpu_last_latency_kernel(void* handle);
 
 /* Dynamic-obstacle tables of the last solve / cost_grad launch, in the coding of mpcgpu_reserve_shape's var_shape: 1 general

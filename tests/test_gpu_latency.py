@@ -117,3 +117,45 @@ def test_wall_clock_limit_ends_the_solve_with_its_own_status(kernel):
     free = BatchSolver(make_cfg(20, solver_max_duration_micros=0, solver_max_inner_iterations=30, solver_max_outer_iterations=2), **kw)
     assert np.all(free.solve(hard).status == 1)
     free.close()
+
+
+@pytest.mark.parametrize("N,B,caps", [(20, 700, (120, 4)), (20, 1024, (60, 3)), (40, 600, (60, 3))])
+def test_mid_batches_run_two_wavefronts_per_problem_bitwise_equal_too(N, B, caps):
+    """Between two and four problems per compute unit (round 3): the compaction is its own launch, the tables are sized from the
+    batch's maxima and a problem gets TWO wavefronts (Lipschitz test + tau = 1 side by side, then two trials per pass), so the
+    whole batch is resident at once.  Same device functions: every output is bitwise that of the throughput kernel."""
+    cfg = make_cfg(N, solver_max_inner_iterations=caps[0], solver_max_outer_iterations=caps[1])
+    sc = scenes.make_batch(cfg, B, n_dyn=4, seed=123, dyn_clearance=0.1, box_clearance=0.3)
+    fast, seq = BatchSolver(cfg), BatchSolver(cfg, latency_batch=0)
+    a, b = fast.solve(sc["p"]), seq.solve(sc["p"])
+    took = fast._L.mpcgpu_last_latency_kernel(fast._h)
+    # N_hor = 20: four two-wavefront workgroups fit a compute unit; N_hor = 40: they do not, the throughput kernel runs
+    assert took == (2 if N == 20 else 0) and seq._L.mpcgpu_last_latency_kernel(seq._h) == 0
+    assert fast.last_shape()["max_dyn"] == 4                      # tables from the batch, not from the configured maxima
+    _same(a, b)
+    ea, eb = fast.last_eval_counts(B), seq.last_eval_counts(B)
+    assert np.array_equal(ea[0], eb[0]) and np.array_equal(ea[1], eb[1])
+    fast.close(); seq.close()
+
+
+def test_reserved_small_batch_takes_the_latency_kernel_with_tables_of_the_reservation():
+    import torch
+    cfg = make_cfg(20, solver_max_inner_iterations=80, solver_max_outer_iterations=3)
+    B = 200
+    sc = scenes.make_batch(cfg, B, n_dyn=3, seed=9, dyn_clearance=0.1, box_clearance=0.3)
+    dev = torch.device("cuda", 0)
+    p = torch.from_numpy(sc["p"]).to(dev)
+    out = dict(u=torch.empty(B, 40, dtype=torch.float64, device=dev), cost=torch.empty(B, dtype=torch.float64, device=dev),
+               status=torch.empty(B, dtype=torch.int32, device=dev))
+    bs = BatchSolver(cfg)
+    bs.reserve_shape(max_static=5, max_fleet=0, max_dyn=2, var_shape=True)        # one row too few for these scenes
+    bs.solve_device(p, out, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert bs._L.mpcgpu_last_latency_kernel(bs._h) == 4
+    assert (out["status"] == 4).all()                                             # reported, not solved
+    bs.reserve_shape(max_static=5, max_fleet=0, max_dyn=3, var_shape=True)
+    bs.solve_device(p, out, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    ref = BatchSolver(cfg, latency_batch=0).solve(sc["p"])
+    assert np.array_equal(out["u"].cpu().numpy(), ref.solution) and np.array_equal(out["status"].cpu().numpy(), ref.status)
+    bs.close()

@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #ifndef MPC_ITEM_LOOP
 #define MPC_ITEM_LOOP _Pragma("unroll 1")  // item loops: keep the loads of one iteration in flight, not of all
@@ -1120,7 +1121,7 @@ struct LbMem {
     double* LOLD;   // [N][4]: previous (u, gamma fpr)
     double* LRHO;   // [mem]
     double* LALPHA; // [mem]        two-loop form only
-    double* GG;     // [2 mem][mem] Gram form only: rows 0..mem-1: s_i.y_j, rows mem..2mem-1: y_i.y_j (slot indices)
+    double* GG;     // Gram form only: [mem][mem] s_i.y_j (slot indices), then y_i.y_j packed symmetric: entry (i >= j) at i(i+1)/2 + j
     double* XA;     // Gram form only: scratch, see PanocLbfgsGram
 };
 
@@ -1283,6 +1284,7 @@ struct PanocLbfgsGram {
     double hgamma = 1.0;
     __device__ __forceinline__ void flush() { active = 0; first = true; }
 
+    static __device__ __forceinline__ int yy_index(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
     template <int NT, int MEMT>
     struct Dims {
         int N, mem, R, G, CL, G2, CR;
@@ -1392,15 +1394,14 @@ struct PanocLbfgsGram {
                     m.GG[ro.slot * mem + h] = ay;                  // s_q . y_new
                     if (ro.slot == h) pr = sr;
                 } else {
-                    m.GG[(mem + ro.slot) * mem + h] = ay;          // y_q . y_new
-                    m.GG[(mem + h) * mem + ro.slot] = ay;
+                    m.GG[mem * mem + yy_index(ro.slot, h)] = ay;   // y_q . y_new (symmetric: stored once)
                     if (ro.slot == h) pr = yr;
                 }
             }
             wave_sync();
             if (lane < mem) m.GG[h * mem + lane] = 0.0;
             if (lane == 0) {
-                m.GG[(mem + h) * mem + h] = yy;
+                m.GG[mem * mem + yy_index(h, h)] = yy;
                 m.LRHO[h] = 1.0 / ys;
             }
             hgamma = P::uni(ys / yy);
@@ -1438,16 +1439,20 @@ struct PanocLbfgsGram {
             for (int tt = 0; tt < CRT; ++tt) mq[tt] = mcol[tt * N];
         }
         // first loop, newest pair first: alpha_p = rho_p s_p.q_p; every row's product with q advances by -alpha_p (row . y_p)
-        const double* grow = m.GG + (ro.isy * mem + ro.slot_a) * mem;
+        // s-rows read row slot of s_i.y_j; y-rows read entry (slot, sp) of the packed symmetric y_i.y_j
+        const double* gs = m.GG + ro.slot_a * mem;
+        const double* gy = m.GG + mem * mem;
+        const int tri_l = ro.slot_a * (ro.slot_a + 1) / 2;
+        auto g1 = [&](int sp) { return ro.isy ? gy[sp <= ro.slot_a ? tri_l + sp : sp * (sp + 1) / 2 + ro.slot_a] : gs[sp]; };
         double acc = pr;
         {
             int sp = head;
-            double gnext = grow[sp];
+            double gnext = g1(sp);
             for (int p = 0; p < active; ++p) {
                 const double gcur = gnext;
                 const int sl = sp * D.G + D.G - 1;
                 sp = sp + 1 >= mem ? 0 : sp + 1;
-                gnext = grow[sp];   // one step ahead of the broadcast that needs it
+                gnext = g1(sp);   // one step ahead of the broadcast that needs it
                 const double al = readlane_d(rho_l * acc, sl);
                 acc = __builtin_fma(-al, gcur, acc);
             }
@@ -1518,11 +1523,13 @@ struct PanocLbfgsGram {
 #ifndef MPC_LBFGS_GRAM
 #define MPC_LBFGS_GRAM 1
 #endif
-template <bool DUO> struct LbfgsOf { using type = PanocLbfgsGram; };
-template <> struct LbfgsOf<true> { using type = PanocLbfgs; };
-#if !MPC_LBFGS_GRAM
-template <> struct LbfgsOf<false> { using type = PanocLbfgs; };
-#endif
+// The Gram form pays when a horizon leaves most of the wavefront idle in the two-loop reductions AND pass 2 can split the rows
+// over lane groups (64 / N >= 2): measured -7 % at N_hor = 20, but +7 % at N_hor = 40 (one lane group does all 2 mem rows in
+// pass 2, the reductions already use 40 of 64 lanes) -- profiles/r03_lbfgs_gram_ab.txt.  So: Gram for compiled horizons up to
+// 32, two-loop otherwise (N_hor = 40 and the runtime-horizon kernel, as in rounds 1-2).
+template <int NT> struct GramFor { static constexpr bool value = MPC_LBFGS_GRAM && NT != 0 && WAVE / (NT ? NT : 1) >= 2; };
+template <bool DUO, int NT> struct LbfgsOf { using type = PanocLbfgs; };
+template <> struct LbfgsOf<false, 20> { using type = std::conditional<GramFor<20>::value, PanocLbfgsGram, PanocLbfgs>::type; };
 // compile-time L-BFGS memory of the kernels with a compile-time horizon (the launcher sends other memories to the generic kernel)
 template <int NT> struct MemOf { static constexpr int value = NT ? 10 : 0; };
 
@@ -1628,7 +1635,7 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
     double akkt_tol = kp.init_tol;
     int iter = 0, num_iter = 0, lip_it = 0, nls = 0;
     bool cont_iters = true, cont_time = true;
-    typename LbfgsOf<P::DUO>::type lb;
+    typename LbfgsOf<P::DUO, NT>::type lb;
     // ALM cache
     int alm_iteration = 0, num_outer = 1, inner_total = 0, status = 0;
     double dy_norm = 0, dy_norm_plus = 0, f2_norm = 0, f2_norm_plus = 0, last_fpr = 0, f_final = 0;

@@ -23,13 +23,17 @@
 
 namespace mpcgpu {
 
-constexpr int TEAM_WAVES = 4;
+constexpr int TEAM_WAVES = 4;   // wavefronts per problem of the latency kernel proper; the mid-batch form runs 2 (template parameter TW)
 constexpr int TEAM_XCH = 8;  // doubles per wavefront in the exchange area
 
 enum { TS_INIT0 = 0, TS_INIT1, TS_FIRST, TS_SPEC, TS_LIPSEQ, TS_BATCH, TS_FALLBACK, TS_OUTER };
 
-template <int NT>
-__global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams kp, BatchPtrs io, int B) {
+// TW = 4: wavefront 0 takes the Lipschitz test, wavefronts 1-3 the trials tau = 1, 1/2, 1/4 (1.38 passes per PANOC step on the
+// benchmark scenes).  TW = 2 (round 3, batches between 2 and 4 problems per compute unit): Lipschitz test + tau = 1 side by side
+// -- 67 % of the steps end there -- then two trials per pass; a workgroup is half as big, so twice as many problems are resident
+// and such a batch runs in ONE round instead of two.  Same device functions, same bits.
+template <int NT, int TW>
+__global__ __launch_bounds__(WAVE * TW) void solve_kernel_team(KParams kp, BatchPtrs io, int B) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     using P = Solo<NT>;
     constexpr bool SC = false;  // general tables: no batch-wide shape information is needed before the launch
@@ -39,6 +43,26 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
     const long long t_start = wall_clock64();
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1), mem = kp.mem;
     double* ws = io.ws + (size_t)b * kp.ws_stride;
+    if (kp.reserved) {   // tables sized from promised / measured maxima: a problem beyond them is reported, not solved (solve_body)
+        const bool over = (int)uniform(ws[H_KS]) > kp.mKs || (int)uniform(ws[H_KF]) > kp.mKf || (int)uniform(ws[H_KD]) > kp.mKd;
+        if (over) {
+            const double nan = __builtin_nan("");
+            if (wid == 0 && lane < N) {
+                io.u[(size_t)b * 2 * N + 2 * lane] = 0.0; io.u[(size_t)b * 2 * N + 2 * lane + 1] = 0.0;
+                if (io.y_out) { io.y_out[(size_t)b * 2 * N + lane] = nan; io.y_out[(size_t)b * 2 * N + N + lane] = nan; }
+            }
+            if (threadIdx.x == 0) {
+                io.cost[b] = nan; io.status[b] = 4;
+                if (io.inner_it) io.inner_it[b] = 0;
+                if (io.outer_it) io.outer_it[b] = 0;
+                if (io.evals) { io.evals[2 * b] = 0; io.evals[2 * b + 1] = 0; }
+                if (io.fpr) io.fpr[b] = nan;
+                if (io.f2norm) io.f2norm[b] = nan;
+                if (io.ms) io.ms[b] = 0.0;
+            }
+            return;
+        }
+    }
     // io.p == NULL: the record was already written by the tracker's assembly kernel (mpc_tracker.hpp)
     if (wid == 0 && io.p) prep_problem(kp, ParamVector{io.p + (size_t)b * kp.np}, ws, io.counts, lane);
     __syncthreads();
@@ -60,7 +84,7 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
         cx.seg = lds + kp.l_seg; cx.stc = lds + kp.l_stc; cx.fxy = lds + kp.l_fxy;
         cx.dyn = lds + kp.l_dyn; cx.dync = cx.dyn; cx.qd = cx.dyn;
         cx.pos = mine + kp.l_pos; cx.H = mine + kp.l_H; cx.W = mine + kp.l_W; cx.part = mine + kp.l_part; cx.stash = mine + kp.l_stash;
-        const int T = WAVE * TEAM_WAVES;
+        const int T = WAVE * TW;
         for (int i = threadIdx.x; i < N * SEGW; i += T) cx.seg[i] = ws[kp.ws_seg + i];
         for (int i = threadIdx.x; i < cx.Ks * STCW; i += T) cx.stc[i] = ws[kp.ws_stc + i];
         for (int i = threadIdx.x; i < cx.Kf * N * 2; i += T) cx.fxy[i] = ws[kp.ws_fxy + i];
@@ -77,7 +101,7 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
     lm.XA = cx.pos;
     for (int i = lane; i < (2 * mem + 1) * N; i += WAVE) reinterpret_cast<double2*>(lm.LM)[i] = make_double2(0.0, 0.0);
     double* XF = lds + kp.l_xch;                          // [TEAM_WAVES][TEAM_XCH]: per-wavefront verdicts of a pass
-    double* XV = XF + TEAM_WAVES * TEAM_XCH;              // [N][6] + 4: the winner's point, gradient, half step and scalars
+    double* XV = XF + TW * TEAM_XCH;                      // [N][6] + 4: the winner's point, gradient, half step and scalars
     const bool vl = cx.vl;
     const int MAX_LIP_IT = 10, MAX_LS_IT = 10;
 
@@ -96,7 +120,7 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
     double akkt_tol = kp.init_tol;
     int iter = 0, num_iter = 0, lip_it = 0, nls = 0, t0 = 0, head_spec = 0;
     bool cont_iters = true, cont_time = true;
-    typename LbfgsOf<false>::type lb;
+    typename LbfgsOf<false, NT>::type lb;
     int alm_iteration = 0, num_outer = 1, inner_total = 0, status = 0;
     double dy_norm = 0, dy_norm_plus = 0, f2_norm = 0, f2_norm_plus = 0, last_fpr = 0, f_final = 0;
     int n_eval = 0, n_eval_grad = 0;  // evaluations of the SEQUENTIAL algorithm (the speculative ones are not counted)
@@ -116,7 +140,7 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
     auto publish = [&](double flag, double* all) {
         if (lane == 0) XF[wid * TEAM_XCH + pub_slot] = flag;
         __syncthreads();
-        for (int j = 0; j < TEAM_WAVES; ++j) all[j] = uniform(XF[j * TEAM_XCH + pub_slot]);
+        for (int j = 0; j < TW; ++j) all[j] = uniform(XF[j * TEAM_XCH + pub_slot]);
         pub_slot ^= 1;
     };
     // the winning wavefront hands over (point, gradient, half step; cost, ||grad||^2, ||gradient step - half step||^2)
@@ -206,7 +230,7 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
                 panoc_envelope_sums<P>(kp, vl, ev, ew, gamma, o.gv, o.gw, thv, thw, tgg, td2h);
                 flag = panoc_fbe(uniform(o.psi), gamma, ig, tgg, td2h) > rhs ? 0.0 : 1.0;  // 1 = accepted
             }
-            double all[TEAM_WAVES];
+            double all[TW];
             publish(flag, all);
             ++n_eval;
             if (all[0] != 0.0) {
@@ -221,7 +245,7 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
                 continue;
             }
             int winner = 0;
-            for (int j = TEAM_WAVES - 1; j >= 1; --j) if (all[j] != 0.0) winner = j;
+            for (int j = TW - 1; j >= 1; --j) if (all[j] != 0.0) winner = j;
             if (winner) {
                 nls = winner - 1;
                 n_eval += nls + 1; n_eval_grad += nls + 1;
@@ -229,8 +253,8 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
                 ++iter;
                 step_begin = true;
             } else {
-                n_eval += TEAM_WAVES - 1; n_eval_grad += TEAM_WAVES - 1;
-                t0 = TEAM_WAVES - 1;
+                n_eval += TW - 1; n_eval_grad += TW - 1;
+                t0 = TW - 1;
                 trial_point(exp2(-(double)(t0 + wid)));
                 want_grad = true; state = TS_BATCH;
                 continue;
@@ -242,10 +266,10 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
             const int t = t0 + wid;
             const bool accepted = !(panoc_fbe(uniform(o.psi), gamma, ig, tgg, td2h) > rhs);
             const double flag = t > MAX_LS_IT ? 0.0 : (accepted ? 1.0 : (t == MAX_LS_IT ? 2.0 : 0.0));  // 2 = last trial, rejected
-            double all[TEAM_WAVES];
+            double all[TW];
             publish(flag, all);
             int winner = -1;
-            for (int j = TEAM_WAVES - 1; j >= 0; --j) if (all[j] != 0.0) winner = j;
+            for (int j = TW - 1; j >= 0; --j) if (all[j] != 0.0) winner = j;
             if (winner >= 0) {
                 nls = t0 + winner;
                 n_eval += winner + 1; n_eval_grad += winner + 1;
@@ -259,8 +283,8 @@ __global__ __launch_bounds__(WAVE * TEAM_WAVES) void solve_kernel_team(KParams k
                 ++iter;
                 step_begin = true;
             } else {
-                n_eval += TEAM_WAVES; n_eval_grad += TEAM_WAVES;
-                t0 += TEAM_WAVES;
+                n_eval += TW; n_eval_grad += TW;
+                t0 += TW;
                 trial_point(exp2(-(double)(t0 + wid)));
                 continue;
             }

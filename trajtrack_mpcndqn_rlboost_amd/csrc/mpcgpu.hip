@@ -45,7 +45,7 @@ struct Handle {
     int last_min_waves = 0;   // launch-bounds variant of the last solve (3 or 4 wavefronts per SIMD)
     int num_cus = 256;
     int team_max_batch = -1;  // MPCGPU_OPT_TEAM_BATCH: largest batch solved by the latency kernel (-1: 4 x number of CUs)
-    int last_team = 0;        // 1: the last solve ran the latency kernel (one problem per workgroup of four wavefronts)
+    int last_team = 0;        // wavefronts per problem of the latency kernel the last solve ran (4 or 2); 0: throughput kernel
     int pairing = -1;   // MPCGPU_OPT_PAIRING: -1 automatic, 0 one problem per wavefront, 1 two per wavefront (N_hor = 20)
     int last_pairing = 0;  // layout of the last solve / cost_grad launch
     int trace_cap = 0;  // -DMPC_TRACE builds: PANOC steps recorded per problem (0 = tracing off)
@@ -188,10 +188,12 @@ int part_doubles(const KParams& k) {
 }
 // The stash (6 doubles per step) and the positions before it are dead between two evaluations; the Gram form of the L-BFGS step
 // uses them as scratch there: the operands of pass 1 ((r, s, y) pairs of every chunk slot) followed by the row coefficients.
+// the kernels evaluate the L-BFGS operator in Gram form for the compiled horizons with 64 / N >= 2 (mpc_kernels.hpp GramFor)
+bool gram_layout(const KParams& k) { return MPC_LBFGS_GRAM && k.N == 20 && k.mem == 10; }
 int stash_doubles(const KParams& k) {
     const int N = k.N;
     int need = N * 6;
-    if (MPC_LBFGS_GRAM) {
+    if (gram_layout(k)) {
         const int R = 2 * k.mem, G = (WAVE / 2) / k.mem, CL = (N + G - 1) / G, G2 = WAVE / N, CR = (R + G2 - 1) / G2;
         int scratch = even(G * CL * 4) + even(G2 * CR);      // pass-1 operands (r, y) + row coefficients
         const int p2 = (G2 - 1) * N * 2;                      // partials of pass 2 (they reuse the operand area)
@@ -235,7 +237,7 @@ void fill_lds_layout(KParams& k, int mKs, int mKf, int mKd, bool shape_const, bo
     k.l_rho = o; o += even(k.mem);
     k.l_alpha = o;
     k.l_gg = o;
-    if (MPC_LBFGS_GRAM) o += 2 * k.mem * k.mem;  // Gram matrices s_i.y_j, y_i.y_j (the alpha scratch of the two-loop form is not needed)
+    if (gram_layout(k)) o += even(k.mem * k.mem + k.mem * (k.mem + 1) / 2);  // Gram matrices: s_i.y_j full, y_i.y_j packed symmetric (the alpha scratch of the two-loop form is not needed)
     else o += even(k.mem);
     k.l_old = o;
     if (lbfgs_in_lds) o += N * 4;
@@ -245,9 +247,11 @@ void fill_lds_layout(KParams& k, int mKs, int mKf, int mKd, bool shape_const, bo
 // LDS carve of the latency kernel (mpc_team.hpp): tables for the CONFIGURED maxima (general dynamic-obstacle records), shared
 // by the four wavefronts of the workgroup; then the exchange area; then one work block per wavefront (positions, stash, hinge
 // matrix / item partials, L-BFGS memory).  Offsets of the work-block fields are those of wavefront 0.
-[[maybe_unused]] void fill_team_layout(KParams& k, const mpcgpu_config& c) {  // unused in -DMPC_TRACE builds
+// `tw` wavefronts per problem; tables for (mKs, mKf, mKd) active rows -- the configured maxima (nothing known before the launch) or
+// the maxima of the batch / of a reservation (mid-batch form).
+[[maybe_unused]] void fill_team_layout(KParams& k, int tw, int mKs, int mKf, int mKd) {  // unused in -DMPC_TRACE builds
     const int N = k.N;
-    k.mKs = c.Nstcobs; k.mKf = c.Nother; k.mKd = c.Ndynobs;
+    k.mKs = mKs; k.mKf = mKf; k.mKd = mKd;
     int o = 0;
     k.l_seg = o; o += even(N * SEGW);
     k.l_stc = o; o += k.mKs * STCW;
@@ -255,7 +259,7 @@ void fill_lds_layout(KParams& k, int mKs, int mKf, int mKd, bool shape_const, bo
     k.l_dyn = o; o += even(k.mKd * N * DYNW);
     k.l_dync = k.l_dyn; k.l_qd = k.l_dyn;
     k.l_hd = o; o += 64;
-    k.l_xch = o; o += TEAM_WAVES * TEAM_XCH + even(N * 6 + 4);
+    k.l_xch = o; o += tw * TEAM_XCH + even(N * 6 + 4);
     const int base = o;
     k.l_pos = o; o += N * 2;
     k.l_stash = o; o += stash_doubles(k);
@@ -267,10 +271,10 @@ void fill_lds_layout(KParams& k, int mKs, int mKf, int mKd, bool shape_const, bo
     k.l_rho = o; o += even(k.mem);
     k.l_alpha = o;
     k.l_gg = o;
-    if (MPC_LBFGS_GRAM) o += 2 * k.mem * k.mem; else o += even(k.mem);
+    if (gram_layout(k)) o += even(k.mem * k.mem + k.mem * (k.mem + 1) / 2); else o += even(k.mem);
     k.l_old = o; o += N * 4;
     k.l_wstride = even(o - base);
-    k.l_total = base + TEAM_WAVES * k.l_wstride;
+    k.l_total = base + tw * k.l_wstride;
     k.reserved = 0;
 }
 
@@ -422,47 +426,83 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
     // configured maxima -- one launch, nothing read back.  Results are bitwise those of the throughput kernel.
     const int team_cap = h->team_max_batch >= 0 ? h->team_max_batch : 4 * h->num_cus;  // measured break-even: 1000-1500 problems (tools/team_sweep.py)
     h->last_team = 0;
+    bool prepared = false;
 #ifndef MPC_TRACE
-    if (B <= team_cap && !h->reserved && !use_duo(h)) {
+#define LAUNCH_TEAM(NT, TW, KT, LDS_T)                                                                               \
+    do {                                                                                                             \
+        auto kern = solve_kernel_team<NT, TW>;                                                                       \
+        if (int r_ = opt_in_lds(h, (const void*)kern, (LDS_T))) return r_;                                           \
+        hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE * TW), (LDS_T), s, KT, io, B);                                   \
+    } while (0)
+#define LAUNCH_TEAM_N(TW, KT, LDS_T)                                                                                 \
+    switch (compiled_horizon(h)) {                                                                                   \
+        case 20: LAUNCH_TEAM(20, TW, KT, LDS_T); break;                                                              \
+        case 40: LAUNCH_TEAM(40, TW, KT, LDS_T); break;                                                              \
+        default: LAUNCH_TEAM(0, TW, KT, LDS_T); break;                                                               \
+    }
+    auto team_done = [&](const KParams& kt, size_t lds_t, int tw) {
+        h->last_B = B; h->last_team = tw; h->last_pairing = 0; h->last_min_waves = 1;
+        h->last_shape[0] = kt.mKs; h->last_shape[1] = kt.mKf; h->last_shape[2] = kt.mKd; h->last_shape[3] = (int)lds_t;
+    };
+    if (B <= team_cap && !use_duo(h)) {
         if (int r = ensure(h, h->ws, (size_t)B * h->kp.ws_stride * sizeof(double))) return r;
         if (int r = ensure(h, h->counts, CNT_WORDS * sizeof(int))) return r;
         if (int r = ensure(h, h->evals, (size_t)B * 2 * sizeof(int32_t))) return r;
         io.p = p; io.ws = (double*)h->ws.ptr; io.counts = nullptr; io.evals = (int32_t*)h->evals.ptr;
         io.u0 = u0; io.y0 = y0; io.c0 = c0; io.u = u; io.cost = cost; io.status = status; io.inner_it = inner_it;
         io.outer_it = outer_it; io.fpr = fpr; io.f2norm = f2norm; io.y_out = y_out; io.ms = ms;
-        KParams kt = h->kp;
-        fill_team_layout(kt, h->cfg);
-        const size_t lds_t = kt.l_total * sizeof(double);
-        // + 256: prep_problem's static __shared__ table travels on top of the dynamic carve
-        if (lds_t + 256 <= 160 * 1024) {   // else (long horizons with many obstacle slots): the throughput kernel below
-            if (!h->capturing) HIP_OK(h, hipEventRecord(h->ev[0], s));
-            if (trk) {   // the records of the latency kernel come from the tracker's arrays: one more (tiny) launch in front of it
-                hipLaunchKernelGGL(tracker_assemble_kernel, dim3(B), dim3(WAVE), 0, s, h->kp, tracker_view(h, trk), refs, io.ws, (int*)nullptr);
+        // (A) up to two problems per compute unit, nothing promised: ONE launch -- four wavefronts per problem, compaction fused,
+        //     tables for the configured maxima, nothing read back.
+        if (B <= 2 * h->num_cus && !h->reserved) {
+            KParams kt = h->kp;
+            fill_team_layout(kt, TEAM_WAVES, h->cfg.Nstcobs, h->cfg.Nother, h->cfg.Ndynobs);
+            const size_t lds_t = kt.l_total * sizeof(double);
+            // + 256: prep_problem's static __shared__ table travels on top of the dynamic carve
+            if (lds_t + 256 <= 160 * 1024) {   // else (long horizons with many obstacle slots): the throughput kernel below
+                if (!h->capturing) HIP_OK(h, hipEventRecord(h->ev[0], s));
+                if (trk) {   // the records come from the tracker's arrays: one more (tiny) launch in front of the solve
+                    hipLaunchKernelGGL(tracker_assemble_kernel, dim3(B), dim3(WAVE), 0, s, h->kp, tracker_view(h, trk), refs, io.ws, (int*)nullptr);
+                    HIP_OK(h, hipGetLastError());
+                }
+                if (!h->capturing) { HIP_OK(h, hipEventRecord(h->ev[1], s)); HIP_OK(h, hipEventRecord(h->ev[2], s)); }
+                LAUNCH_TEAM_N(TEAM_WAVES, kt, lds_t)
                 HIP_OK(h, hipGetLastError());
+                if (!h->capturing) HIP_OK(h, hipEventRecord(h->ev[3], s));
+                h->timing_valid = !h->capturing;
+                team_done(kt, lds_t, TEAM_WAVES);
+                return 0;
             }
-            if (!h->capturing) { HIP_OK(h, hipEventRecord(h->ev[1], s)); HIP_OK(h, hipEventRecord(h->ev[2], s)); }
-#define LAUNCH_TEAM(NT)                                                                                              \
-    do {                                                                                                             \
-        auto kern = solve_kernel_team<NT>;                                                                           \
-        if (int r_ = opt_in_lds(h, (const void*)kern, lds_t)) return r_;                                             \
-        hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE * TEAM_WAVES), lds_t, s, kt, io, B);                             \
-    } while (0)
-            switch (compiled_horizon(h)) {
-                case 20: LAUNCH_TEAM(20); break;
-                case 40: LAUNCH_TEAM(40); break;
-                default: LAUNCH_TEAM(0); break;
-            }
-#undef LAUNCH_TEAM
+        }
+        // (B) up to four problems per compute unit (or a reservation): the compaction runs as its own launch, the tables are sized
+        //     from the batch's maxima (read back: microseconds against a solve of tens of milliseconds) or from the reservation, and
+        //     a problem gets TWO wavefronts when four such workgroups fit a compute unit -- the whole batch is resident at once.
+        if (int r = prepare(h, B, p, s, io, true, trk, refs)) return r;
+        prepared = true;
+        io.u0 = u0; io.y0 = y0; io.c0 = c0; io.u = u; io.cost = cost; io.status = status; io.inner_it = inner_it;
+        io.outer_it = outer_it; io.fpr = fpr; io.f2norm = f2norm; io.y_out = y_out; io.ms = ms;
+        io.evals = (int32_t*)h->evals.ptr;
+        const int tw = B <= 2 * h->num_cus ? TEAM_WAVES : 2;
+        KParams kt = h->kp;
+        fill_team_layout(kt, tw, h->kp.mKs, h->kp.mKf, h->kp.mKd);
+        kt.reserved = 1;                       // every problem is checked against the tables' size on the device
+        const size_t lds_t = kt.l_total * sizeof(double);
+        const int per_cu = tw == 2 ? 4 : 2;    // 256 VGPRs per wavefront: eight wavefronts per compute unit
+        if ((lds_t + 64) * per_cu <= 160 * 1024) {
+            io.p = nullptr;                    // the records exist already
+            if (!h->capturing) HIP_OK(h, hipEventRecord(h->ev[2], s));
+            if (tw == 2) { LAUNCH_TEAM_N(2, kt, lds_t) } else { LAUNCH_TEAM_N(TEAM_WAVES, kt, lds_t) }
             HIP_OK(h, hipGetLastError());
             if (!h->capturing) HIP_OK(h, hipEventRecord(h->ev[3], s));
             h->timing_valid = !h->capturing;
-            h->last_B = B; h->last_team = 1; h->last_pairing = 0; h->last_min_waves = 1;
-            h->last_shape[0] = kt.mKs; h->last_shape[1] = kt.mKf; h->last_shape[2] = kt.mKd; h->last_shape[3] = (int)lds_t;
+            team_done(kt, lds_t, tw);
             return 0;
         }
     }
+#undef LAUNCH_TEAM_N
+#undef LAUNCH_TEAM
 #endif
-    if (int r = prepare(h, B, p, s, io, true, trk, refs)) return r;
+    if (!prepared)
+        if (int r = prepare(h, B, p, s, io, true, trk, refs)) return r;
     io.u0 = u0; io.y0 = y0; io.c0 = c0; io.u = u; io.cost = cost; io.status = status; io.inner_it = inner_it;
     io.outer_it = outer_it; io.fpr = fpr; io.f2norm = f2norm; io.y_out = y_out; io.ms = ms;
     if (int r = ensure(h, h->evals, (size_t)B * 2 * sizeof(int32_t))) return r;
@@ -887,7 +927,7 @@ int32_t mpcgpu_last_waves_per_simd(void* handle) {
 
 int32_t mpcgpu_last_latency_kernel(void* handle) {
     Handle* h = (Handle*)handle;
-    return h ? h->last_team : -1;
+    return h ? h->last_team : -1;   // 0: throughput kernel; 4 / 2: wavefronts per problem of the latency kernel
 }
 
 int32_t mpcgpu_last_table_kind(void* handle) {
