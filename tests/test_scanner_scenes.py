@@ -50,11 +50,30 @@ def test_batch_replay_of_the_scanner_scene(s):
     assert np.median(o["goal_distance"]) < 0.1
     assert o["ticks"] < 120                                       # ... within the recorded horizon of the scanner
     assert o["status_histogram"][2:].sum() == 0                   # no time-outs, no non-finite solves, no shape overflow
-    if s in (1, 3, 4):                                            # single obstacle crossing / approaching / leading:
-        assert o["min_core"].min() > 0.95                         # the robots stay outside its hard ellipse
+    # What the reference's OWN simulator run shows for the same quantities (tests/golden/fleet_trace.npz `ref_summary_<s>`:
+    # Simulator.run unchanged, nominal start pose, oracle stand-in behind the plugin; scenes 2-5 -- scene 1 needs the visibility
+    # planner around its box).  [ticks, robots, converged calls, closest approach to a hard ellipse, robot-robot distance, ...]
+    ref = np.load(os.path.join(ROOT, "tests", "golden", "fleet_trace.npz"))
+    if s in (2, 4):
+        core_ref = float(ref[f"ref_summary_{s}"][3])
+        print(f"    reference run: closest approach to a hard ellipse {core_ref:.3f}; batch replay median {np.median(o['min_core']):.3f}")
+        assert o["min_core"].min() > 0.95                         # nobody enters a hard ellipse ...
+        assert abs(np.median(o["min_core"]) - core_ref) < 0.15 * core_ref      # ... and the typical clearance is the reference run's
+    if s == 1:
+        assert o["min_core"].min() > 0.95
+    if s == 3:
+        # Head-on "crash" scene: the obstacle comes down the robot's own lane.  From the exactly symmetric nominal pose the
+        # reference run itself ends up INSIDE the hard ellipse (closest approach 0.20: nothing breaks the symmetry until the
+        # penalty is large); a few centimetres of lateral offset decide the side and the robots pass on the ellipse's edge.
+        core_ref = float(ref["ref_summary_3"][3])
+        print(f"    reference run (symmetric start): closest approach {core_ref:.3f}; batch replay (5 cm jitter) min {o['min_core'].min():.3f}")
+        assert core_ref < 0.5 and o["min_core"].min() > 0.95
     if s == 5:
         # Two robots swap lanes.  The fleet term of the reference is a soft hinge on W^2 - d^2 with W = vehicle_width = 0.5 m
-        # between CENTRES (mpc_generator.py:105-108, 211-216): it only acts below 0.5 m, so the robots pass each other at
-        # about that distance and some worlds get closer (measured 0.18 .. 0.8 m) -- a property of the formulation, reproduced
-        # bit for bit against the sequential loop in tests/test_gpu_fleet.py.  Asserted: the typical pass keeps them apart.
-        assert np.median(o["min_pair"]) > 0.4
+        # between CENTRES (mpc_generator.py:105-108, 211-216): it only acts below 0.5 m.  The reference's own run passes at
+        # 0.63 m; the jittered worlds scatter around that (measured 0.28 .. 0.8 m), bit for bit the sequential loop's answers
+        # (tests/test_gpu_fleet.py).
+        pair_ref = float(ref["ref_summary_5"][4])
+        print(f"    reference run: robot-robot distance {pair_ref:.3f} m; batch replay median {np.median(o['min_pair']):.3f} m, min {o['min_pair'].min():.3f} m")
+        assert abs(np.median(o["min_pair"]) - pair_ref) < 0.2
+        assert o["min_pair"].min() > 0.2

@@ -46,6 +46,11 @@ class BatchedTracker:
         self.dyn_weights = [1e3] * N
         self.pred_states = np.zeros((self.B, N, config.ns))
         self.active = np.ones(self.B, dtype=bool)   # False once a robot's termination test has fired
+        # InterfaceMpc.get_action stops serving a robot whose termination test has fired (src/interface_mpc.py:83-85); the
+        # multi-robot simulator keeps calling run_step for every robot until ALL have arrived (src/scenario_simulator.py:226-250).
+        # False reproduces the latter: the test is still evaluated (``arrived``), but nobody is frozen.
+        self.stop_when_done = True
+        self.arrived = np.zeros(self.B, dtype=bool)
         self.last_result: Optional[BatchResult] = None
         self._P: Optional[np.ndarray] = None
 
@@ -168,7 +173,9 @@ class BatchedTracker:
         whole batch with whatever ``other_robot_states`` holds (Jacobi when fed by ``share_predictions``)."""
         cfg = self.config
         near = np.all(np.abs(self.states[:, :2] - self.goals[:, :2]) <= 0.05, axis=1)
-        self.active &= ~(near & (np.abs(self.last_actions[:, 0]) < 0.05))     # check_termination_condition
+        self.arrived = near & (np.abs(self.last_actions[:, 0]) < 0.05)        # check_termination_condition
+        if self.stop_when_done:
+            self.active &= ~self.arrived
         if initial_guess is None and self.warm_start and self.last_result is not None:
             # receding-horizon warm start (what OpEn's TCP server does with its cached solution): previous plan
             # shifted by the inputs already applied, last input repeated
