@@ -85,28 +85,40 @@ def first_divergence(tg, to):
 # Thresholds (median first discrete divergence, median first scalar drift beyond 1e-3, worst relative scalar error over
 # steps 0..9) are the measured behaviour with a margin.  With 80 unknowns (N = 40) rounding differences are amplified
 # faster: decisions flip after ~40 steps instead of ~70 (the oracle against itself with 1-ulp perturbed inputs does the same).
-@pytest.mark.parametrize("N,fallback,max_inner,max_outer,min_fd,min_sd,early_tol", [
-    (20, "last_trial", 40, 6, 50, 30, 1e-6),   # 240 steps across 6 inner problems: c = 10 .. 10*5^5, multipliers updated 5 times
-    (20, "half_step", 40, 6, 50, 30, 1e-6),
-    (40, "last_trial", 40, 6, 30, 20, 1e-5),
-    (20, "last_trial", 500, 10, 50, 30, 1e-6)])  # the yaml's caps: the first 240 steps of the first inner problem
-def test_decision_trace_matches_oracle(N, fallback, max_inner, max_outer, min_fd, min_sd, early_tol):
-    """Benchmark-family scenes (hard constraints active: F2 > 0, penalty growing) from a non-zero initial guess."""
+@pytest.mark.parametrize("N,fallback,max_inner,max_outer,min_fd,min_sd,early_tol,kernel,cold", [
+    (20, "last_trial", 40, 6, 50, 30, 1e-6, "throughput", False),   # 240 steps across 6 inner problems: c = 10 .. 10*5^5, multipliers updated 5 times
+    (20, "half_step", 40, 6, 50, 30, 1e-6, "throughput", False),
+    (40, "last_trial", 40, 6, 30, 20, 1e-5, "throughput", False),
+    (20, "last_trial", 500, 10, 50, 30, 1e-6, "throughput", False),  # the yaml's caps: the first 240 steps of the first inner problem
+    # round 3: the LATENCY kernel's own trace (four wavefronts per problem, speculative evaluations) against the oracle ...
+    (20, "last_trial", 40, 6, 50, 30, 1e-6, "latency", False),
+    (40, "last_trial", 40, 6, 30, 20, 1e-5, "latency", False),
+    # ... and the reference's real call pattern: cold start u0 = 0 (src/interface_mpc.py:82) with the yaml's caps.  The Lipschitz
+    # estimate then perturbs by h = 1e-12, so L -- and with it gamma and every scalar after it -- is rounding-noise limited
+    # (~1e-4 relative) in ANY float64 implementation: the scalars part at once (no early_tol / min_sd), the DISCRETE decisions
+    # still coincide for a median of 20 steps (measured; profiles/r03_parity_report.txt)
+    (20, "last_trial", 500, 10, 12, 0, None, "throughput", True),
+    (20, "last_trial", 40, 6, 12, 0, None, "latency", True)])
+def test_decision_trace_matches_oracle(N, fallback, max_inner, max_outer, min_fd, min_sd, early_tol, kernel, cold):
+    """Benchmark-family scenes (hard constraints active: F2 > 0, penalty growing); from a non-zero initial guess, or cold.  The
+    oracle evaluates the L-BFGS operator in the form the kernel uses for the horizon (Gram at N_hor = 20, two-loop at 40)."""
     CAP, B = 240, 48
     cfg = make_cfg(N, solver_linesearch_fallback=fallback, solver_max_inner_iterations=max_inner,
                    solver_max_outer_iterations=max_outer)
-    ocfg = oracle_cfg(cfg)
+    od = cfg.solver_dict(); od["lbfgs_gram"] = 1 if N == 20 else 0
+    ocfg = oracle.OracleConfig.from_dict(od)
     assert ocfg.ls_fallback == (1 if fallback == "half_step" else 0)
-    bs = BatchSolver(cfg, library=variant_path("trace"))
+    bs = BatchSolver(cfg, library=variant_path("trace"), latency_batch=0 if kernel == "throughput" else None)
     bs.set_trace(CAP)
     sc = scenes.make_batch(cfg, B, n_dyn=8, seed=77 + N)
-    u0 = np.tile([0.6, 0.1], (B, N))
+    u0 = None if cold else np.tile([0.6, 0.1], (B, N))
     res = bs.solve(sc["p"], u0)
+    assert bool(bs.last_shape()["latency_kernel"]) == (kernel == "latency")
     tr = bs.read_trace(B)
     firsts, drifts, n_outer3, top_outer = [], [], 0, 0
     early = 0.0
     for b in range(B):
-        _, ro, to, steps = oracle.solve_trace(ocfg, sc["p"][b], u0[b], cap=CAP)
+        _, ro, to, steps = oracle.solve_trace(ocfg, sc["p"][b], None if cold else u0[b], cap=CAP)
         tg = tr[b][~np.isnan(tr[b, :, 0])]
         assert len(tg) == min(steps, CAP) or res.num_inner_iterations[b] != ro["inner_iters"]
         n_outer3 += int(ro["outer_iters"] >= 3)
@@ -129,18 +141,21 @@ def test_decision_trace_matches_oracle(N, fallback, max_inner, max_outer, min_fd
     firsts, drifts = np.array(firsts), np.array(drifts)
     hist = np.bincount(np.minimum(firsts // 25, 8), minlength=9)
     dhist = np.bincount(np.minimum(drifts // 25, 8), minlength=9)
-    print(f"\n[N={N} {fallback} {max_inner}x{max_outer}] first divergence of a discrete decision, per problem (bins of 25 steps, last = none in "
+    print(f"\n[N={N} {fallback} {max_inner}x{max_outer} {kernel}{' cold' if cold else ''}] first divergence of a discrete decision, per problem (bins of 25 steps, last = none in "
           f"{CAP}): {hist.tolist()}; median {np.median(firsts):.0f}, min {firsts.min()}; first step with a scalar off by > {SCALAR_TOL:g} "
           f"(or the discrete divergence, whichever comes first): {dhist.tolist()}; median {np.median(drifts):.0f}, min {drifts.min()}; "
           f"worst scalar rel. error in steps 0..9: {early:.2e}; problems with >= 3 outer iterations: {n_outer3}/{B}; highest outer "
           f"index matched {top_outer}")
     assert n_outer3 >= B // 2                       # the solves do go through several outer iterations
-    if max_inner * 3 <= CAP and N == 20:
-        assert top_outer >= 2                       # ... and decisions were matched beyond the second penalty update
-    assert early <= early_tol                       # the first 10 steps are tight
-    assert firsts.min() >= 10                       # nobody diverges in the first steps
     assert np.median(firsts) >= min_fd              # typically dozens of identical decisions in a row
-    assert np.median(drifts) >= min_sd and drifts.min() >= 10   # ... with scalars within 1e-3 over the first dozens of steps
+    if cold:
+        assert firsts.min() >= 3                    # rounding-noise-limited Lipschitz estimate: see the parametrisation
+    else:
+        if max_inner * 3 <= CAP and N == 20:
+            assert top_outer >= 2                   # ... and decisions were matched beyond the second penalty update
+        assert early <= early_tol                   # the first 10 steps are tight
+        assert firsts.min() >= 10                   # nobody diverges in the first steps
+        assert np.median(drifts) >= min_sd and drifts.min() >= 10   # ... with scalars within 1e-3 over the first dozens of steps
     bs.close()
 
 

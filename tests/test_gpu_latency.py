@@ -159,3 +159,23 @@ def test_reserved_small_batch_takes_the_latency_kernel_with_tables_of_the_reserv
     ref = BatchSolver(cfg, latency_batch=0).solve(sc["p"])
     assert np.array_equal(out["u"].cpu().numpy(), ref.solution) and np.array_equal(out["status"].cpu().numpy(), ref.status)
     bs.close()
+
+
+@pytest.mark.parametrize("B", [40, 700])
+def test_latency_kernel_decision_trace_is_bitwise_the_throughput_kernel_trace(B):
+    """Trace builds record one line per PANOC step (penalty, Lipschitz estimate, step size, residual, psi, doublings, pairs,
+    halvings, tau): the four- and two-wavefront kernels write the very lines the one-wavefront kernel writes."""
+    from trajtrack_mpcndqn_rlboost_amd.solver import variant_path
+    cfg = make_cfg(20, solver_max_inner_iterations=40, solver_max_outer_iterations=4)
+    sc = scenes.make_batch(cfg, B, n_dyn=8, seed=55)
+    out = []
+    for kw in ({}, dict(latency_batch=0)):
+        bs = BatchSolver(cfg, library=variant_path("trace"), **kw)
+        bs.set_trace(160)
+        res = bs.solve(sc["p"], np.tile([0.6, 0.1], (B, 20)))
+        out.append((res, bs.read_trace(B), bs._L.mpcgpu_last_latency_kernel(bs._h)))
+        bs.close()
+    assert out[0][2] == (4 if B <= 512 else 2) and out[1][2] == 0
+    _same(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1], equal_nan=True)
+    assert np.isfinite(out[0][1][:, :20]).all() and np.isfinite(out[0][1][:, 100]).mean() > 0.5   # the steps were recorded

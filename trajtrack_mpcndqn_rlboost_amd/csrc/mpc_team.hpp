@@ -125,6 +125,24 @@ __global__ __launch_bounds__(WAVE * TW) void solve_kernel_team(KParams kp, Batch
     double dy_norm = 0, dy_norm_plus = 0, f2_norm = 0, f2_norm_plus = 0, last_fpr = 0, f_final = 0;
     int n_eval = 0, n_eval_grad = 0;  // evaluations of the SEQUENTIAL algorithm (the speculative ones are not counted)
 
+#ifdef MPC_TRACE
+    // decision trace (trace builds, tests): the record of solve_body, written by wavefront 0 when a PANOC step completes
+    int tr_n = 0;
+    double tr_psi_u = 0.0;
+    auto tr_write = [&](int nls_, double tau_) {
+        if (wid == 0 && lane == 0 && io.trace && tr_n < io.trace_cap) {
+            double* r = io.trace + ((size_t)b * io.trace_cap + tr_n) * TRACE_W;
+            r[0] = alm_iteration; r[1] = iter; r[2] = c; r[3] = Lip; r[4] = gamma; r[5] = nfpr; r[6] = tr_psi_u;
+            r[7] = lip_it; r[8] = lb.active; r[9] = nls_; r[10] = tau_; r[11] = cost;
+        }
+        ++tr_n;
+    };
+#define TEAM_TRACE(nls_, tau_) tr_write(nls_, tau_)
+#define TEAM_TRACE_PSI() tr_psi_u = cost
+#else
+#define TEAM_TRACE(nls_, tau_)
+#define TEAM_TRACE_PSI()
+#endif
     int state = TS_INIT0;
     double ev = uv, ew = uw;
     bool want_grad = true;
@@ -202,6 +220,7 @@ __global__ __launch_bounds__(WAVE * TW) void solve_kernel_team(KParams kp, Batch
                 continue;
             }
             sigma = uniform(KC(K_SIGMA) * ig);
+            TEAM_TRACE_PSI();
             double lb_pr = 0.0;
             lb.template update<P, NT, MEMT>(cx, kp, vl, lane, uv, uw, rv_, rw_, nfpr, lm, lb_pr);
             wave_sync();
@@ -211,6 +230,7 @@ __global__ __launch_bounds__(WAVE * TW) void solve_kernel_team(KParams kp, Batch
                 uv = hv; uw = hw;
                 cost = uniform(o.psi); gv = o.gv; gw = o.gw;
                 panoc_envelope_sums<P>(kp, vl, uv, uw, gamma, gv, gw, hv, hw, gg, d2h);
+                TEAM_TRACE(-1, 1.0);
                 ++iter;
                 step_begin = true;
             } else {
@@ -249,11 +269,14 @@ __global__ __launch_bounds__(WAVE * TW) void solve_kernel_team(KParams kp, Batch
             if (winner) {
                 nls = winner - 1;
                 n_eval += nls + 1; n_eval_grad += nls + 1;
+                TEAM_TRACE_PSI();
                 adopt(winner, uniform(o.psi), tgg, td2h, thv, thw);
+                TEAM_TRACE(nls, exp2(-(double)nls));
                 ++iter;
                 step_begin = true;
             } else {
                 n_eval += TW - 1; n_eval_grad += TW - 1;
+                TEAM_TRACE_PSI();
                 t0 = TW - 1;
                 trial_point(exp2(-(double)(t0 + wid)));
                 want_grad = true; state = TS_BATCH;
@@ -274,12 +297,15 @@ __global__ __launch_bounds__(WAVE * TW) void solve_kernel_team(KParams kp, Batch
                 nls = t0 + winner;
                 n_eval += winner + 1; n_eval_grad += winner + 1;
                 if (all[winner] == 2.0 && kp.ls_fallback == 1) {
+                    TEAM_TRACE_PSI();
                     // 10 halvings without acceptance, tau = 0 reading: u - gamma*fpr is evaluated and taken
                     ev = uv - rv_; ew = uw - rw_;
                     want_grad = true; state = TS_FALLBACK;
                     continue;
                 }
+                TEAM_TRACE_PSI();
                 adopt(winner, uniform(o.psi), tgg, td2h, thv, thw);
+                TEAM_TRACE(nls, exp2(-(double)nls));
                 ++iter;
                 step_begin = true;
             } else {
@@ -293,6 +319,7 @@ __global__ __launch_bounds__(WAVE * TW) void solve_kernel_team(KParams kp, Batch
             uv = ev; uw = ew;
             cost = uniform(o.psi); gv = o.gv; gw = o.gw;
             panoc_envelope_sums<P>(kp, vl, uv, uw, gamma, gv, gw, hv, hw, gg, d2h);
+            TEAM_TRACE(nls, 0.0);
             ++iter;
             step_begin = true;
         } else {  // TS_OUTER

@@ -249,7 +249,7 @@ void fill_lds_layout(KParams& k, int mKs, int mKf, int mKd, bool shape_const, bo
 // matrix / item partials, L-BFGS memory).  Offsets of the work-block fields are those of wavefront 0.
 // `tw` wavefronts per problem; tables for (mKs, mKf, mKd) active rows -- the configured maxima (nothing known before the launch) or
 // the maxima of the batch / of a reservation (mid-batch form).
-[[maybe_unused]] void fill_team_layout(KParams& k, int tw, int mKs, int mKf, int mKd) {  // unused in -DMPC_TRACE builds
+void fill_team_layout(KParams& k, int tw, int mKs, int mKf, int mKd) {
     const int N = k.N;
     k.mKs = mKs; k.mKf = mKf; k.mKd = mKd;
     int o = 0;
@@ -427,7 +427,15 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
     const int team_cap = h->team_max_batch >= 0 ? h->team_max_batch : 4 * h->num_cus;  // measured break-even: 1000-1500 problems (tools/team_sweep.py)
     h->last_team = 0;
     bool prepared = false;
-#ifndef MPC_TRACE
+#ifdef MPC_TRACE
+    if (h->trace_cap > 0) {     // trace builds (tests): one record per PANOC step, from whichever kernel runs
+        const size_t tb = (size_t)B * h->trace_cap * TRACE_W * sizeof(double);
+        if (int r = ensure(h, h->trace, tb)) return r;
+        HIP_OK(h, hipMemsetAsync(h->trace.ptr, 0xFF, tb, s));  // NaN = record not written
+        io.trace = (double*)h->trace.ptr;
+        io.trace_cap = h->trace_cap;
+    }
+#endif
 #define LAUNCH_TEAM(NT, TW, KT, LDS_T)                                                                               \
     do {                                                                                                             \
         auto kern = solve_kernel_team<NT, TW>;                                                                       \
@@ -500,22 +508,12 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
     }
 #undef LAUNCH_TEAM_N
 #undef LAUNCH_TEAM
-#endif
     if (!prepared)
         if (int r = prepare(h, B, p, s, io, true, trk, refs)) return r;
     io.u0 = u0; io.y0 = y0; io.c0 = c0; io.u = u; io.cost = cost; io.status = status; io.inner_it = inner_it;
     io.outer_it = outer_it; io.fpr = fpr; io.f2norm = f2norm; io.y_out = y_out; io.ms = ms;
     if (int r = ensure(h, h->evals, (size_t)B * 2 * sizeof(int32_t))) return r;
     io.evals = (int32_t*)h->evals.ptr;
-#ifdef MPC_TRACE
-    if (h->trace_cap > 0) {
-        const size_t tb = (size_t)B * h->trace_cap * TRACE_W * sizeof(double);
-        if (int r = ensure(h, h->trace, tb)) return r;
-        HIP_OK(h, hipMemsetAsync(h->trace.ptr, 0xFF, tb, s));  // NaN = record not written
-        io.trace = (double*)h->trace.ptr;
-        io.trace_cap = h->trace_cap;
-    }
-#endif
     h->last_B = B;
     if (!h->capturing) HIP_OK(h, hipEventRecord(h->ev[2], s));
     const size_t lds = h->kp.l_total * sizeof(double);
