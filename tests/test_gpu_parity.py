@@ -498,12 +498,14 @@ def test_large_lds_carve_long_horizon_with_time_varying_obstacles():
     uo, _, ro, _ = oracle.solve_batch(oracle_cfg(cfgk), p, u0)
     assert np.array_equal(res.num_inner_iterations, ro["inner_iters"]) and np.max(np.abs(res.solution - uo)) < 1e-6
     bs.close()
-    big = make_cfg(N, Ndynobs=32)
+    big = make_cfg(N, Ndynobs=32, Nother=16)
     bs = BatchSolver(big)
     pb = np.zeros((1, big.num_params))
     ob = big.offsets()
     blk = np.ones((32, N, 6)) * np.arange(1, N + 1)[None, :, None]      # every row active and time-varying
     pb[0, ob["od"]:ob["od"] + 32 * 6 * N] = blk.reshape(-1)
+    pb[0, ob["c"]:ob["os"]] = 1.0                                        # ... and every other-robot row too (round 3: the hinge
+    #                                                                      matrix left LDS, 32 general rows alone fit again)
     with pytest.raises(MpcGpuError, match="LDS carve"):
         bs.solve(pb)
     bs.close()

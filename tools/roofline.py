@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Roofline numbers of the solve kernel, rebuilt from the raw rocprofv3 CSVs kept under profiles/.
 
-    python tools/roofline.py rebuild  [--raw profiles/raw_r02] [--out profiles/r02_roofline_bench.json]
-    python tools/roofline.py show     [profiles/r02_roofline_bench.json] [bench-line.json]
+    python tools/roofline.py rebuild  [--raw profiles/raw_r03] [--out profiles/r03_roofline_bench.json]
+    python tools/roofline.py show     [profiles/r03_roofline_bench.json] [bench-line.json]
 
 `rebuild` reads, from the raw directory (copies of what `tools/collect_profiles.sh` wrote on the GPU box):
     workload.json                 {"N_hor", "n_dyn", "batch_per_gpu"}: the bench.py arguments of every pass
@@ -68,15 +68,19 @@ def flops_per_eval(N: int, Ks: int, Kf: int, Kd: int, grad: bool) -> float:
 
 def flops_per_solve_kernel_launch(N, Ks, Kf, Kd, n_psi, n_grad) -> float:
     """Executed f64 flops of one launch from the per-problem evaluation counters (n_grad of the n_psi evaluations also
-    produced the gradient).  The solver algebra between evaluations (~10 N-vector operations and the two-loop recursion,
-    4 x mem x 2N flops per PANOC iteration) is added per gradient evaluation, of which ~1/3 start a PANOC iteration."""
+    produced the gradient).  The solver algebra between evaluations (~10 N-vector operations and the
+    L-BFGS step) is added per PANOC iteration / gradient evaluation."""
     import numpy as np
     n_psi = np.asarray(n_psi, dtype=np.float64)
     n_grad = np.asarray(n_grad, dtype=np.float64)
     f_psi = flops_per_eval(N, Ks, Kf, Kd, False)
     f_grad = flops_per_eval(N, Ks, Kf, Kd, True)
     n_iter = n_psi - n_grad                       # one gradient-free evaluation (Lipschitz check) per PANOC iteration
-    algebra = n_iter * (4 * 10 * 2 * N + 20 * 2 * N) + n_grad * (8 * 2 * N)
+    # L-BFGS step per PANOC iteration.  Gram form (N_hor = 20, round 3): pass 1 = 2 mem rows x 2N x 2 products, the two scalar
+    # recurrences 2 x mem x (2 mem rows), pass 2 = 2 mem rows x 2N; two-loop form: 4 x mem dot products / updates of length 2N.
+    mem = 10
+    lbfgs = (2 * (2 * mem) * (2 * N) * 2 + 2 * (2 * mem) * (2 * N) + 2 * 2 * mem * 2 * mem) if N == 20 else 2 * (4 * mem * 2 * N)
+    algebra = n_iter * (lbfgs + 20 * 2 * N) + n_grad * (8 * 2 * N)
     return float(((n_psi - n_grad) * f_psi + n_grad * f_grad + algebra).sum())
 
 
@@ -187,8 +191,8 @@ def show(derived_path, bench_path=None):
 if __name__ == "__main__":
     cmd = sys.argv[1] if len(sys.argv) > 1 else "show"
     if cmd == "rebuild":
-        raw = os.path.join(ROOT, "profiles", "raw_r02")
-        out = os.path.join(ROOT, "profiles", "r02_roofline_bench.json")
+        raw = os.path.join(ROOT, "profiles", "raw_r03")
+        out = os.path.join(ROOT, "profiles", "r03_roofline_bench.json")
         a = sys.argv[2:]
         while a:
             if a[0] == "--raw": raw = a[1]
@@ -197,5 +201,5 @@ if __name__ == "__main__":
         d = rebuild(raw, out)
         print(json.dumps({k: v for k, v in d.items() if k != "raw_per_launch"}, indent=1))
     else:
-        show(sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r02_roofline_bench.json"),
+        show(sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r03_roofline_bench.json"),
              sys.argv[3] if len(sys.argv) > 3 else None)

@@ -48,6 +48,17 @@ struct Prof {
 #define PROF_COUNT(i)
 #endif
 
+// Row sums of the hinge matrix H[i][k] = max(0, inside_ellipse(row i, step k)) (the hard dynamic-obstacle constraint F2):
+// 1 = every item lane adds its positive terms to D_i in LDS (ds_add_f64: the lanes of one instruction are served in a fixed
+// order, so the sum is deterministic and the same in every kernel that runs this code); 0 = rounds 1-2: the matrix is stored
+// (Kd x N doubles of LDS) and lane i sums its row in a serial loop.
+#ifndef MPC_H_ATOMIC
+#define MPC_H_ATOMIC 1
+#endif
+__device__ __forceinline__ void lds_add(double* p, double v) {
+    __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)p, v);
+}
+
 constexpr int WAVE = 64;
 constexpr int HDR = 64;        // header doubles per problem in the workspace
 constexpr int SEGW = 9;        // LDS / workspace doubles per reference segment: s1x, s1y, dx, dy, 1/(|d|^2+1e-16), then the
@@ -680,6 +691,9 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     const double dCw = -ts * (2.0 * sm + s2) * sixth, dSw = ts * (2.0 * cm + c2) * sixth;
     const double X = HD(H_X0) + P::template prefix<RV>(c_vl ? ts * v * Cx : 0.0);
     const double Y = HD(H_Y0) + P::template prefix<RV>(c_vl ? ts * v * Sy : 0.0);
+#if MPC_H_ATOMIC
+    if (lane < cx.Kd) cx.H[lane] = 0.0;   // row sums of the hard-constraint hinges, accumulated by the item lanes below
+#endif
     if (c_vl) {
         cx.pos[2 * lane] = X; cx.pos[2 * lane + 1] = Y;
         // rollout quantities needed again only after the item phase (per-step terms, adjoint): parked in LDS so
@@ -796,7 +810,11 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
             const double a2 = d.a * d.a, b2 = d.b * d.b;
             const double Ih = 1.0 - a2 * d.ihx - b2 * d.ihy;
             anyh |= Ih > 0.0;
+#if MPC_H_ATOMIC
+            if (Ih > 0.0) lds_add(cx.H + i, Ih);      // D_i = sum_k max(0, Ih(i, k)): accumulated where the terms arise
+#else
             cx.H[i * N + k] = Ih > 0.0 ? Ih : 0.0;
+#endif
             const double Is = 1.0 - a2 * d.isx - b2 * d.isy;
             if (Is > 0.0) {
                 cost_l += d.wgt * Is * Is;
@@ -839,8 +857,12 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     double F2e = 0.0;
     if (lane < cx.Kd) {
         double D = 0.0;
+#if MPC_H_ATOMIC
+        if (any_h) D = cx.H[lane];
+#else
         if (any_h)
             for (int k = 0; k < N; ++k) D += cx.H[lane * N + k];
+#endif
         F2e = S + D;
     }
     const double F2pad = cx.pad_d ? S + (any_hp ? P::template sum<RV>(hp) : 0.0) : 0.0;

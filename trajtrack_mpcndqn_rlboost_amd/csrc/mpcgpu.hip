@@ -226,8 +226,9 @@ void fill_lds_layout(KParams& k, int mKs, int mKf, int mKd, bool shape_const, bo
     k.l_hd = o; o += 64;
     // H (hinge matrix, read right after it is written) and the item-lane partials are never live together:
     // LDS operations of the single wave execute in order, so they share one region
-    const int h_sz = even(mKd * N) + even(mKd), part_sz = part_doubles(k);
-    k.l_H = o; k.l_W = o + even(mKd * N); k.l_part = o;
+    const int h_rows = MPC_H_ATOMIC ? even(mKd) : even(mKd * N);   // row sums only (accumulated in place) / the whole hinge matrix
+    const int h_sz = h_rows + even(mKd), part_sz = part_doubles(k);
+    k.l_H = o; k.l_W = o + h_rows; k.l_part = o;
     o += h_sz > part_sz ? h_sz : part_sz;
     k.l_S = k.l_Y = o;
     if (lbfgs_in_lds) {
@@ -263,8 +264,9 @@ void fill_team_layout(KParams& k, int tw, int mKs, int mKf, int mKd) {
     const int base = o;
     k.l_pos = o; o += N * 2;
     k.l_stash = o; o += stash_doubles(k);
-    const int h_sz = even(k.mKd * N) + even(k.mKd), part_sz = part_doubles(k);
-    k.l_H = o; k.l_W = o + even(k.mKd * N); k.l_part = o;
+    const int h_rows = MPC_H_ATOMIC ? even(k.mKd) : even(k.mKd * N);
+    const int h_sz = h_rows + even(k.mKd), part_sz = part_doubles(k);
+    k.l_H = o; k.l_W = o + h_rows; k.l_part = o;
     o += h_sz > part_sz ? h_sz : part_sz;
     k.l_S = o; o += k.mem * N * 2;
     k.l_Y = o; o += k.mem * N * 2 + N * 2;  // + the zero row
