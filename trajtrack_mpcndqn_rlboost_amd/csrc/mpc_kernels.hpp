@@ -236,7 +236,9 @@ __device__ __forceinline__ double clampd(double x, double lo, double hi) { retur
 // inclusive prefix PRODUCT of unit complex numbers (re, im) over lanes 0..16*ROWS-1 (lanes >= n carry 1+0i)
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ void cmul_step(double& re, double& im) {
-    const double pr = dppf<CTRL, ROW_MASK>(re, 1.0), pi = dppf<CTRL, ROW_MASK>(im, 0.0);
+    // identity element 1 + 0i for lanes without a source: the real part needs its fill value preloaded, the imaginary part is the
+    // zero-filling form (two v_mov less per step)
+    const double pr = dppf<CTRL, ROW_MASK>(re, 1.0), pi = dpp0<CTRL, ROW_MASK>(im);
     const double nr = re * pr - im * pi, ni = re * pi + im * pr;
     re = nr; im = ni;
 }
@@ -318,6 +320,21 @@ struct Solo {
     template <int ROWS> static __device__ __forceinline__ void cprod(double& re, double& im) { scan_cprod<ROWS>(re, im); }
     template <int ROWS> static __device__ __forceinline__ double suffix(double x, int lane) { return scan_suffix<ROWS>(x, lane); }
     static __device__ __forceinline__ double from_lane(double x, int l) { return readlane_d(x, l); }
+    // two inclusive prefix sums over the vector lanes for the price of one when they fit half a wavefront: b travels in rows 2-3
+    // (v_permlane32_swap), one DPP sequence serves both halves, b comes back the same way.  Bitwise the two separate scans.
+    template <int ROWS> static __device__ __forceinline__ void prefix2(double a, double b, double& pa, double& pb) {
+        if (ROWS <= 2) {
+            auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+            auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+            double x = __hiloint2double((int)hi[0], (int)lo[0]);   // lanes 0..31: a, lanes 32..63: b (its lanes 0..31)
+            x = row_prefix(x);
+            if (ROWS > 1) x += dpp0<DPP_BCAST15, 0xA>(x);          // rows 0 -> 1 and 2 -> 3
+            lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(x), false, false);
+            hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(x), false, false);
+            pa = x;                                                // lanes 0..31 (the others are not vector lanes)
+            pb = __hiloint2double((int)hi[1], (int)lo[1]);         // lanes 0..31 receive what lanes 32..63 hold
+        } else { pa = scan_prefix<ROWS>(a); pb = scan_prefix<ROWS>(b); }
+    }
 };
 template <int NT>
 struct Duo {
@@ -340,6 +357,9 @@ struct Duo {
     template <int ROWS> static __device__ __forceinline__ void cprod(double& re, double& im) { scan_cprod<2>(re, im); }
     template <int ROWS> static __device__ __forceinline__ double suffix(double x, int) { return half_suffix(x); }
     static __device__ __forceinline__ double from_lane(double x, int l) { return half_allsum(lane() == l ? x : 0.0); }
+    template <int ROWS> static __device__ __forceinline__ void prefix2(double a, double b, double& pa, double& pb) {
+        pa = scan_prefix<2>(a); pb = scan_prefix<2>(b);
+    }
 };
 
 // Double-precision literals cannot be instruction operands on gfx950; the compiler materialises each one in a VGPR
@@ -689,8 +709,10 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     {
     const double Cx = (c0 + 4.0 * cm + c2) * sixth, Sy = (s0 + 4.0 * sm + s2) * sixth;
     const double dCw = -ts * (2.0 * sm + s2) * sixth, dSw = ts * (2.0 * cm + c2) * sixth;
-    const double X = HD(H_X0) + P::template prefix<RV>(c_vl ? ts * v * Cx : 0.0);
-    const double Y = HD(H_Y0) + P::template prefix<RV>(c_vl ? ts * v * Sy : 0.0);
+    double pX, pY;
+    P::template prefix2<RV>(c_vl ? ts * v * Cx : 0.0, c_vl ? ts * v * Sy : 0.0, pX, pY);
+    const double X = HD(H_X0) + pX;
+    const double Y = HD(H_Y0) + pY;
 #if MPC_H_ATOMIC
     if (lane < cx.Kd) cx.H[lane] = 0.0;   // row sums of the hard-constraint hinges, accumulated by the item lanes below
 #endif
