@@ -29,4 +29,4 @@ for i, n in enumerate(names):
 for i, n in enumerate(states):
     c = t[16 + i]
     print(f"  logic before {n:6s} evals {c / B:8.0f}/solve  {t[10 + i] / max(c, 1):8.0f} cyc each  {100 * t[10 + i] / tot:5.1f} %")
-print(f"  per-segment pruning pass entered in {t[23] / evals:.3f} of the evaluations")
+print(f"  reference segments beyond the two nearest: the suffix-circle loop was entered (by at least one lane) in {t[23] / evals:.3f} of the evaluations")

@@ -4,6 +4,7 @@
 set -u
 REPO="$(cd "$(dirname "$0")/.." && pwd)"
 B="${1:-8192}"; OUT="${2:-$REPO/gpurun_out/pmc_stalls}"
+case "$OUT" in /*) ;; *) OUT="$REPO/$OUT";; esac
 mkdir -p "$OUT"; export TMPDIR=/tmp; cd /tmp
 i=0
 for SET in "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES" \
