@@ -103,6 +103,73 @@ struct KParams {
     int l_wstride, l_xch;  // team kernel (mpc_team.hpp): doubles per wavefront work block, offset of the exchange area
 };
 
+// How H * (gamma fpr) is evaluated: 1 = Gram form (PanocLbfgsGram, round 3), 0 = two-loop recursion (PanocLbfgs; the build
+// `make variants` keeps as libmpcgpu_twoloop.so for A/B runs).  Two problems per wavefront (Duo) always take the two-loop form.
+#ifndef MPC_LBFGS_GRAM
+#define MPC_LBFGS_GRAM 1
+#endif
+
+// ------------------------------------------------------------------------------------------------
+// LDS carve, fixed part.  Every region whose size depends only on (N_hor, L-BFGS memory) comes FIRST, at offsets that are
+// compile-time constants for the kernels with a compiled horizon; the tables whose size follows the batch's active rows (static
+// polygons, fleet discs, dynamic ellipses) come after them.  A kernel with a compiled horizon then addresses positions, stash,
+// partials, header, segments, Gram matrices ... through the 16-bit immediate offset of the DS instructions: no base pointer in
+// an SGPR (the scalar file of the solve kernel is over-subscribed: 94 spilled SGPRs, every reload a v_readlane on the VALU), no
+// address arithmetic beyond the lane's own scaled index.  The host (mpcgpu.hip fill_lds_layout / fill_team_layout) fills
+// KParams::l_* from the SAME function, so the generic kernel and the latency kernel read the identical layout at run time.
+// ------------------------------------------------------------------------------------------------
+struct FixedLds { int hd, seg, pos, stash, part, W, rho, gg, S, Y, old, end; };
+__host__ __device__ constexpr int even_c(int x) { return (x + 1) & ~1; }
+__host__ __device__ constexpr bool gram_shape(int N, int mem) { return MPC_LBFGS_GRAM && N == 20 && mem == 10; }
+// Item-lane partials (eval_point): every item lane beyond the vector lanes parks PARTW = 5 doubles.  With a compiled horizon that
+// nearly divides the wavefront (N_hor = 20: 60 item lanes) the split is uniform and the last lanes idle -- the rule of eval_point.
+__host__ __device__ constexpr int part_doubles_c(int N, int mem) {
+    const bool compiled = (N == 20 || N == 40) && mem == 10;
+    const bool uniform = compiled && (64 % N) * 5 <= N;
+    const int item_lanes = uniform ? (64 / N) * N : 64;
+    return (item_lanes - N) * 5;
+}
+// The stash (6 doubles per step) and the positions before it are dead between two evaluations; the Gram form of the L-BFGS step
+// uses them as scratch there: the operands of pass 1 ((r, y) pairs of every chunk slot) followed by the row coefficients.
+__host__ __device__ constexpr int stash_doubles_c(int N, int mem) {
+    int need = N * 6;
+    if (gram_shape(N, mem)) {
+        const int R = 2 * mem, G = 32 / mem, CL = (N + G - 1) / G, G2 = 64 / N, CR = (R + G2 - 1) / G2;
+        int scratch = even_c(G * CL * 4) + even_c(G2 * CR);      // pass-1 operands (r, y) + row coefficients
+        const int p2 = (G2 - 1) * N * 2;                          // partials of pass 2 (they reuse the operand area)
+        if (p2 > scratch) scratch = p2;
+        if (scratch - N * 2 > need) need = scratch - N * 2;
+    }
+    return need;
+}
+static_assert(MPC_H_ATOMIC, "the fixed LDS carve reserves room for the hinge ROW SUMS only (the stored hinge matrix of rounds 1-2 is gone)");
+constexpr int HW_ROWS = 32;   // doubles reserved for the hinge row sums D_i; the weights W_i follow at this offset (Ndynobs <= 32)
+__host__ __device__ constexpr FixedLds fixed_lds(int N, int mem, bool lbfgs_in_lds) {
+    FixedLds f{};
+    int o = 0;
+    f.hd = o; o += 64;
+    f.seg = o; o += even_c(N * 9);
+    f.pos = o; o += N * 2;
+    f.stash = o; o += stash_doubles_c(N, mem);
+    // hinge row sums + weights and the item-lane partials are never live together (LDS operations of one wavefront execute in
+    // order): one region
+    f.part = o; f.W = o + HW_ROWS;
+    { const int ps = part_doubles_c(N, mem); o += ps > 2 * HW_ROWS ? ps : 2 * HW_ROWS; }
+    f.rho = o; o += even_c(mem);
+    f.gg = o;   // Gram matrices s_i.y_j (full) + y_i.y_j (packed symmetric), or the alpha scratch of the two-loop form
+    o += gram_shape(N, mem) ? even_c(mem * mem + mem * (mem + 1) / 2) : even_c(mem);
+    f.S = f.Y = f.old = o;
+    if (lbfgs_in_lds) {
+        f.S = o; o += mem * N * 2;
+        f.Y = o; o += mem * N * 2 + N * 2;  // + the zero row
+        f.old = o; o += N * 4;
+    }
+    f.end = o;
+    return f;
+}
+
+// compile-time L-BFGS memory of the kernels with a compile-time horizon (the launcher sends other memories to the generic kernel)
+template <int NT> struct MemOf { static constexpr int value = NT ? 10 : 0; };
 // compile-time horizon NT (0 = runtime horizon from KParams; DPP row counts then cover the whole wave)
 template <int NT>
 struct Dim {
@@ -589,7 +656,10 @@ __device__ __forceinline__ void load_problem(const KParams& kp, const double* __
     cx.il = true;
     cx.ik = lane % N;
     cx.isub = lane / N;
-    double* hd = lds + kp.l_hd;
+    // compiled horizon, one problem per wavefront: the fixed part of the carve sits at compile-time offsets (fixed_lds)
+    constexpr bool FIXED = NT != 0 && !P::DUO;
+    constexpr FixedLds FL = fixed_lds(NT ? NT : 2, MemOf<NT>::value ? MemOf<NT>::value : 1, false);  // fields up to `gg` do not depend on where S, Y live
+    double* hd = lds + (FIXED ? FL.hd : kp.l_hd);
     if (lane < KC_BASE) hd[lane] = ws[lane];
     if (lane < 27) hd[KC_BASE + lane] = KTAB[lane];
     cx.hd = hd;
@@ -598,9 +668,13 @@ __device__ __forceinline__ void load_problem(const KParams& kp, const double* __
     cx.pad_f = U(H_NPF) > 0.0; cx.pad_d = U(H_NPD) > 0.0;
     cx.terminal = U(H_QN) != 0.0 || U(H_QTHN) != 0.0;
     cx.vref = cx.vl ? ws[kp.ws_vref + lane] : 0.0;
-    cx.seg = lds + kp.l_seg; cx.stc = lds + kp.l_stc; cx.fxy = lds + kp.l_fxy;
-    cx.dyn = lds + kp.l_dyn; cx.dync = lds + kp.l_dync; cx.qd = lds + kp.l_qd; cx.pos = lds + kp.l_pos; cx.H = lds + kp.l_H;
-    cx.W = lds + kp.l_W; cx.part = lds + kp.l_part; cx.stash = lds + kp.l_stash;
+    cx.stc = lds + kp.l_stc; cx.fxy = lds + kp.l_fxy;
+    cx.dyn = lds + kp.l_dyn; cx.dync = lds + kp.l_dync; cx.qd = lds + kp.l_qd;
+    if (FIXED) {
+        cx.seg = lds + FL.seg; cx.pos = lds + FL.pos; cx.stash = lds + FL.stash; cx.H = lds + FL.part; cx.W = lds + FL.W; cx.part = lds + FL.part;
+    } else {
+        cx.seg = lds + kp.l_seg; cx.pos = lds + kp.l_pos; cx.stash = lds + kp.l_stash; cx.H = lds + kp.l_H; cx.W = lds + kp.l_W; cx.part = lds + kp.l_part;
+    }
     // coalesced table copies HBM -> LDS (only the active entries of this problem)
     for (int i = lane; i < N * SEGW; i += P::W) cx.seg[i] = ws[kp.ws_seg + i];
     for (int i = lane; i < cx.Ks * STCW; i += P::W) cx.stc[i] = ws[kp.ws_stc + i];
@@ -1562,11 +1636,6 @@ struct PanocLbfgsGram {
     }
 };
 
-// How H * (gamma fpr) is evaluated: 1 = Gram form (PanocLbfgsGram, round 3), 0 = two-loop recursion (PanocLbfgs; the build
-// `make variants` keeps as libmpcgpu_twoloop.so for A/B runs).  Two problems per wavefront (Duo) always take the two-loop form.
-#ifndef MPC_LBFGS_GRAM
-#define MPC_LBFGS_GRAM 1
-#endif
 // The Gram form pays when a horizon leaves most of the wavefront idle in the two-loop reductions AND pass 2 can split the rows
 // over lane groups (64 / N >= 2): measured -7 % at N_hor = 20, but +7 % at N_hor = 40 (one lane group does all 2 mem rows in
 // pass 2, the reductions already use 40 of 64 lanes) -- profiles/r03_lbfgs_gram_ab.txt.  So: Gram for compiled horizons up to
@@ -1574,8 +1643,6 @@ struct PanocLbfgsGram {
 template <int NT> struct GramFor { static constexpr bool value = MPC_LBFGS_GRAM && NT != 0 && WAVE / (NT ? NT : 1) >= 2; };
 template <bool DUO, int NT> struct LbfgsOf { using type = PanocLbfgs; };
 template <> struct LbfgsOf<false, 20> { using type = std::conditional<GramFor<20>::value, PanocLbfgsGram, PanocLbfgs>::type; };
-// compile-time L-BFGS memory of the kernels with a compile-time horizon (the launcher sends other memories to the generic kernel)
-template <int NT> struct MemOf { static constexpr int value = NT ? 10 : 0; };
 
 // ALM / PM outer step: y+ <- y + c (F1(u) - Proj_C(F1(u) + y/c)); ||y+ - y||
 template <class P>
@@ -1645,14 +1712,16 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
     // streamed once per PANOC iteration, one pair ahead of the dot product that consumes them)
     constexpr int MEMT = MemOf<NT>::value;
     LbMem lm;
-    lm.LM = LBG ? io.ws + (size_t)b * kp.ws_stride + kp.ws_lbs : lds + kp.l_S;  // [S; Y], contiguous in both layouts
-    lm.LRHO = lds + kp.l_rho;  // [mem]
-    lm.LALPHA = lds + kp.l_alpha;
+    constexpr bool FIXED = NT != 0 && !P::DUO;   // compile-time offsets of the fixed part of the carve (fixed_lds)
+    constexpr FixedLds FL = fixed_lds(NT ? NT : 2, MEMT ? MEMT : 1, !LBG);
+    lm.LM = LBG ? io.ws + (size_t)b * kp.ws_stride + kp.ws_lbs : lds + (FIXED ? FL.S : kp.l_S);  // [S; Y], contiguous in both layouts
+    lm.LRHO = lds + (FIXED ? FL.rho : kp.l_rho);  // [mem]
+    lm.LALPHA = lds + (FIXED ? FL.gg : kp.l_alpha);
     // [N][4]: L-BFGS old state (u) and old g (gamma*fpr); read and written once per PANOC iteration by its own lane.
     // It follows S and Y into the workspace record (measured: keeping it in LDS when it still fits is no faster for the
     // benchmark batch and slower for small batches and for N = 40).
-    lm.LOLD = LBG ? io.ws + (size_t)b * kp.ws_stride + kp.ws_lold : lds + kp.l_old;
-    lm.GG = lds + kp.l_gg;
+    lm.LOLD = LBG ? io.ws + (size_t)b * kp.ws_stride + kp.ws_lold : lds + (FIXED ? FL.old : kp.l_old);
+    lm.GG = lds + (FIXED ? FL.gg : kp.l_gg);
     lm.XA = cx.pos;  // scratch between two evaluations: positions + stash are dead there
     // pass 2 of the Gram form multiplies EVERY row by its coefficient (0 for the slots that hold no pair): the rows must be finite
     for (int i = lane; i < (2 * mem + 1) * N; i += P::W) reinterpret_cast<double2*>(lm.LM)[i] = make_double2(0.0, 0.0);

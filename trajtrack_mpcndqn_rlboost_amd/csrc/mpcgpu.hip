@@ -177,31 +177,10 @@ void fill_static_params(Handle* h) {
     k.ws_stride = (o + 15) & ~15;
 }
 
-// Item-lane partials (eval_point): every item lane beyond the vector lanes parks 5 doubles.  With a compiled horizon that nearly
-// divides the wavefront (N_hor = 20: 60 item lanes) the split is uniform and the last lanes idle -- the rule of eval_point.
-int part_doubles(const KParams& k) {
-    const int N = k.N;
-    const bool compiled = (N == 20 || N == 40) && k.mem == 10;
-    const bool uniform = compiled && (WAVE % N) * 5 <= N;
-    const int item_lanes = uniform ? (WAVE / N) * N : WAVE;
-    return (item_lanes - N) * PARTW;
-}
-// The stash (6 doubles per step) and the positions before it are dead between two evaluations; the Gram form of the L-BFGS step
-// uses them as scratch there: the operands of pass 1 ((r, s, y) pairs of every chunk slot) followed by the row coefficients.
-// the kernels evaluate the L-BFGS operator in Gram form for the compiled horizons with 64 / N >= 2 (mpc_kernels.hpp GramFor)
-bool gram_layout(const KParams& k) { return MPC_LBFGS_GRAM && k.N == 20 && k.mem == 10; }
-int stash_doubles(const KParams& k) {
-    const int N = k.N;
-    int need = N * 6;
-    if (gram_layout(k)) {
-        const int R = 2 * k.mem, G = (WAVE / 2) / k.mem, CL = (N + G - 1) / G, G2 = WAVE / N, CR = (R + G2 - 1) / G2;
-        int scratch = even(G * CL * 4) + even(G2 * CR);      // pass-1 operands (r, y) + row coefficients
-        const int p2 = (G2 - 1) * N * 2;                      // partials of pass 2 (they reuse the operand area)
-        if (p2 > scratch) scratch = p2;
-        if (scratch - N * 2 > need) need = scratch - N * 2;
-    }
-    return need;
-}
+// sizes of the fixed regions: mpc_kernels.hpp (part_doubles_c, stash_doubles_c, fixed_lds) -- shared with the kernels
+int part_doubles(const KParams& k) { return part_doubles_c(k.N, k.mem); }
+bool gram_layout(const KParams& k) { return gram_shape(k.N, k.mem); }
+int stash_doubles(const KParams& k) { return stash_doubles_c(k.N, k.mem); }
 
 // LDS carve for the batch maxima (doubles; every offset even => 16-byte aligned).
 // shape_const: every active dynamic row of the batch keeps (rx, ry, angle, alpha) over the horizon -> 2 doubles per
@@ -209,8 +188,13 @@ int stash_doubles(const KParams& k) {
 void fill_lds_layout(KParams& k, int mKs, int mKf, int mKd, bool shape_const, bool lbfgs_in_lds) {
     const int N = k.N;
     k.mKs = mKs; k.mKf = mKf; k.mKd = mKd;
-    int o = 0;
-    k.l_seg = o; o += even(N * SEGW);
+    // fixed part first (compile-time offsets in the kernels with a compiled horizon), then the tables that follow the batch
+    const FixedLds f = fixed_lds(N, k.mem, lbfgs_in_lds);
+    k.l_hd = f.hd; k.l_seg = f.seg; k.l_pos = f.pos; k.l_stash = f.stash;
+    k.l_H = f.part; k.l_W = f.W; k.l_part = f.part;
+    k.l_rho = f.rho; k.l_alpha = f.gg; k.l_gg = f.gg;
+    k.l_S = f.S; k.l_Y = f.Y; k.l_old = f.old;
+    int o = f.end;
     k.l_stc = o; o += mKs * STCW;
     k.l_fxy = o; o += mKf * N * 2;
     if (shape_const) {
@@ -221,27 +205,6 @@ void fill_lds_layout(KParams& k, int mKs, int mKf, int mKd, bool shape_const, bo
         k.l_dyn = o; o += even(mKd * N * DYNW);
         k.l_dync = k.l_dyn; k.l_qd = k.l_dyn;
     }
-    k.l_pos = o; o += N * 2;
-    k.l_stash = o; o += stash_doubles(k);
-    k.l_hd = o; o += 64;
-    // H (hinge matrix, read right after it is written) and the item-lane partials are never live together:
-    // LDS operations of the single wave execute in order, so they share one region
-    const int h_rows = MPC_H_ATOMIC ? even(mKd) : even(mKd * N);   // row sums only (accumulated in place) / the whole hinge matrix
-    const int h_sz = h_rows + even(mKd), part_sz = part_doubles(k);
-    k.l_H = o; k.l_W = o + h_rows; k.l_part = o;
-    o += h_sz > part_sz ? h_sz : part_sz;
-    k.l_S = k.l_Y = o;
-    if (lbfgs_in_lds) {
-        k.l_S = o; o += k.mem * N * 2;
-        k.l_Y = o; o += k.mem * N * 2 + N * 2;  // + the zero row
-    }
-    k.l_rho = o; o += even(k.mem);
-    k.l_alpha = o;
-    k.l_gg = o;
-    if (gram_layout(k)) o += even(k.mem * k.mem + k.mem * (k.mem + 1) / 2);  // Gram matrices: s_i.y_j full, y_i.y_j packed symmetric (the alpha scratch of the two-loop form is not needed)
-    else o += even(k.mem);
-    k.l_old = o;
-    if (lbfgs_in_lds) o += N * 4;
     k.l_total = o;
 }
 
