@@ -201,6 +201,28 @@ def test_lbfgs_in_lds_build_is_bitwise_equal_to_the_product_build(N, B):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("N,B,fam", [(20, 512, "passing"), (20, 256, "bench"), (40, 128, "passing")])
+def test_one_call_site_build_is_bitwise_equal_to_the_product_build(N, B, fam):
+    """The product kernel runs the PANOC steps in a loop of their own with separate call sites of the evaluation for the
+    Lipschitz test and the line search (MPC_STEP_LOOP, mpc_kernels.hpp); rounds 1-3 ran ONE loop around ONE call site.  Same
+    device functions on the same inputs: every output must agree bit for bit -- converged, cap-limited and half-way problems,
+    evaluation counters included."""
+    cfg = make_cfg(N)
+    kw = dict(dyn_clearance=0.1, box_clearance=0.3) if fam == "passing" else {}
+    sc = scenes.make_batch(cfg, B, n_dyn=8, seed=77 + N, **kw)
+    a = BatchSolver(cfg, latency_batch=0)
+    b = BatchSolver(cfg, library=variant_path("onesite"), latency_batch=0)
+    ra, rb = a.solve(sc["p"]), b.solve(sc["p"])
+    ea, eb = a.last_eval_counts(B), b.last_eval_counts(B)
+    assert np.array_equal(ra.solution, rb.solution) and np.array_equal(ra.cost, rb.cost)
+    assert np.array_equal(ra.num_inner_iterations, rb.num_inner_iterations)
+    assert np.array_equal(ra.num_outer_iterations, rb.num_outer_iterations)
+    assert np.array_equal(ra.status, rb.status)
+    assert np.array_equal(np.asarray(ea), np.asarray(eb))
+    assert len(set(ra.status.tolist())) >= (2 if fam == "passing" else 1)
+    a.close(); b.close()
+
+
 def test_solve_device_is_ordered_with_torch_work_on_the_same_stream_without_host_sync():
     """`p` is produced by a torch kernel right before solve_device and `u` is consumed by one right after, on torch's
     current stream (raw handle 0 for the default stream), with no host synchronisation in between."""

@@ -1,0 +1,12 @@
+#!/bin/bash
+# usage: tools/kres.sh [extra hipcc flags]  -> registers / scratch of the benchmark solve kernel + its assembly in /tmp/asm/k.s
+# (compile-only: the experiment loop of a register-pressure change needs no GPU)
+cd "$(dirname "$0")/../trajtrack_mpcndqn_rlboost_amd/csrc" || exit 1
+mkdir -p /tmp/asm/k
+K=${KERNEL:-solve_kernel_pairILi20ELb1ELb1ELi4ELb1E}
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-variable -ffp-contract=on -mllvm -amdgpu-sched-strategy=iterative-ilp \
+  --cuda-device-only -S -o /tmp/asm/k/all.s "$@" mpcgpu.hip || exit 1
+awk -v k="$K" '$0 ~ "^_ZN6mpcgpu.*"k".*:" {p=1} p {print} p && /^\.Lfunc_end/ {exit}' /tmp/asm/k/all.s > /tmp/asm/k.s
+grep -E "^; (NumVgprs|ScratchSize|Occupancy|codeLenInByte|NumSgprs)|sgpr_spill_count|vgpr_spill_count" /tmp/asm/k/all.s | head -0
+awk -v k="$K" '$0 ~ "\\.name:.*"k {p=1} p && /(vgpr_count|vgpr_spill|sgpr_spill|private_segment_fixed)/ {print} p && /\.wavefront_size/ {exit}' /tmp/asm/k/all.s
+echo "lines $(wc -l < /tmp/asm/k.s)  scratch ops $(grep -c scratch_ /tmp/asm/k.s)  v_mov_b64 $(grep -c v_mov_b64 /tmp/asm/k.s)  readlane $(grep -c v_readlane /tmp/asm/k.s) writelane $(grep -c v_writelane /tmp/asm/k.s)"

@@ -299,6 +299,12 @@ __device__ __forceinline__ double shift_down1(double x) {  // lane k gets lane k
     return dpp0<DPP_WAVE_SHL1>(x);
 }
 __device__ __forceinline__ double clampd(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
+// A kernel argument / a zero that has to be formed WHERE IT IS USED.  Without this the compiler forms loop invariants such as
+// 0.5 * ts, 2 * fleet weight or a plain 0.0 once, before the solver loop, keeps them in VGPRs for the whole solve -- and, the
+// 128-VGPR build being full, spills them: the reload (a scratch load + s_waitcnt vmcnt(0)) then sits at the head of every
+// evaluation's dependency chain.  One VALU instruction at the point of use is cheaper than that by two orders of magnitude.
+__device__ __forceinline__ double here_s(double x) { asm volatile("" : "+s"(x)); return x; }   // stays an SGPR pair
+__device__ __forceinline__ double zero_here() { double z = 0.0; asm volatile("" : "+v"(z)); return z; }
 
 // inclusive prefix PRODUCT of unit complex numbers (re, im) over lanes 0..16*ROWS-1 (lanes >= n carry 1+0i)
 template <int CTRL, int ROW_MASK>
@@ -745,7 +751,8 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     const int c_ik = lane % N, c_isub = lane / N;
     const int LPS = UNIFORM ? PW / N : (PW - 1 - c_ik) / N + 1;
     constexpr int RV = P::RV, RI = P::RI;
-    const double ts = kp.ts;
+    const double ts = here_s(kp.ts);
+    const double fleetw = here_s(kp.fleetw);
     const double inf = __builtin_huge_val();
     if (!c_vl) { v = 0.0; w = 0.0; }
 
@@ -788,7 +795,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     const double X = HD(H_X0) + pX;
     const double Y = HD(H_Y0) + pY;
 #if MPC_H_ATOMIC
-    if (lane < cx.Kd) cx.H[lane] = 0.0;   // row sums of the hard-constraint hinges, accumulated by the item lanes below
+    if (lane < cx.Kd) cx.H[lane] = zero_here();   // row sums of the hard-constraint hinges, accumulated by the item lanes below
 #endif
     if (c_vl) {
         cx.pos[2 * lane] = X; cx.pos[2 * lane + 1] = Y;
@@ -874,9 +881,9 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
             const double ex = px - cx.fxy[(j * N + k) * 2], ey = py - cx.fxy[(j * N + k) * 2 + 1];
             const double hh = kp.W2 - (ex * ex + ey * ey);
             if (hh > 0.0) {
-                cost_l += kp.fleetw * hh;
-                gx -= 2.0 * kp.fleetw * ex;
-                gy -= 2.0 * kp.fleetw * ey;
+                cost_l += fleetw * hh;
+                gx -= 2.0 * fleetw * ex;
+                gy -= 2.0 * fleetw * ey;
             }
         }
         // static polygons, 4 half-planes each (mpc_generator.py:219-225,46-54)
@@ -935,7 +942,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         r2o = X * X + Y * Y;
         if (cx.pad_f) {
             const double hh = kp.W2 - r2o;
-            if (hh > 0.0) cost_l += kp.fleetw * HD(H_NPF) * hh;  // its gradient is added on the vector lanes below
+            if (hh > 0.0) cost_l += fleetw * HD(H_NPF) * hh;  // its gradient is added on the vector lanes below
         }
         if (cx.pad_d) {
             const double ipad = KC(K_IPAD);
@@ -1024,8 +1031,8 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         Gx += HD(H_QRPD) * wbx; Gy += HD(H_QRPD) * wby;
         vcost = HD(H_QRPD) * bb;
         if (cx.pad_f && kp.W2 - r2o > 0.0) {
-            Gx -= 2.0 * kp.fleetw * HD(H_NPF) * X;
-            Gy -= 2.0 * kp.fleetw * HD(H_NPF) * Y;
+            Gx -= 2.0 * fleetw * HD(H_NPF) * X;
+            Gy -= 2.0 * fleetw * HD(H_NPF) * Y;
         }
     }
 
@@ -1136,6 +1143,18 @@ __global__ __launch_bounds__(WAVE) void cost_grad_kernel(KParams kp, BatchPtrs i
 // ------------------------------------------------------------------------------------------------
 enum { ST_INIT0 = 0, ST_INIT1, ST_LIP, ST_NOLS, ST_LS, ST_OUTER };
 
+// 1 (round 3): the PANOC steps of an inner problem run in a loop of their OWN inside the state machine, with one call site of
+// eval_point for the Lipschitz test and one for the trial points of the line search (solve_body).  0: rounds 1-3, ONE call site:
+// every evaluation is a state of the machine (`make variants` keeps it as libmpcgpu_onesite.so for A/B runs).  Same arithmetic,
+// same bits; what changes is what the register allocator has to carry.  With one loop around one call site every variable of the
+// solver is a loop-carried value of that loop: on EVERY evaluation ~20 of them were shuffled into their loop-header registers
+// (v_mov_b64), four went through scratch (store at the latch, reload at the use -- the ~3 TB of write traffic per launch the
+// rocprof passes of rounds 1-3 showed) and 18 SGPR state words were copied.  In the step loop the line search carries (tau, the
+// trial point) and nothing else; u, gamma fpr, the direction and the step's scalars are loop-invariant around it.  Measured
+// (profiles/r03_step_loop_ab.txt): 1018 -> 896 ms at B = 32 768 (-12 %), 322 -> 281 ms at B = 8192, code 27 -> 44 KB.
+#ifndef MPC_STEP_LOOP
+#define MPC_STEP_LOOP 1
+#endif
 #ifndef MPC_MIN_WAVES
 #define MPC_MIN_WAVES 3  // waves per SIMD the register allocator must leave room for (512 / MPC_MIN_WAVES VGPRs)
 #endif
@@ -1792,7 +1811,9 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
             panoc_lip_estimate<P>(cx, o.gv - gv, o.gw - gw, nh, Lip, gamma, ig, sigma);
             panoc_envelope_sums<P>(kp, vl, uv, uw, gamma, gv, gw, hv, hw, gg, d2h);
             step_begin = true;
-        } else if (state == ST_LIP) {
+        }
+#if !MPC_STEP_LOOP
+        else if (state == ST_LIP) {
             const double cost_half = o.psi;
             if (panoc_lip_test_fails(cx, cost_half, cost, ip, ig, nfpr) && lip_it < MAX_LIP_IT && Lip < KC(K_MAX_LIP)) {
                 lb.flush();  // invalidate the L-BFGS buffer
@@ -1822,7 +1843,9 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
             ev = panoc_trial(uv, rv_, dv, tau); ew = panoc_trial(uw, rw_, dw, tau);  // u_plus
             want_grad = true; state = ST_LS;
             continue;
-        } else if (state == ST_NOLS) {
+        }
+#endif
+        else if (state == ST_NOLS) {
             cost = P::uni(o.psi); gv = o.gv; gw = o.gw;
             panoc_envelope_sums<P>(kp, vl, uv, uw, gamma, gv, gw, hv, hw, gg, d2h);
 #ifdef MPC_TRACE
@@ -1830,7 +1853,9 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
 #endif
             ++iter;
             step_begin = true;
-        } else if (state == ST_LS) {
+        }
+#if !MPC_STEP_LOOP
+        else if (state == ST_LS) {
             // (ev, ew) is the trial point u_plus
             cost = P::uni(o.psi); gv = o.gv; gw = o.gw;
             panoc_envelope_sums<P>(kp, vl, ev, ew, gamma, gv, gw, hv, hw, gg, d2h);
@@ -1856,7 +1881,9 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
 #endif
             ++iter;
             step_begin = true;
-        } else {  // ST_OUTER: evaluated at the inner solution (c, y still those of the inner problem)
+        }
+#endif
+        else {  // ST_OUTER: evaluated at the inner solution (c, y still those of the inner problem)
             inner_total += num_iter;
             last_fpr = nfpr;
             f_final = P::uni(o.f);
@@ -1893,6 +1920,92 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
             continue;
         }
 
+#if MPC_STEP_LOOP
+        if (step_begin) {
+            // ---- the PANOC steps of an inner problem: a loop of its own with its own call sites of eval_point (Lipschitz test,
+            //      line search); the state machine above is left with the evaluations that happen ten times per solve.
+            bool count_step = state != ST_INIT1;   // a full step has completed: the solver loop's bookkeeping
+            bool to_nols = false;
+            for (;;) {
+                bool inner_done = false;
+                if (count_step) {
+                    if (cont_iters && cont_time) {
+                        ++num_iter;
+                        cont_iters = num_iter < kp.max_inner;
+                        if (kp.max_ticks > 0) cont_time = (wall_clock64() - t_start) <= kp.max_ticks;
+                    } else {
+                        inner_done = true;
+                    }
+                }
+                count_step = true;
+                if (!inner_done && panoc_step_residual<P>(cx, kp, vl, uv, uw, hv, hw, gv, gw, gamma, iter, akkt_tol, rv_, rw_, nfpr, ip))
+                    inner_done = true;
+                if (inner_done) break;
+                lip_it = 0;
+                for (;;) {   // Lipschitz test at the half step
+                    PROF_MARK(10 + ST_LIP);
+                    PROF_COUNT(16 + ST_LIP);
+                    ++n_eval;
+                    eval_point<NT, SC, P, AXIS>(kp, cx, hv, hw, c, icm, ya, yb, false, false, o PROF_PASS);
+                    const double cost_half = o.psi;
+                    if (panoc_lip_test_fails(cx, cost_half, cost, ip, ig, nfpr) && lip_it < MAX_LIP_IT && Lip < KC(K_MAX_LIP)) {
+                        lb.flush();  // invalidate the L-BFGS buffer
+                        panoc_lip_update<P>(kp, vl, uv, uw, gv, gw, Lip, gamma, ig, hv, hw, rv_, rw_, d2h, nfpr, ip);
+                        ++lip_it;
+                        continue;
+                    }
+                    break;
+                }
+                sigma = P::uni(KC(K_SIGMA) * ig);
+#ifdef MPC_TRACE
+                tr_psi_u = cost;
+#endif
+                double lb_pr = 0.0;
+                lb.template update<P, NT, MEMT>(cx, kp, vl, lane, uv, uw, rv_, rw_, nfpr, lm, lb_pr);
+                wave_sync();
+                if (iter == 0) { to_nols = true; break; }   // first iteration of an inner problem: no line search (state machine)
+                lb.template direction<P, NT, MEMT, LBG>(cx, kp, vl, lane, rv_, rw_, lm, lb_pr, dv, dw);
+                rhs = P::uni(panoc_fbe_rhs(cost, gamma, ig, gg, d2h, sigma, nfpr));
+                tau = 1.0; nls = 0;
+                ev = panoc_trial(uv, rv_, dv, tau); ew = panoc_trial(uw, rw_, dw, tau);  // u_plus
+                for (;;) {   // line search on the forward-backward envelope
+                    PROF_MARK(10 + ST_LS);
+                    PROF_COUNT(16 + ST_LS);
+                    ++n_eval; ++n_eval_grad;
+                    eval_point<NT, SC, P, AXIS>(kp, cx, ev, ew, c, icm, ya, yb, true, false, o PROF_PASS);
+                    cost = P::uni(o.psi); gv = o.gv; gw = o.gw;
+                    panoc_envelope_sums<P>(kp, vl, ev, ew, gamma, gv, gw, hv, hw, gg, d2h);
+                    const double lhs = panoc_fbe(cost, gamma, ig, gg, d2h);
+                    if (lhs > rhs && nls < MAX_LS_IT) {
+                        tau = P::uni(tau * 0.5); ++nls;
+                        ev = panoc_trial(uv, rv_, dv, tau); ew = panoc_trial(uw, rw_, dw, tau);
+                        continue;
+                    }
+                    if (kp.ls_fallback == 1 && lhs > rhs && tau != 0.0) {   // see ST_LS
+                        tau = 0.0;
+                        ev = uv - rv_; ew = uw - rw_;
+                        continue;
+                    }
+                    break;
+                }
+                uv = ev; uw = ew;
+#ifdef MPC_TRACE
+                tr_write(nls, tau);
+#endif
+                ++iter;
+            }
+            if (to_nols) {
+                uv = hv; uw = hw;
+                ev = uv; ew = uw; want_grad = true; state = ST_NOLS;
+                continue;
+            }
+            // inner problem finished: the feasible half step is the result
+            status = !cont_iters ? 1 : (!cont_time ? 2 : 0);
+            uv = hv; uw = hw;
+            ev = uv; ew = uw; want_grad = false; state = ST_OUTER;
+        }
+    }
+#else
         if (step_begin) {
             bool inner_done = false;
             if (state != ST_INIT1) {  // a full step has completed: the solver loop's bookkeeping
@@ -1920,6 +2033,7 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
         }
     }
 
+#endif
 #ifdef MPC_PROFILE
     prof.mark(22); prof.flush();
 #endif
