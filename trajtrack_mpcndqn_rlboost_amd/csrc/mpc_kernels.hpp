@@ -72,7 +72,17 @@ constexpr int DYNC = 7;        // shape-constant LDS record per row: cosA, sinA,
                                // (the item weight q_dyn[k] * alpha is formed where it is used: q_dyn is one value per step)
 constexpr int PARTW = 5;       // doubles per item-lane partial  (gx, gy, best, bgx, bgy)
 constexpr int MAX_MEM = 16;
-constexpr int SEG_WIN = 2;     // reference segments per item lane that are evaluated unconditionally
+// Reference segments per item lane that are evaluated unconditionally before the suffix-circle test takes over.  Rounds 1-3: 2
+// (the 6 nearest segments of a step at N_hor = 20; the pruned loop then ran in 0.1 % of the evaluations).  1 = the 3 nearest:
+// the pruned loop runs in 2.2 % of the evaluations and one unconditional trip per evaluation is gone: -3.0 % kernel time at
+// N_hor = 20, -1.6 % at N_hor = 40, same bits (the same segments win in the same order; profiles/r03_step_loop_ab.txt).
+#ifndef MPC_HMASK
+#define MPC_HMASK 1
+#endif
+#ifndef MPC_SEG_WIN
+#define MPC_SEG_WIN 1
+#endif
+constexpr int SEG_WIN = MPC_SEG_WIN;
 
 // header slots (doubles); 0..17 are p[0..17] of the reference layout
 enum { H_X0 = 0, H_Y0 = 1, H_TH0 = 2, H_XG = 3, H_YG = 4, H_THG = 5, H_VINIT = 6, H_WINIT = 7, H_QVEL = 9, H_RV = 11, H_RW = 12,
@@ -382,6 +392,7 @@ struct Solo {
     static __device__ __forceinline__ int half() { return 0; }
     static __device__ __forceinline__ int problem() { return blockIdx.x; }
     static __device__ __forceinline__ double uni(double x) { return uniform(x); }
+    static __device__ __forceinline__ unsigned uni_u(unsigned x) { return (unsigned)__builtin_amdgcn_readfirstlane((int)x); }
     template <int ROWS> static __device__ __forceinline__ double sum(double x) { return wave_sum_u<ROWS>(x); }
     // two independent sums over the vector lanes
     static __device__ __forceinline__ void sum2(double a, double b, double& sa, double& sb) {
@@ -420,6 +431,7 @@ struct Duo {
     static __device__ __forceinline__ int half() { return threadIdx.x >> 5; }
     static __device__ __forceinline__ int problem() { return 2 * blockIdx.x + (threadIdx.x >> 5); }
     static __device__ __forceinline__ double uni(double x) { return x; }
+    static __device__ __forceinline__ unsigned uni_u(unsigned x) { return x; }
     template <int ROWS> static __device__ __forceinline__ double sum(double x) { return half_allsum(x); }
     static __device__ __forceinline__ void sum2(double a, double b, double& sa, double& sb) { sa = half_allsum(a); sb = half_allsum(b); }
     static __device__ __forceinline__ bool any(bool c) {
@@ -813,6 +825,16 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     double best = inf, bgx = 0.0, bgy = 0.0;
     double px = 0.0, py = 0.0;
     bool anyh = false;
+    // Dynamic rows are visited in TRIPS (trip t: row c_isub + t LPS of every item lane).  Bit t of hmask: some item lane of trip t
+    // lies inside a hard ellipse -- the second item pass (weighted hard-constraint gradients) then skips the trips in which no
+    // lane has anything to add: the obstacle that is being crossed sits in one or two rows, the others are far away.  Kept where
+    // the steps of the second half of the horizon have ONE item lane each and a trip is a single row (N_hor = 40: -1.5 % kernel
+    // time); with three lanes per step (N_hor = 20: three trips of three rows) the ballots cost what the skipped trips save
+    // (+1 %, measured) and the rows are walked as in rounds 1-3.
+    constexpr bool HM = MPC_HMASK && !UNIFORM;
+    unsigned hmask = 0u;
+    const int minLPS = UNIFORM ? PW / N : (PW - N) / N + 1;
+    const int ntrip = HM ? (cx.Kd + minLPS - 1) / minLPS : 0;
     if (c_il) {
         const int k = c_ik;
         px = cx.pos[2 * k]; py = cx.pos[2 * k + 1];
@@ -907,31 +929,38 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         }
         PROF_MARK(3);  // fleet + static
         // dynamic ellipses: hard indicator -> H, soft cost with social margin (mpc_generator.py:229-241,38-44,85-95)
+        // one body for both walks: HM: t = 0 .. ntrip-1 for every lane, row c_isub + t LPS if it exists; else i = c_isub, c_isub + LPS ...
         MPC_ITEM_LOOP
-        for (int i = c_isub; i < cx.Kd; i += LPS) {
-            const DynItem d = dyn_item<SC, AXIS>(cx, i, k, N, px, py);
-            const double a2 = d.a * d.a, b2 = d.b * d.b;
-            const double Ih = 1.0 - a2 * d.ihx - b2 * d.ihy;
-            anyh |= Ih > 0.0;
+        for (int t = 0, i = c_isub; HM ? t < ntrip : i < cx.Kd; ++t, i += LPS) {
+            bool inside = false;
+            if (!HM || i < cx.Kd) {
+                const DynItem d = dyn_item<SC, AXIS>(cx, i, k, N, px, py);
+                const double a2 = d.a * d.a, b2 = d.b * d.b;
+                const double Ih = 1.0 - a2 * d.ihx - b2 * d.ihy;
+                inside = Ih > 0.0;
+                anyh |= inside;
 #if MPC_H_ATOMIC
-            if (Ih > 0.0) lds_add(cx.H + i, Ih);      // D_i = sum_k max(0, Ih(i, k)): accumulated where the terms arise
+                if (Ih > 0.0) lds_add(cx.H + i, Ih);      // D_i = sum_k max(0, Ih(i, k)): accumulated where the terms arise
 #else
-            cx.H[i * N + k] = Ih > 0.0 ? Ih : 0.0;
+                cx.H[i * N + k] = Ih > 0.0 ? Ih : 0.0;
 #endif
-            const double Is = 1.0 - a2 * d.isx - b2 * d.isy;
-            if (Is > 0.0) {
-                cost_l += d.wgt * Is * Is;
-                const double wI = 2.0 * d.wgt * Is;
-                if (AXIS) {   // the general terms with cos = 1, sin = 0: the products by 1 are exact, those by 0 vanish
-                    gx += wI * (-2.0 * d.a * d.isx);
-                    gy += wI * (2.0 * d.b * d.isy);
-                } else {
-                    gx += wI * (-2.0 * d.a * d.ca * d.isx - 2.0 * d.b * d.sa * d.isy);
-                    gy += wI * (-2.0 * d.a * d.sa * d.isx + 2.0 * d.b * d.ca * d.isy);
+                const double Is = 1.0 - a2 * d.isx - b2 * d.isy;
+                if (Is > 0.0) {
+                    cost_l += d.wgt * Is * Is;
+                    const double wI = 2.0 * d.wgt * Is;
+                    if (AXIS) {   // the general terms with cos = 1, sin = 0: the products by 1 are exact, those by 0 vanish
+                        gx += wI * (-2.0 * d.a * d.isx);
+                        gy += wI * (2.0 * d.b * d.isy);
+                    } else {
+                        gx += wI * (-2.0 * d.a * d.ca * d.isx - 2.0 * d.b * d.sa * d.isy);
+                        gy += wI * (-2.0 * d.a * d.sa * d.isx + 2.0 * d.b * d.ca * d.isy);
+                    }
                 }
             }
+            if (HM && P::any(inside)) hmask |= 1u << t;
         }
     }
+    if (HM) hmask = P::uni_u(hmask);
     PROF_MARK(4);  // dynamic
     double X = 0.0, Y = 0.0;  // position of this vector lane's step, back from LDS
     if (c_vl) { X = cx.pos[2 * lane]; Y = cx.pos[2 * lane + 1]; }
@@ -950,7 +979,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         }
     }
     const bool any_hp = P::any(hp > 0.0);
-    const bool any_h = P::any(anyh);
+    const bool any_h = HM ? hmask != 0u : P::any(anyh);
     wave_sync();
 
     // ---- constraint sums: S (static, broadcast into every F2 component), D_i (row sums of H).
@@ -984,7 +1013,8 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
             const int k = c_ik;
             if (any_h) {
                 MPC_ITEM_LOOP
-        for (int i = c_isub; i < cx.Kd; i += LPS) {
+                for (int t = 0, i = c_isub; HM ? t < ntrip : i < cx.Kd; ++t, i += LPS) {
+                    if (HM && (!((hmask >> t) & 1u) || i >= cx.Kd)) continue;   // no lane of this trip is inside a hard ellipse
                     const DynItem d = dyn_item<SC, AXIS>(cx, i, k, N, px, py);
                     const double Ih = 1.0 - d.a * d.a * d.ihx - d.b * d.b * d.ihy;
                     if (Ih > 0.0) {
