@@ -53,7 +53,7 @@ def flops_per_eval(N: int, Ks: int, Kf: int, Kd: int, grad: bool) -> float:
     # reference segments: SEG_WIN * LPS of them are always evaluated (fewer near the end of the horizon: N - k remain);
     # 20 flops each (projection 6, clamp 2, offset 6, distance 3, compare) + 8 for the gradient of the running minimum
     lps = max(1, 64 // N)
-    seg = sum(min(2 * lps, N - k) for k in range(N)) / N
+    seg = sum(min(1 * lps, N - k) for k in range(N)) / N   # SEG_WIN = 1 (2 in rounds 1-3)
     per_step += seg * 24 + 6            # + pruning test against the suffix bounding circle
     per_step += Ks * 27                 # 4 half-planes (4 x 4), squares (4), products (3), compare; gradient only inside
     per_step += Kf * 6                  # squared distance + hinge

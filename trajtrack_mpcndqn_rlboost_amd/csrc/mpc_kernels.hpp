@@ -1006,7 +1006,9 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     // ---- item phase B (only when some penalty constraint is violated): weighted hard-constraint gradients
     double Gpx = 0.0, Gpy = 0.0;  // vector lanes: gradient of the padded-row terms w.r.t. the position
     if (want_grad && viol) {
-        const double sumF2 = P::template sum<2>(F2e) + HD(H_NPD) * F2pad;
+        // sum of ALL F2 entries: the weight of the static-polygon term S inside every entry.  Its gradient (dsx, dsy) is exactly
+        // zero in every lane unless some lane is inside a polygon (any_S): the reduction is formed only then
+        const double sumF2 = any_S ? P::template sum<2>(F2e) + HD(H_NPD) * F2pad : 0.0;
         if (lane < cx.Kd) cx.W[lane] = c * F2e;
         wave_sync();
         if (c_il) {
@@ -1029,8 +1031,10 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
                     }
                 }
             }
-            gx += c * sumF2 * dsx;
-            gy += c * sumF2 * dsy;
+            if (any_S) {
+                gx += c * sumF2 * dsx;
+                gy += c * sumF2 * dsy;
+            }
         }
         if (any_hp && hp > 0.0) {  // a = X, b = -Y for the padded ellipse (cosA = 1, sinA = 0)
             const double ipad = KC(K_IPAD);
@@ -1165,7 +1169,9 @@ __global__ __launch_bounds__(WAVE) void cost_grad_kernel(KParams kp, BatchPtrs i
 
 // ------------------------------------------------------------------------------------------------
 // solver kernels: ALM/PM outer loop around PANOC, one problem per wavefront.
-// The iteration is organised as a small state machine around ONE call site of eval_point.
+// The iteration is organised as a small state machine (initial point, Lipschitz estimate, first step, outer step: the
+// evaluations that happen once per inner problem) around the loop of the PANOC steps, which has its own call sites of
+// eval_point for the Lipschitz test and the line search (MPC_STEP_LOOP below).
 //   solve_kernel_pair: lane k holds (v_k, w_k) of every horizon vector, L-BFGS memory in LDS.
 //   (An element-per-lane variant with the L-BFGS memory in 40 VGPRs was built and measured in round 1: the
 //   unrolled register-resident two-loop recursion pushed the kernel past 256 VGPRs and it ran 1.6-2.8x slower;
@@ -1722,7 +1728,7 @@ __device__ __forceinline__ bool alm_stalled(const Ctx& cx, const KParams& kp, in
 }
 
 // The whole ALM / PANOC solve of problem P::problem() on the lanes P gives it.  `lds` is the workgroup's dynamic LDS.
-// The iteration is a small state machine around ONE call site of eval_point.
+// The rare evaluations are states of a small machine; the PANOC steps run in a loop of their own (MPC_STEP_LOOP).
 template <int NT, bool SC, bool LBG, class P, bool AXIS = false>
 __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& io, int B, double* lds) {
     const int b = P::problem();
