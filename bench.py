@@ -27,9 +27,12 @@ child's code.  It exits non-zero when fewer than N devices are present, and when
 Rank 0 prints ONE JSON line (contract in the task description) with extra objects:
   roofline      -- dominant kernel (solve_kernel) against the HBM roofline, timed with HIP events on the launch
                    stream IN THIS RUN; `flops` is the executed f64 flop rate from the in-kernel evaluation counters
-                   of this run.  Everything that comes from a rocprofv3 PMC pass (`traffic`, `secondary`) is read
-                   from profiles/r03_roofline_bench.json -- collected on this very workload, rebuilt from the raw
-                   CSVs by tools/roofline.py -- and is marked `measured_in_run: false`.
+                   of this run.  What needs hardware counters (`traffic`, `secondary`) is measured in this run as well
+                   when rocprofv3 is there (N = 1): after the timed legs, three `rocprofv3 --pmc` passes (SQ counters,
+                   FETCH_SIZE, WRITE_SIZE: one pass each, never combined with a trace) over a child bench.py on the
+                   same parameter vectors, rebuilt by tools/roofline.py -- `measured_in_run: true`.  Without the
+                   profiler (or with --no-pmc) the fields come from profiles/r03_roofline_bench.json -- the committed
+                   passes on this very workload -- and are marked `measured_in_run: false` with the reason.
   config.convergent -- the same step on the "passing" scene family (same N, obstacle counts and batch; a
                    collision-free plan exists), where about half of the solves converge: the headline family is the
                    one SURVEY.md 8(d) prescribes and it is cap-limited (see status_histogram).
@@ -77,6 +80,8 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 disables)")
     ap.add_argument("--no-convergent", action="store_true", help="skip the second leg (profiling runs)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the reference-batch legs (profiling runs)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not re-measure the counter-based roofline fields in this run")
+    ap.add_argument("--p-file", default=None, help=argparse.SUPPRESS)   # counter passes: the parent's parameter vectors (.npy)
     return ap.parse_args(argv)
 
 
@@ -99,6 +104,58 @@ def self_launch(args) -> int:
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
+
+
+PMC_PASSES = (("pmc_sq", ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_INSTS_SALU", "SQ_WAVES", "GRBM_GUI_ACTIVE")),
+              ("pmc_fetch", ("FETCH_SIZE",)),
+              ("pmc_write", ("WRITE_SIZE",)))
+
+
+def pmc_in_run(args, p_host):
+    """The counter-based roofline fields, measured IN THIS RUN: three `rocprofv3 --pmc` passes (SQ counters, FETCH_SIZE and
+    WRITE_SIZE each in a pass of its own -- never combined with a trace) over a CHILD bench.py on the very same parameter vectors
+    (one warm-up + one timed launch of the whole shard, no side legs), then tools/roofline.py's rebuild on the CSVs.  The
+    profiled program is `python3 bench.py ...` itself, placed directly after `--`.  Returns (derived dict, None) or
+    (None, reason)."""
+    import shutil
+    import tempfile
+    rp = shutil.which("rocprofv3")
+    if rp is None:
+        return None, "rocprofv3 not on PATH"
+    raw = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+    pfile = os.path.join(raw, "p.npy")
+    try:
+        np.save(pfile, p_host)
+        with open(os.path.join(raw, "workload.json"), "w") as fh:
+            json.dump({"N_hor": args.horizon, "n_dyn": args.n_dyn, "batch_per_gpu": args.batch, "steps": 1, "warmup": 1,
+                       "command": "bench.py's own counter passes (pmc_in_run)"}, fh)
+        child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--cpu-seconds", "0",
+                 "--no-convergent", "--no-sweep", "--no-pmc", "--batch", str(args.batch), "--n-dyn", str(args.n_dyn),
+                 "--horizon", str(args.horizon), "--p-file", pfile]
+        env = dict(os.environ, TMPDIR="/tmp")
+        env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+        t0 = time.perf_counter()
+        for name, counters in PMC_PASSES:
+            cmd = [rp, "--pmc", *counters, "--output-format", "csv", "-d", os.path.join(raw, name), "-o", name, "--"] + child
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+            if r.returncode != 0:
+                return None, f"{name}: rocprofv3 exit code {r.returncode}: " + r.stdout.decode(errors="replace")[-200:]
+            found = None
+            for d, _, files in os.walk(os.path.join(raw, name)):
+                for f in files:
+                    if f.endswith("counter_collection.csv"):
+                        found = os.path.join(d, f)
+            if found is None:
+                return None, f"{name}: no counter_collection.csv"
+            shutil.copy(found, os.path.join(raw, name + "_counter_collection.csv"))
+        from tools.roofline import rebuild
+        d = rebuild(raw, os.path.join(raw, "roofline.json"))
+        d["pmc_passes_wall_s"] = time.perf_counter() - t0
+        return d, None
+    except Exception as e:   # noqa: BLE001 -- the bench line must come out whatever the profiler does
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(raw, ignore_errors=True)
 
 
 class StubSolver:
@@ -271,7 +328,11 @@ def main():
         return max(vals), vals
 
     # every rank owns its own B robots of the global scene set (weak scaling): global problem g = rank*B + i
-    sc = scenes.make_batch(cfg, B, n_dyn=args.n_dyn, seed=1234 + 7919 * rank)
+    if args.p_file:   # counter pass of a parent bench.py: its parameter vectors, not a second scene generation
+        sc = {"p": np.load(args.p_file)}
+        assert sc["p"].shape == (B, cfg.num_params), sc["p"].shape
+    else:
+        sc = scenes.make_batch(cfg, B, n_dyn=args.n_dyn, seed=1234 + 7919 * rank)
     p = torch.from_numpy(sc["p"]).to(dev)
     leg = timed_leg(p, args.steps, args.warmup)
     elapsed, per_rank_s = over_ranks(leg["elapsed"])
@@ -365,6 +426,10 @@ def main():
         if not stub:
             from tools.roofline import flops_per_solve_kernel_launch, load_pmc_for
             pmc = load_pmc_for(ROOFLINE_JSON, N, args.n_dyn, B)
+            pmc_here, pmc_err = (None, "disabled (--no-pmc)") if (args.no_pmc or world > 1) else pmc_in_run(args, sc["p"])
+            in_run = pmc_here is not None
+            if in_run:
+                pmc = pmc_here
             shape = solver.last_shape()
             flops = flops_per_solve_kernel_launch(N, shape["max_static"], shape["max_fleet"], shape["max_dyn"], n_psi, n_grad)
             tf = flops / (k_ms * 1e-3) / 1e12
@@ -373,12 +438,15 @@ def main():
                     "kernel": "solve_kernel", "kernel_ms": k_ms, "prep_kernel_ms": leg["prep_ms"],
                     "algorithmic_bytes_per_solve": algo_bytes // B,
                     "measured_in_run": {"achieved": True, "kernel_ms": True, "frac": True, "flops": True,
-                                        "traffic": False, "wasted_traffic_ratio": False, "traffic_GBps": False,
-                                        "secondary": False},
+                                        "traffic": in_run, "wasted_traffic_ratio": in_run, "traffic_GBps": in_run,
+                                        "secondary": in_run},
                     "wasted_traffic_ratio": (pmc["traffic_bytes_per_launch"] / algo_bytes) if pmc else None,
                     "traffic_GBps": (pmc["traffic_bytes_per_launch"] / (pmc["kernel_avg_ms_kernel_trace"] * 1e-3) / 1e9) if pmc else None,
-                    "traffic_source": (os.path.relpath(ROOFLINE_JSON, ROOT) + ": separate rocprofv3 --pmc passes on this "
-                                       "workload; NOT re-measured in this run") if pmc else None,
+                    "traffic_source": (("this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, one pass each, over a child "
+                                        f"bench.py on the same parameter vectors ({pmc_here['pmc_passes_wall_s']:.0f} s for the three "
+                                        "counter passes)") if in_run else
+                                       (os.path.relpath(ROOFLINE_JSON, ROOT) + ": separate rocprofv3 --pmc passes on this "
+                                        f"workload; NOT re-measured in this run ({pmc_err})") if pmc else None),
                     "note": "state is register/LDS/L2 resident: the kernel is VALU-issue bound (see secondary); traffic = "
                             "L2<->fabric bytes of the kernel's own cold state (L-BFGS ring, spill slots), DESIGN.md section 2",
                     "flops": {"bound": "valu_f64_flops", "achieved": tf, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s",
@@ -389,13 +457,14 @@ def main():
             if pmc:
                 # VALU issue: instructions per launch from the PMC pass of this workload over THAT pass's kernel time, against
                 # one wave64 instruction per 4 cycles per SIMD
-                roof["secondary"] = {"bound": "valu_issue", "measured_in_run": False,
+                roof["secondary"] = {"bound": "valu_issue", "measured_in_run": in_run,
                                      "frac": pmc["valu_issue_frac_of_peak"],
                                      "valu_busy_frac_pmc": pmc["valu_busy_fraction"],
                                      "resident_waves_per_simd": pmc["resident_waves_per_simd"],
                                      "valu_instructions_per_solve": pmc["valu_instructions_per_launch"] / B,
                                      "kernel_ms_of_the_pmc_pass": pmc["kernel_avg_ms_kernel_trace"],
-                                     "source": os.path.relpath(ROOFLINE_JSON, ROOT)}
+                                     "source": "this run: rocprofv3 --pmc SQ_* pass over a child bench.py" if in_run
+                                               else os.path.relpath(ROOFLINE_JSON, ROOT)}
             line["roofline"] = roof
         if args.cpu_seconds > 0 and world == 1 and not stub:
             line["cpu_baseline"] = cpu_baseline(cfg, sc["p"], args.cpu_seconds)

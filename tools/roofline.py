@@ -99,6 +99,19 @@ def _read_counters(path, kernel_substr):
     return dict(tot), len(disp)
 
 
+def _dispatch_avg_ns(path, kernel_substr):
+    """Average duration of the kernel's dispatches from the timestamps of a counter-collection CSV (every row of a dispatch
+    carries them), and the number of dispatches."""
+    dur = {}
+    with open(path, newline="") as fh:
+        for row in csv.DictReader(fh):
+            if kernel_substr in row["Kernel_Name"] and row.get("Start_Timestamp") and row.get("End_Timestamp"):
+                dur[row["Dispatch_Id"]] = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+    if not dur:
+        raise KeyError(kernel_substr)
+    return sum(dur.values()) / len(dur), len(dur)
+
+
 def _kernel_avg_ns(path, kernel_substr):
     with open(path, newline="") as fh:
         for row in csv.DictReader(fh):
@@ -113,8 +126,15 @@ def rebuild(raw_dir, out_path):
     B, N = wl["batch_per_gpu"], wl["N_hor"]
     np_ = 18 + 4 * N + 3 * N * 10 + 120 + 15 * 6 * N + 2 * N       # mpc_default.yaml dimensions
     algo = 8 * np_ + 16 * N * 2 + 40
-    avg_ns, calls = _kernel_avg_ns(os.path.join(raw_dir, "kt_kernel_stats.csv"), "solve_kernel")
-    prep_ns, _ = _kernel_avg_ns(os.path.join(raw_dir, "kt_kernel_stats.csv"), "prep_kernel")
+    kt = os.path.join(raw_dir, "kt_kernel_stats.csv")
+    if os.path.exists(kt):
+        avg_ns, calls = _kernel_avg_ns(kt, "solve_kernel")
+        prep_ns, _ = _kernel_avg_ns(kt, "prep_kernel")
+        time_source = "rocprofv3 --kernel-trace --stats pass"
+    else:   # bench.py's in-run passes: no kernel-trace pass, the dispatch timestamps of the SQ counter pass itself
+        avg_ns, calls = _dispatch_avg_ns(os.path.join(raw_dir, "pmc_sq_counter_collection.csv"), "solve_kernel")
+        prep_ns, _ = _dispatch_avg_ns(os.path.join(raw_dir, "pmc_sq_counter_collection.csv"), "prep_kernel")
+        time_source = "dispatch timestamps of the SQ counter pass"
     sq, n_sq = _read_counters(os.path.join(raw_dir, "pmc_sq_counter_collection.csv"), "solve_kernel")
     fe, n_fe = _read_counters(os.path.join(raw_dir, "pmc_fetch_counter_collection.csv"), "solve_kernel")
     wr, n_wr = _read_counters(os.path.join(raw_dir, "pmc_write_counter_collection.csv"), "solve_kernel")
@@ -130,7 +150,7 @@ def rebuild(raw_dir, out_path):
     derived = {
         "workload": wl,
         "kernel": wl.get("kernel", "solve_kernel_pair"),
-        "kernel_avg_ms_kernel_trace": avg_ns * 1e-6, "kernel_calls_kernel_trace": calls,
+        "kernel_avg_ms_kernel_trace": avg_ns * 1e-6, "kernel_calls_kernel_trace": calls, "kernel_time_source": time_source,
         "prep_kernel_avg_ms": prep_ns * 1e-6,
         "raw_per_launch": {"sq_pass": sq, "FETCH_SIZE_KiB": fetch_kib, "WRITE_SIZE_KiB": write_kib,
                            "prep_kernel_FETCH_SIZE_KiB": prep_fetch / 1024.0},
