@@ -259,8 +259,28 @@ __device__ __forceinline__ double row_suffix(double x) {
 // Row totals are chained with row_bcast15 / row_bcast31 (2 DPP moves + 1 add each; rows without a source read 0 through
 // bound_ctrl, their lanes are not used) and the total is read from the last lane: 17 / 20 VALU instructions for 2 / 4 rows
 // instead of 20 / 27 with one v_readlane pair per row.
+// EXPERIMENT (MPC_MFMA_SUM = 1, off in the product): the same totals on the matrix pipe.  v_mfma_f64_4x4x4 (4 blocks) with a
+// matrix of ones as second operand adds, for every lane position of a row, the four rows; a second one adds the four lanes of
+// every quad (operand layout measured with tools/probes/mfma_f64_layout.hip: A[b][i][k] in lane 16k + 4b + i, B[b][k][j] in
+// lane 16k + 4b + j, D[b][i][j] in lane 16i + 4b + j); two DPP steps add the four quads: lanes 12..15 of every row hold the
+// total of all 64 lanes.  2 MFMA + 6 VALU + 2 v_readlane instead of 17-20 VALU -- but a DIFFERENT summation order, i.e.
+// different rounding of every inner product: results are no longer bitwise those of the DPP build.  Measured on the
+// issue-bound step-loop kernel (round 3, profiles/r03_step_loop_ab.txt): 1.63 instead of 1.60 ms per 10^6 evaluations at
+// N_hor = 20 (+1.5 %), -1 % at N_hor = 40, same status histograms and iteration counts: an f64 MFMA holds the issue port
+// for its four passes, two of them cost what the DPP steps they replace cost.  Not used.
+#ifndef MPC_MFMA_SUM
+#define MPC_MFMA_SUM 0
+#endif
+__device__ __forceinline__ double mfma_allsum(double x) {  // every lane outside the summed set must carry 0
+    const double d1 = __builtin_amdgcn_mfma_f64_4x4x4f64(x, 1.0, 0.0, 0, 0, 0);
+    double d2 = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, d1, 0.0, 0, 0, 0);
+    d2 += dpp0<DPP_ROW_SHR0 + 4>(d2);
+    d2 += dpp0<DPP_ROW_SHR0 + 8>(d2);
+    return d2;
+}
 template <int ROWS>
 __device__ __forceinline__ double wave_sum_u(double x) {
+    if (MPC_MFMA_SUM) return readlane_d(mfma_allsum(x), 15);
     x = row_prefix(x);  // lane 15 of each row = row total
     if (ROWS == 1) return readlane_d(x, 15);
     if (ROWS == 3) {    // rows 1 and 3 only, then rows 2-3: lane 47 = r2 + (r1 + r0)
@@ -275,6 +295,7 @@ __device__ __forceinline__ double wave_sum_u(double x) {
 // two sums over lanes 0..31 for the price of one: b travels in rows 2-3 (v_permlane32_swap), one DPP sequence serves both.
 // Bitwise the same totals as wave_sum_u<2>(a), wave_sum_u<2>(b).
 __device__ __forceinline__ void wave_sum2_u(double a, double b, double& sa, double& sb) {
+    if (MPC_MFMA_SUM) { sa = readlane_d(mfma_allsum(a), 15); sb = readlane_d(mfma_allsum(b), 15); return; }
     const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
     const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
     double x = __hiloint2double((int)hi[0], (int)lo[0]);  // lanes 0..31: a, lanes 32..63: b (lanes 0..31 of it)
