@@ -1,0 +1,46 @@
+"""bench.py on the GPU at a small batch: the JSON line carries the contract's fields, `roofline` is consistent with the
+run's own HIP-event kernel time, and the counter-based fields are measured in the run when rocprofv3 is there."""
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_line_contract_and_in_run_counters():
+    B = 4096
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", str(B), "--steps", "2", "--warmup", "1",
+                        "--cpu-seconds", "2", "--no-convergent", "--no-sweep"], cwd=ROOT, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                   # ONE JSON line
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "solves/s" and d["dtype"] == "f64" and d["n_gpus"] == 1 and d["steps"] == 2 and d["vs_baseline"] is None
+    assert abs(d["value"] - B * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    ro = d["roofline"]
+    assert ro["bound"] == "hbm" and ro["unit"] == "GB/s" and ro["peak"] == 8000.0
+    assert ro["algorithmic_bytes_per_solve"] == 21944                      # 8 np + 16 N + 16 N + 40 at N = 20
+    assert abs(ro["achieved"] - 21944 * B / (ro["kernel_ms"] * 1e-3) / 1e9) < 1e-9 * ro["achieved"] + 1e-12
+    assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-15
+    assert ro["kernel_ms"] <= d["ms_per_step"] * 1.001                     # the kernel fits into the step it is part of
+    assert sum(d["config"]["status_histogram"]) == B
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    if shutil.which("rocprofv3"):
+        assert ro["measured_in_run"]["traffic"] and ro["measured_in_run"]["secondary"], ro.get("traffic_source")
+        assert ro["traffic"] > 21944 * B                                   # the kernel's own cold state on top of the inputs
+        sec = ro["secondary"]
+        assert sec["measured_in_run"] and 0.1 < sec["valu_busy_frac_pmc"] <= 1.0
+        assert 5e6 < sec["valu_instructions_per_solve"] < 3e7
+    else:
+        assert not ro["measured_in_run"]["traffic"]
