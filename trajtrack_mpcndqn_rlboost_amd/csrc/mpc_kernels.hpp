@@ -330,6 +330,15 @@ __device__ __forceinline__ double shift_down1(double x) {  // lane k gets lane k
     return dpp0<DPP_WAVE_SHL1>(x);
 }
 __device__ __forceinline__ double clampd(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
+// The same clamp for WAVE-UNIFORM bounds (kernel arguments), as the two instructions it is.  fmin / fmax make the compiler
+// canonicalise every operand it did not compute itself (v_max_f64 x, x, x -- also for the bounds, on every call): 10
+// instructions for the two clamps of a half step instead of 4.  v_max_f64 / v_min_f64 return the other operand for a quiet NaN
+// exactly as fmax / fmin do; the bits are those of clampd.
+__device__ __forceinline__ double clamp_u(double x, double lo, double hi) {
+    double r;
+    asm("v_max_f64 %0, %1, %2\n\tv_min_f64 %0, %0, %3" : "=&v"(r) : "v"(x), "s"(lo), "s"(hi));
+    return r;
+}
 // A kernel argument / a zero that has to be formed WHERE IT IS USED.  Without this the compiler forms loop invariants such as
 // 0.5 * ts, 2 * fleet weight or a plain 0.0 once, before the solver loop, keeps them in VGPRs for the whole solve -- and, the
 // 128-VGPR build being full, spills them: the reload (a scratch load + s_waitcnt vmcnt(0)) then sits at the head of every
@@ -824,7 +833,9 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     const double Cx = (c0 + 4.0 * cm + c2) * sixth, Sy = (s0 + 4.0 * sm + s2) * sixth;
     const double dCw = -ts * (2.0 * sm + s2) * sixth, dSw = ts * (2.0 * cm + c2) * sixth;
     double pX, pY;
-    P::template prefix2<RV>(c_vl ? ts * v * Cx : 0.0, c_vl ? ts * v * Sy : 0.0, pX, pY);
+    // lanes beyond the horizon carry v = 0 and finite phasors: their increments are (signed) zeros without a select, and an
+    // inclusive PREFIX never reads them into a vector lane
+    P::template prefix2<RV>(ts * v * Cx, ts * v * Sy, pX, pY);
     const double X = HD(H_X0) + pX;
     const double Y = HD(H_Y0) + pY;
 #if MPC_H_ATOMIC
@@ -1096,12 +1107,16 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     v = 0.0; w = 0.0;
     if (c_vl) { v = cx.stash[lane * 6 + 4]; w = cx.stash[lane * 6 + 5]; }
     const double vprev = shift_up1(v, lane, HD(H_VINIT)), wprev = shift_up1(w, lane, HD(H_WINIT));
-    const double a = c_vl ? (v - vprev) * kp.inv_ts : 0.0;
-    const double bacc = c_vl ? (w - wprev) * kp.inv_ts : 0.0;
+    // (lane N holds -v_{N-1} / ts here: every consumer of a, bacc -- box distance, costs, adjoint, the outer step -- selects the
+    // vector lanes itself)
+    const double a = (v - vprev) * kp.inv_ts;
+    const double bacc = (w - wprev) * kp.inv_ts;
     out.F1a = a; out.F1b = bacc;
     const double za = a + ya * icm, zb = bacc + yb * icm;
-    const double ea = za > kp.amax ? za - kp.amax : (za < kp.amin ? za - kp.amin : 0.0);
-    const double eb = zb > kp.aamax ? zb - kp.aamax : (zb < -kp.aamax ? zb + kp.aamax : 0.0);
+    // z - Proj_C(z): z - amax above the box, z - amin below it, z - z = +0 inside -- the bits of the three-way select, in three
+    // instructions per component instead of compares, EXEC masks and branches
+    const double ea = za - clamp_u(za, kp.amin, kp.amax);
+    const double eb = zb - clamp_u(zb, -kp.aamax, kp.aamax);
     double gthN = 0.0;
     if (c_vl) {
         const double dv = v - cx.vref;
@@ -1139,7 +1154,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         double Cx = 0.0, Sy = 0.0, dCw = 0.0, dSw = 0.0;
         if (c_vl) { const double* st = cx.stash + lane * 6; Cx = st[0]; Sy = st[1]; dCw = st[2]; dSw = st[3]; }
         const double Ax = P::template suffix<RV>(Gx, lane), Ay = P::template suffix<RV>(Gy, lane);
-        const double T = c_vl ? ts * v * (-Sy * Ax + Cx * Ay) : 0.0;
+        const double T = ts * v * (-Sy * Ax + Cx * Ay);   // v = 0 and finite factors beyond the horizon: a (signed) zero there
         const double Bx = P::template suffix<RV>(T, lane) - T;
         gv += ts * (Cx * Ax + Sy * Ay);
         gw += ts * v * (dCw * Ax + dSw * Ay) + ts * (Bx + gthN);
@@ -1249,8 +1264,8 @@ __device__ __forceinline__ void panoc_lip_estimate(const Ctx& cx, double d0, dou
 __device__ __forceinline__ double panoc_half_step(const KParams& kp, bool vl, double bv, double bw, double gamma, double g0, double g1,
                                                   double& hv, double& hw) {
     const double sv = bv - gamma * g0, sw = bw - gamma * g1;
-    hv = vl ? clampd(sv, kp.vmin, kp.vmax) : 0.0;
-    hw = vl ? clampd(sw, -kp.wmax, kp.wmax) : 0.0;
+    hv = vl ? clamp_u(sv, kp.vmin, kp.vmax) : 0.0;
+    hw = vl ? clamp_u(sw, -kp.wmax, kp.wmax) : 0.0;
     const double e0 = vl ? sv - hv : 0.0, e1 = vl ? sw - hw : 0.0;
     return __builtin_fma(e0, e0, e1 * e1);
 }
