@@ -448,7 +448,7 @@ def main():
                                        (os.path.relpath(ROOFLINE_JSON, ROOT) + ": separate rocprofv3 --pmc passes on this "
                                         f"workload; NOT re-measured in this run ({pmc_err})") if pmc else None),
                     "note": "state is register/LDS/L2 resident: the kernel is VALU-issue bound (see secondary); traffic = "
-                            "L2<->fabric bytes of the kernel's own cold state (L-BFGS ring, spill slots), DESIGN.md section 2",
+                            "L2<->fabric bytes of the kernel's own cold state (L-BFGS ring, previous iterate), DESIGN.md section 2",
                     "flops": {"bound": "valu_f64_flops", "achieved": tf, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s",
                               "frac": tf / FP64_VECTOR_PEAK_TF, "measured_in_run": True,
                               "source": "static f64-flop table per evaluation (tools/roofline.py: by horizon and active rows) "
