@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MPCGPU_ABI_VERSION 4
+#define MPCGPU_ABI_VERSION 5
 
 /* replaces: the yaml config consumed by MpcModule.build (mpc_generator.py:151-158, config/mpc_default.yaml:7-55)
  * plus the SolverConfiguration of mpc_generator.py:285-293 (opengen defaults quoted there). */
@@ -176,8 +176,18 @@ int32_t mpcgpu_reserve_batch(void* handle, int32_t B);
  *       fused; LDS carve from the configured maxima, nothing read back before the launch).  -1 (default): 4 x the number of
  *       compute units (the measured break-even against the throughput kernel is 1000-1500 problems); 0 switches it off.  Every horizon
  *       whose carve fits the 160 KiB of a compute unit; results are bitwise those of the throughput kernel.
+ *   MPCGPU_OPT_ORDER  (ABI 5) in which order the throughput kernel starts the problems of a batch that is larger than what is
+ *       resident at once (16 problems per compute unit).  A solve takes 10^1 .. 10^4 PANOC steps and whatever is long and
+ *       starts last finishes on a draining GPU.
+ *       1 (default)  longest first, by the psi-evaluation counts the PREVIOUS solve call of the same batch size left on this
+ *                    handle (mpcgpu_last_eval_counts): in a receding-horizon loop problem i of this call is robot i one tick
+ *                    later.  First call, or another batch size: as given.  Three small kernels on the launch stream (counting
+ *                    sort on 1024 bins), no host synchronisation, capturable.
+ *       0            as given (workgroup g solves problem g).
+ *     Every problem is solved independently and writes the outputs of ITS index: results are bitwise the same in any order.
+ *     The reference has no counterpart (one robot per solver.run call).
  */
-enum { MPCGPU_OPT_LINESEARCH_FALLBACK = 1, MPCGPU_OPT_PAIRING = 2, MPCGPU_OPT_TEAM_BATCH = 3 };
+enum { MPCGPU_OPT_LINESEARCH_FALLBACK = 1, MPCGPU_OPT_PAIRING = 2, MPCGPU_OPT_TEAM_BATCH = 3, MPCGPU_OPT_ORDER = 4 };
 int32_t mpcgpu_set_option(void* handle, int32_t option, double value);
 
 /* Register-allocation variant the last solve call was launched with: 3 (148 VGPRs, no spills) or 4 wavefronts per SIMD
@@ -196,6 +206,9 @@ int32_t mpcgpu_last_table_kind(void* handle);
 
 /* Problems per wavefront of the last solve / cost_grad launch: 1 or 2 (MPCGPU_OPT_PAIRING). */
 int32_t mpcgpu_last_problems_per_wavefront(void* handle);
+
+/* 1 when the last solve call started its problems longest first (MPCGPU_OPT_ORDER), 0 when in the order given. */
+int32_t mpcgpu_last_ordered(void* handle);
 
 /* ------------------------------------------------------------------------------------------------------------------------
  * Batched tracker harness on the device.  Replaces, for B robots per call and without a

@@ -193,6 +193,7 @@ struct BatchPtrs {
     double* fpr; double* f2norm; double* y_out; double* ms;
     double* ws; int* counts;
     int32_t* evals;  // [B][2] psi evaluations / of those with gradient (library-owned; read by mpcgpu_last_eval_counts)
+    const int32_t* perm;  // throughput kernel: workgroup g solves problem perm[g] (NULL: problem g) -- MPCGPU_OPT_ORDER, mpc_order.hpp
     double* trace;   // -DMPC_TRACE builds only: [B][trace_cap][TRACE_W] decision trace, one record per PANOC step
     int trace_cap;
 };
@@ -1767,8 +1768,8 @@ __device__ __forceinline__ bool alm_stalled(const Ctx& cx, const KParams& kp, in
 // The rare evaluations are states of a small machine; the PANOC steps run in a loop of their own (MPC_STEP_LOOP).
 template <int NT, bool SC, bool LBG, class P, bool AXIS = false>
 __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& io, int B, double* lds) {
-    const int b = P::problem();
-    if (b >= B) return;
+    if (P::problem() >= B) return;
+    const int b = io.perm ? io.perm[P::problem()] : P::problem();   // every output below is indexed by the PROBLEM, not by the workgroup
     const long long t_start = wall_clock64();
     const int lane = P::lane(), N = NT ? NT : kp.N, mem = kp.mem;
     lds += P::half() * kp.l_total;  // this problem's carve

@@ -6,6 +6,7 @@
 #include "mpc_kernels.hpp"
 #include "mpc_team.hpp"
 #include "mpc_tracker.hpp"
+#include "mpc_order.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -36,7 +37,10 @@ struct Handle {
     bool timing_valid = false;
     std::string err;
     // grow-only device buffers
-    DevBuf ws, counts, evals, trace, p, u0, y0, c0, u, cost, status, inner, outer, fpr, f2, y, ms, xi, psi, f, grad, F1, F2;
+    DevBuf ws, counts, evals, perm, bins, trace, p, u0, y0, c0, u, cost, status, inner, outer, fpr, f2, y, ms, xi, psi, f, grad, F1, F2;
+    int order = 1;      // MPCGPU_OPT_ORDER: 0 problems are dispatched as given, 1 longest first by the previous call's evaluation counts
+    int evals_B = 0;    // batch size of the call whose evaluation counts `evals` holds (0: none)
+    int last_ordered = 0;  // the last throughput launch used a permutation
     int* h_counts = nullptr;  // pinned
     int last_shape[4] = {0, 0, 0, 0};
     int last_B = 0;  // batch size of the last solve (for mpcgpu_last_eval_counts)
@@ -355,7 +359,7 @@ void mpcgpu_destroy(void* handle) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf* bufs[] = {&h->ws, &h->counts, &h->evals, &h->trace, &h->p, &h->u0, &h->y0, &h->c0, &h->u, &h->cost, &h->status, &h->inner,
+    DevBuf* bufs[] = {&h->ws, &h->counts, &h->evals, &h->perm, &h->bins, &h->trace, &h->p, &h->u0, &h->y0, &h->c0, &h->u, &h->cost, &h->status, &h->inner,
                       &h->outer, &h->fpr, &h->f2, &h->y, &h->ms, &h->xi, &h->psi, &h->f, &h->grad, &h->F1, &h->F2};
     for (DevBuf* b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
@@ -415,6 +419,7 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
     }
     auto team_done = [&](const KParams& kt, size_t lds_t, int tw) {
         h->last_B = B; h->last_team = tw; h->last_pairing = 0; h->last_min_waves = 1;
+        h->evals_B = B; h->last_ordered = 0;
         h->last_shape[0] = kt.mKs; h->last_shape[1] = kt.mKf; h->last_shape[2] = kt.mKd; h->last_shape[3] = (int)lds_t;
     };
     if (B <= team_cap && !use_duo(h)) {
@@ -481,6 +486,26 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
     io.evals = (int32_t*)h->evals.ptr;
     h->last_B = B;
     if (!h->capturing) HIP_OK(h, hipEventRecord(h->ev[2], s));
+    // MPCGPU_OPT_ORDER (mpc_order.hpp): longest first by the evaluation counts the previous call of this batch size left in
+    // `evals` -- only when the batch is larger than what is resident at once (else everything starts together anyway).  The three
+    // small kernels are part of the timed solve.
+    io.perm = nullptr;
+    h->last_ordered = 0;
+    if (h->order == 1 && h->evals_B == B && B > 16 * h->num_cus) {
+        if (int r = ensure(h, h->perm, (size_t)B * sizeof(int32_t))) return r;
+        if (int r = ensure(h, h->bins, ORD_BINS * sizeof(int))) return r;
+        // bin width: 1024 bins over the largest possible evaluation count (about 12 per PANOC step)
+        int shift = 0;
+        while (((long long)h->kp.max_inner * h->kp.max_outer * 12 + 64) >> shift > ORD_BINS) ++shift;
+        HIP_OK(h, hipMemsetAsync(h->bins.ptr, 0, ORD_BINS * sizeof(int), s));
+        hipLaunchKernelGGL(order_hist_kernel, dim3((B + 255) / 256), dim3(256), 0, s, (const int32_t*)h->evals.ptr, B, (int*)h->bins.ptr, shift);
+        hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(ORD_BINS), 0, s, (int*)h->bins.ptr);
+        hipLaunchKernelGGL(order_scatter_kernel, dim3((B + 255) / 256), dim3(256), 0, s, (const int32_t*)h->evals.ptr, B, (int*)h->bins.ptr,
+                           (int32_t*)h->perm.ptr, shift);
+        io.perm = (const int32_t*)h->perm.ptr;
+        h->last_ordered = 1;
+    }
+    h->evals_B = B;
     const size_t lds = h->kp.l_total * sizeof(double);
     // more than 64 KiB of dynamic LDS (long horizons with many time-varying obstacles) must be opted into per kernel
 #define LAUNCH_PAIR_WA(NT, SC, MINW, AX)                                                                           \
@@ -838,6 +863,8 @@ int32_t mpcgpu_reserve_batch(void* handle, int32_t B) {
     if (int r = ensure(h, h->ws, (size_t)B * h->kp.ws_stride * sizeof(double))) return r;
     if (int r = ensure(h, h->counts, CNT_WORDS * sizeof(int))) return r;
     if (int r = ensure(h, h->evals, (size_t)B * 2 * sizeof(int32_t))) return r;
+    if (int r = ensure(h, h->perm, (size_t)B * sizeof(int32_t))) return r;
+    if (int r = ensure(h, h->bins, ORD_BINS * sizeof(int))) return r;
     return 0;
 }
 
@@ -857,6 +884,10 @@ int32_t mpcgpu_set_option(void* handle, int32_t option, double value) {
             if (value != -1.0 && value != 0.0 && value != 1.0) return fail(h, -1, "pairing must be -1 (automatic), 0 or 1, got %g", value);
             if (value == 1.0 && !duo_available(h)) return fail(h, -1, "two problems per wavefront are compiled for N_hor = 20 only (N_hor = %d)", h->kp.N);
             h->pairing = (int)value;
+            return 0;
+        case MPCGPU_OPT_ORDER:
+            if (value != 0.0 && value != 1.0) return fail(h, -1, "order must be 0 (as given) or 1 (longest first by the previous call), got %g", value);
+            h->order = (int)value;
             return 0;
         default:
             return fail(h, -1, "unknown option %d", option);
@@ -904,6 +935,7 @@ int32_t mpcgpu_last_problems_per_wavefront(void* handle) {
     Handle* h = (Handle*)handle;
     return h ? 1 + h->last_pairing : -1;
 }
+int32_t mpcgpu_last_ordered(void* handle) { Handle* h = (Handle*)handle; return h ? h->last_ordered : -1; }
 
 #ifdef MPC_PROFILE
 // profiling builds only: read and clear the phase-cycle table (24 counters)

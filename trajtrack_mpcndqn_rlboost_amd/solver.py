@@ -22,11 +22,12 @@ _LIB = os.environ.get("MPCGPU_LIB", os.path.join(_PKG, "libmpcgpu.so"))  # overr
 
 STATUS_NAMES = ("Converged", "NotConvergedIterations", "NotConvergedOutOfTime", "NotFiniteComputation",
                 "ShapeExceeded")
-ABI_VERSION = 4
+ABI_VERSION = 5
 _STREAM_OWN = C.c_void_p(-1)      # MPCGPU_STREAM_OWN: the handle's own non-blocking stream
 OPT_LINESEARCH_FALLBACK = 1       # MPCGPU_OPT_LINESEARCH_FALLBACK
 OPT_PAIRING = 2                   # MPCGPU_OPT_PAIRING
 OPT_TEAM_BATCH = 3                # MPCGPU_OPT_TEAM_BATCH
+OPT_ORDER = 4                     # MPCGPU_OPT_ORDER
 
 
 def _stream_arg(stream):
@@ -57,7 +58,7 @@ class _CConfig(C.Structure):
 EXPORTS = ("mpcgpu_abi_version", "mpcgpu_create", "mpcgpu_destroy", "mpcgpu_last_error", "mpcgpu_num_params",
            "mpcgpu_solve_batch", "mpcgpu_solve_batch_dev", "mpcgpu_cost_grad_batch", "mpcgpu_last_timing",
            "mpcgpu_last_eval_counts", "mpcgpu_last_shape", "mpcgpu_last_waves_per_simd", "mpcgpu_reserve_shape",
-           "mpcgpu_set_option", "mpcgpu_last_problems_per_wavefront", "mpcgpu_last_latency_kernel", "mpcgpu_reserve_batch", "mpcgpu_last_table_kind", "mpcgpu_tracker_window_dev",
+           "mpcgpu_set_option", "mpcgpu_last_problems_per_wavefront", "mpcgpu_last_ordered", "mpcgpu_last_latency_kernel", "mpcgpu_reserve_batch", "mpcgpu_last_table_kind", "mpcgpu_tracker_window_dev",
            "mpcgpu_tracker_step_dev", "mpcgpu_rl_reference_dev", "mpcgpu_hint_switch_dev", "mpcgpu_debug_read_workspace",
            "mpcgpu_workspace_stride", "mpcgpu_workspace_record", "mpcgpu_debug_prep", "mpcgpu_debug_tracker_assemble")
 
@@ -139,6 +140,8 @@ def load_library(path: Optional[str] = None):
     L.mpcgpu_last_latency_kernel.restype = C.c_int32
     L.mpcgpu_last_problems_per_wavefront.argtypes = [vp]
     L.mpcgpu_last_problems_per_wavefront.restype = C.c_int32
+    L.mpcgpu_last_ordered.argtypes = [vp]
+    L.mpcgpu_last_ordered.restype = C.c_int32
     L.mpcgpu_reserve_shape.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.mpcgpu_reserve_shape.restype = C.c_int32
     tp = C.POINTER(CTracker)
@@ -209,11 +212,15 @@ class BatchSolver:
     """One handle of libmpcgpu.so = one generated solver of the reference, for batches of problems."""
 
     def __init__(self, config: Optional[MpcConfig] = None, device: int = 0, library: Optional[str] = None,
-                 pairing: Optional[int] = None, latency_batch: Optional[int] = None):
+                 pairing: Optional[int] = None, latency_batch: Optional[int] = None, order: Optional[str] = None):
         """``pairing``: problems per wavefront of the solve kernel -- None = the library's rule (the faster layout: one),
         1 or 2 to force a layout (MPCGPU_OPT_PAIRING; 2 exists for N_hor = 20; env MPCGPU_PAIRING overrides None).
         ``latency_batch``: largest batch solved by the latency kernel (MPCGPU_OPT_TEAM_BATCH; None = the library's rule,
-        0 = never; env MPCGPU_TEAM_BATCH overrides None)."""
+        0 = never; env MPCGPU_TEAM_BATCH overrides None).
+        ``order``: in which order the throughput kernel starts the problems of a large batch (MPCGPU_OPT_ORDER): None /
+        "longest_first" = by the evaluation counts of this handle's previous call of the same batch size (the library's
+        default: robot i of this tick is robot i of the last one), "as_given" = workgroup g solves problem g.  Results do not
+        depend on it (bitwise)."""
         self.config = config if config is not None else MpcConfig()
         self._L = load_library(library)
         self._h = C.c_void_p()
@@ -244,6 +251,13 @@ class BatchSolver:
             if pairing not in (1, 2):
                 raise MpcGpuError(f"pairing must be 1 or 2 problems per wavefront, got {pairing!r}")
             self._check(self._L.mpcgpu_set_option(self._h, OPT_PAIRING, float(pairing - 1)), "mpcgpu_set_option")
+        if order is not None:
+            self.set_order(order)
+
+    def set_order(self, order: str):
+        if order not in ("as_given", "longest_first"):
+            raise MpcGpuError(f"order must be 'as_given' or 'longest_first', got {order!r}")
+        self._check(self._L.mpcgpu_set_option(self._h, OPT_ORDER, 1.0 if order == "longest_first" else 0.0), "mpcgpu_set_option")
 
     # -- lifetime ---------------------------------------------------------------------------------
     def close(self):
@@ -437,6 +451,7 @@ class BatchSolver:
         return dict(max_static=v[0].value, max_fleet=v[1].value, max_dyn=v[2].value, lds_bytes=v[3].value,
                     waves_per_simd=int(self._L.mpcgpu_last_waves_per_simd(self._h)),
                     problems_per_wavefront=int(self._L.mpcgpu_last_problems_per_wavefront(self._h)),
+                    ordered=bool(self._L.mpcgpu_last_ordered(self._h)),
                     latency_kernel=bool(self._L.mpcgpu_last_latency_kernel(self._h)),
                     shape_const=int(self._L.mpcgpu_last_table_kind(self._h)) != 1,
                     axis_aligned=int(self._L.mpcgpu_last_table_kind(self._h)) == 2)
