@@ -219,8 +219,8 @@ class BatchSolver:
         0 = never; env MPCGPU_TEAM_BATCH overrides None).
         ``order``: in which order the throughput kernel starts the problems of a large batch (MPCGPU_OPT_ORDER): None /
         "longest_first" = by the evaluation counts of this handle's previous call of the same batch size (the library's
-        default: robot i of this tick is robot i of the last one), "as_given" = workgroup g solves problem g.  Results do not
-        depend on it (bitwise)."""
+        default: robot i of this tick is robot i of the last one), "as_given" = workgroup g solves problem g (env MPCGPU_ORDER
+        overrides None).  Results do not depend on it (bitwise)."""
         self.config = config if config is not None else MpcConfig()
         self._L = load_library(library)
         self._h = C.c_void_p()
@@ -251,6 +251,8 @@ class BatchSolver:
             if pairing not in (1, 2):
                 raise MpcGpuError(f"pairing must be 1 or 2 problems per wavefront, got {pairing!r}")
             self._check(self._L.mpcgpu_set_option(self._h, OPT_PAIRING, float(pairing - 1)), "mpcgpu_set_option")
+        if order is None and os.environ.get("MPCGPU_ORDER"):
+            order = os.environ["MPCGPU_ORDER"]
         if order is not None:
             self.set_order(order)
 
