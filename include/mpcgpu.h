@@ -177,8 +177,8 @@ int32_t mpcgpu_reserve_batch(void* handle, int32_t B);
  *       compute units (the measured break-even against the throughput kernel is 1000-1500 problems); 0 switches it off.  Every horizon
  *       whose carve fits the 160 KiB of a compute unit; results are bitwise those of the throughput kernel.
  *   MPCGPU_OPT_ORDER  (ABI 5) in which order the throughput kernel starts the problems of a batch that is larger than what is
- *       resident at once (16 problems per compute unit).  A solve takes 10^1 .. 10^4 PANOC steps and whatever is long and
- *       starts last finishes on a draining GPU.
+ *       resident at once (12 - 16 problems per compute unit, by the registers and the LDS carve of the kernel the batch runs on).
+ *       A solve takes 10^1 .. 10^4 PANOC steps and whatever is long and starts last finishes on a draining GPU.
  *       1 (default)  longest first, by the psi-evaluation counts the PREVIOUS solve call of the same batch size left on this
  *                    handle (mpcgpu_last_eval_counts): in a receding-horizon loop problem i of this call is robot i one tick
  *                    later.  First call, or another batch size: as given.  Three small kernels on the launch stream (counting

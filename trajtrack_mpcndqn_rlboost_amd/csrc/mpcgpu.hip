@@ -486,26 +486,6 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
     io.evals = (int32_t*)h->evals.ptr;
     h->last_B = B;
     if (!h->capturing) HIP_OK(h, hipEventRecord(h->ev[2], s));
-    // MPCGPU_OPT_ORDER (mpc_order.hpp): longest first by the evaluation counts the previous call of this batch size left in
-    // `evals` -- only when the batch is larger than what is resident at once (else everything starts together anyway).  The three
-    // small kernels are part of the timed solve.
-    io.perm = nullptr;
-    h->last_ordered = 0;
-    if (h->order == 1 && h->evals_B == B && B > 16 * h->num_cus) {
-        if (int r = ensure(h, h->perm, (size_t)B * sizeof(int32_t))) return r;
-        if (int r = ensure(h, h->bins, ORD_BINS * sizeof(int))) return r;
-        // bin width: 1024 bins over the largest possible evaluation count (about 12 per PANOC step)
-        int shift = 0;
-        while (((long long)h->kp.max_inner * h->kp.max_outer * 12 + 64) >> shift > ORD_BINS) ++shift;
-        HIP_OK(h, hipMemsetAsync(h->bins.ptr, 0, ORD_BINS * sizeof(int), s));
-        hipLaunchKernelGGL(order_hist_kernel, dim3((B + 255) / 256), dim3(256), 0, s, (const int32_t*)h->evals.ptr, B, (int*)h->bins.ptr, shift);
-        hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(ORD_BINS), 0, s, (int*)h->bins.ptr);
-        hipLaunchKernelGGL(order_scatter_kernel, dim3((B + 255) / 256), dim3(256), 0, s, (const int32_t*)h->evals.ptr, B, (int*)h->bins.ptr,
-                           (int32_t*)h->perm.ptr, shift);
-        io.perm = (const int32_t*)h->perm.ptr;
-        h->last_ordered = 1;
-    }
-    h->evals_B = B;
     const size_t lds = h->kp.l_total * sizeof(double);
     // more than 64 KiB of dynamic LDS (long horizons with many time-varying obstacles) must be opted into per kernel
 #define LAUNCH_PAIR_WA(NT, SC, MINW, AX)                                                                           \
@@ -530,6 +510,31 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
     const bool sc = h->shape_const;
     const bool four = MPC_TRY_FOUR_WAVES && lds <= 10 * 1024 && B > 4 * MPC_MIN_WAVES * h->num_cus;
     h->last_min_waves = four && compiled_horizon(h) == 20 ? 4 : MPC_MIN_WAVES;
+    // MPCGPU_OPT_ORDER (mpc_order.hpp): longest first by the evaluation counts the previous call of this batch size left in
+    // `evals` -- only when the batch is larger than what is resident at once (else everything starts together anyway).  The three
+    // small kernels are part of the timed solve.
+    io.perm = nullptr;
+    h->last_ordered = 0;
+    int resident = 0;
+    {   // wavefronts resident at once: registers (4 per SIMD for the 128-VGPR build, else MPC_MIN_WAVES) and the LDS carve
+        const int by_regs = 4 * (h->last_pairing ? 2 : h->last_min_waves), by_lds = (int)(160 * 1024 / (lds * (h->last_pairing ? 2 : 1)));
+        resident = (by_regs < by_lds ? by_regs : by_lds) * h->num_cus * (h->last_pairing ? 2 : 1);
+    }
+    if (h->order == 1 && h->evals_B == B && B > resident) {
+        if (int r = ensure(h, h->perm, (size_t)B * sizeof(int32_t))) return r;
+        if (int r = ensure(h, h->bins, ORD_BINS * sizeof(int))) return r;
+        // bin width: 1024 bins over the largest possible evaluation count (about 12 per PANOC step)
+        int shift = 0;
+        while (((long long)h->kp.max_inner * h->kp.max_outer * 12 + 64) >> shift > ORD_BINS) ++shift;
+        HIP_OK(h, hipMemsetAsync(h->bins.ptr, 0, ORD_BINS * sizeof(int), s));
+        hipLaunchKernelGGL(order_hist_kernel, dim3((B + 255) / 256), dim3(256), 0, s, (const int32_t*)h->evals.ptr, B, (int*)h->bins.ptr, shift);
+        hipLaunchKernelGGL(order_scan_kernel, dim3(1), dim3(ORD_BINS), 0, s, (int*)h->bins.ptr);
+        hipLaunchKernelGGL(order_scatter_kernel, dim3((B + 255) / 256), dim3(256), 0, s, (const int32_t*)h->evals.ptr, B, (int*)h->bins.ptr,
+                           (int32_t*)h->perm.ptr, shift);
+        io.perm = (const int32_t*)h->perm.ptr;
+        h->last_ordered = 1;
+    }
+    h->evals_B = B;
 #define LAUNCH_DUO(NT, SC)                                                                                          \
     do {                                                                                                             \
         auto kern = solve_kernel_duo<NT, SC, LBFGS_IN_WORKSPACE>;                                                    \
