@@ -1,6 +1,9 @@
 set -u
 O=gpurun_out/r03
 mkdir -p $O
+# the tables below are those of rounds 1-3: problems started in the order given (bench.py sets the order of each of its legs itself);
+# the library's default order gets a table of its own at the end
+export MPCGPU_ORDER=as_given
 python bench.py --steps 5 --warmup 1 > $O/bench_line.json 2> $O/bench.err
 (echo "# tools/phase_prof.py on a -DMPC_PROFILE build of the final round-3 source (throughput kernel; shader-clock cycles per phase; 16 resident wavefronts per CU at N = 20, 12 at N = 40)"; MPCGPU_LIB=$PWD/build_ab/libmpcgpu_prof.so python tools/phase_prof.py 8192 20; MPCGPU_LIB=$PWD/build_ab/libmpcgpu_prof.so python tools/phase_prof.py 4096 40) > $O/phase_table.txt 2>&1
 (echo "# tools/team_sweep.py bench (kernel ms, best of 3)"; python tools/team_sweep.py bench; python tools/team_sweep.py passing) > $O/team_sweep.txt 2>&1
@@ -14,4 +17,5 @@ python tools/train_dqn.py --envs 4096 --timesteps 401408 --graph --save $O/dqn_c
 ls $O/dqn_ckpt >> $O/dqn_config5.txt; rm -rf $O/dqn_ckpt
 bash tools/collect_profiles.sh gpurun_out/raw_r03 > $O/collect.log 2>&1
 bash tools/pmc_stalls.sh 8192 gpurun_out/pmc_stalls_r03 > $O/pmc_stalls_B8192.txt 2>&1
+(echo "# dispatch order (MPCGPU_OPT_ORDER): tools/prof_solve.py B 4 8 N, kernel ms of four consecutive calls of one handle (the first has no hints)"; for a in "8192 4 8 20" "32768 4 8 20" "4096 4 8 40" "16384 4 8 40"; do for o in as_given longest_first; do echo "## $a  MPCGPU_ORDER=$o"; MPCGPU_ORDER=$o python tools/prof_solve.py $a 2>&1 | grep solve_ms | sed "s/inner.*//"; done; done) > $O/order_table.txt 2>&1
 tail -2 $O/bench.err; cat $O/bench_line.json | cut -c1-400
