@@ -21,7 +21,7 @@ def _out(B, n, dev):
                 ms=torch.empty(B, dtype=torch.float64, device=dev))
 
 
-@pytest.mark.parametrize("B", [1536, 4096])
+@pytest.mark.parametrize("B", [1536, 4096, 6144])
 def test_captured_solve_replays_bitwise(B):
     cfg = make_cfg(20, solver_max_inner_iterations=60, solver_max_outer_iterations=3)
     dev = torch.device("cuda", 0)
@@ -45,9 +45,15 @@ def test_captured_solve_replays_bitwise(B):
             bs.solve_device(p, out, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     bs.reserve_batch(B)
+    if B > 4096:
+        # more problems than are resident at once: after one eager call the handle holds evaluation counts, and the captured
+        # launch carries the three ordering kernels (MPCGPU_OPT_ORDER) -- every replay re-sorts by the counts of the one before
+        bs.solve_device(p, out, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g, stream=side):
         bs.solve_device(p, out, stream=torch.cuda.current_stream().cuda_stream)
+    assert bs.last_shape()["ordered"] == (B > 4096)
     for t in out.values():
         t.zero_()
     for _ in range(2):
