@@ -76,6 +76,9 @@ constexpr int MAX_MEM = 16;
 // (the 6 nearest segments of a step at N_hor = 20; the pruned loop then ran in 0.1 % of the evaluations).  1 = the 3 nearest:
 // the pruned loop runs in 2.2 % of the evaluations and one unconditional trip per evaluation is gone: -3.0 % kernel time at
 // N_hor = 20, -1.6 % at N_hor = 40, same bits (the same segments win in the same order; profiles/r03_step_loop_ab.txt).
+#ifndef MPC_STASH_DIET
+#define MPC_STASH_DIET 1
+#endif
 #ifndef MPC_HMASK
 #define MPC_HMASK 1
 #endif
@@ -141,8 +144,15 @@ __host__ __device__ constexpr int part_doubles_c(int N, int mem) {
 }
 // The stash (6 doubles per step) and the positions before it are dead between two evaluations; the Gram form of the L-BFGS step
 // uses them as scratch there: the operands of pass 1 ((r, y) pairs of every chunk slot) followed by the row coefficients.
+// Doubles per step in the stash: the Simpson sums and their derivatives (Cx, Sy, dCw, dSw) and, where registers are short, the
+// point itself (v, w).  The long compiled horizon runs a 168-register kernel that can carry (v, w) through the item phase, and
+// its carve is what decides the residency there: LDS is handed out in 1280-byte granules, 13 440 B are 11 granules = 11
+// wavefronts per CU -- measured: 2.58 resident wavefronts per SIMD on a 21-round batch (tools/occupancy_probe.sh), where 12 per
+// CU would show 2.8 -- and 12 wavefronts need <= 12 800 B.  Without (v, w) (640 B) and with q_dyn in the pad double of the
+// segment records (320 B) the N_hor = 40 carve is 12 480 B.
+__host__ __device__ constexpr int stash_stride_c(int N, int mem) { return (MPC_STASH_DIET && N == 40 && mem == 10) ? 4 : 6; }
 __host__ __device__ constexpr int stash_doubles_c(int N, int mem) {
-    int need = N * 6;
+    int need = N * stash_stride_c(N, mem);
     if (gram_shape(N, mem)) {
         const int R = 2 * mem, G = 32 / mem, CL = (N + G - 1) / G, G2 = 64 / N, CR = (R + G2 - 1) / G2;
         int scratch = even_c(G * CL * 4) + even_c(G2 * CR);      // pass-1 operands (r, y) + row coefficients
@@ -681,7 +691,7 @@ struct Ctx {
     bool vl, il;
     double vref;  // vector lane k: speed reference of step k
     // LDS tables
-    double *seg, *stc, *fxy, *dyn, *dync, *qd, *pos, *H, *W, *part, *stash;
+    double *seg, *stc, *fxy, *dyn, *dync, *pos, *H, *W, *part, *stash;
 };
 constexpr int KC_BASE = 32;
 #define KC(i) (cx.hd[KC_BASE + (i)])
@@ -718,7 +728,7 @@ __device__ __forceinline__ void load_problem(const KParams& kp, const double* __
     cx.terminal = U(H_QN) != 0.0 || U(H_QTHN) != 0.0;
     cx.vref = cx.vl ? ws[kp.ws_vref + lane] : 0.0;
     cx.stc = lds + kp.l_stc; cx.fxy = lds + kp.l_fxy;
-    cx.dyn = lds + kp.l_dyn; cx.dync = lds + kp.l_dync; cx.qd = lds + kp.l_qd;
+    cx.dyn = lds + kp.l_dyn; cx.dync = lds + kp.l_dync;
     if (FIXED) {
         cx.seg = lds + FL.seg; cx.pos = lds + FL.pos; cx.stash = lds + FL.stash; cx.H = lds + FL.part; cx.W = lds + FL.W; cx.part = lds + FL.part;
     } else {
@@ -738,7 +748,8 @@ __device__ __forceinline__ void load_problem(const KParams& kp, const double* __
             const double* d = ws + kp.ws_dyn + i * DYNW;
             cx.dyn[i * DYNP] = d[0]; cx.dyn[i * DYNP + 1] = d[1];
         }
-        for (int i = lane; i < N; i += P::W) cx.qd[i] = ws[kp.ws_qd + i];
+        // q_dyn of step i: the pad double of segment record i (after the copy of the records above: LDS writes keep their order)
+        for (int i = lane; i < N; i += P::W) cx.seg[SEGW * i + 8] = ws[kp.ws_qd + i];
     } else {
         for (int i = lane; i < cx.Kd * N * DYNW; i += P::W) cx.dyn[i] = ws[kp.ws_dyn + i];
     }
@@ -759,7 +770,7 @@ __device__ __forceinline__ DynItem dyn_item(const Ctx& cx, int i, int k, int N, 
     if (SC) {
         const double* e = cx.dyn + (i * N + k) * DYNP;
         const double* s = cx.dync + i * DYNC;
-        ex = px - e[0]; ey = py - e[1]; d.wgt = cx.qd[k] * s[6];  // the same product prep_kernel forms for the general table
+        ex = px - e[0]; ey = py - e[1]; d.wgt = cx.seg[SEGW * k + 8] * s[6];  // q_dyn[k] * alpha: the same product prep_kernel forms for the general table
         d.ca = s[0]; d.sa = s[1]; d.ihx = s[2]; d.ihy = s[3]; d.isx = s[4]; d.isy = s[5];
     } else {
         const double* e = cx.dyn + (i * N + k) * DYNW;
@@ -794,6 +805,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     const int c_ik = lane % N, c_isub = lane / N;
     const int LPS = UNIFORM ? PW / N : (PW - 1 - c_ik) / N + 1;
     constexpr int RV = P::RV, RI = P::RI;
+    const int STW = NT ? stash_stride_c(NT, MemOf<NT>::value) : stash_stride_c(kp.N, kp.mem);   // stash doubles per step
     const double ts = here_s(kp.ts);
     const double fleetw = here_s(kp.fleetw);
     const double inf = __builtin_huge_val();
@@ -846,8 +858,9 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         cx.pos[2 * lane] = X; cx.pos[2 * lane + 1] = Y;
         // rollout quantities needed again only after the item phase (per-step terms, adjoint): parked in LDS so
         // that they do not occupy registers across the item loops
-        double* st = cx.stash + lane * 6;
-        st[0] = Cx; st[1] = Sy; st[2] = dCw; st[3] = dSw; st[4] = v; st[5] = w;
+        double* st = cx.stash + lane * STW;
+        st[0] = Cx; st[1] = Sy; st[2] = dCw; st[3] = dSw;
+        if (STW == 6) { st[4] = v; st[5] = w; }
     }
     }
     wave_sync();
@@ -1105,8 +1118,10 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
 
     PROF_MARK(7);  // combine
     // ---- per-step terms on the vector lanes (mpc_generator.py:208-209,246,254-267)
-    v = 0.0; w = 0.0;
-    if (c_vl) { v = cx.stash[lane * 6 + 4]; w = cx.stash[lane * 6 + 5]; }
+    if (STW == 6) {   // (else (v, w) are still in their registers: zero beyond the horizon since the top of the evaluation)
+        v = 0.0; w = 0.0;
+        if (c_vl) { v = cx.stash[lane * 6 + 4]; w = cx.stash[lane * 6 + 5]; }
+    }
     const double vprev = shift_up1(v, lane, HD(H_VINIT)), wprev = shift_up1(w, lane, HD(H_WINIT));
     // (lane N holds -v_{N-1} / ts here: every consumer of a, bacc -- box distance, costs, adjoint, the outer step -- selects the
     // vector lanes itself)
@@ -1153,7 +1168,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         double gw = 2.0 * HD(H_RW) * w + db - db_n;
         // adjoint of the rollout: suffix sums instead of a serial backward sweep
         double Cx = 0.0, Sy = 0.0, dCw = 0.0, dSw = 0.0;
-        if (c_vl) { const double* st = cx.stash + lane * 6; Cx = st[0]; Sy = st[1]; dCw = st[2]; dSw = st[3]; }
+        if (c_vl) { const double* st = cx.stash + lane * STW; Cx = st[0]; Sy = st[1]; dCw = st[2]; dSw = st[3]; }
         const double Ax = P::template suffix<RV>(Gx, lane), Ay = P::template suffix<RV>(Gy, lane);
         const double T = ts * v * (-Sy * Ax + Cx * Ay);   // v = 0 and finite factors beyond the horizon: a (signed) zero there
         const double Bx = P::template suffix<RV>(T, lane) - T;

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(WAVE * TW) void solve_kernel_team(KParams kp, Batch
         cx.terminal = U(H_QN) != 0.0 || U(H_QTHN) != 0.0;
         cx.vref = cx.vl ? ws[kp.ws_vref + lane] : 0.0;
         cx.seg = lds + kp.l_seg; cx.stc = lds + kp.l_stc; cx.fxy = lds + kp.l_fxy;
-        cx.dyn = lds + kp.l_dyn; cx.dync = cx.dyn; cx.qd = cx.dyn;
+        cx.dyn = lds + kp.l_dyn; cx.dync = cx.dyn;
         cx.pos = mine + kp.l_pos; cx.H = mine + kp.l_H; cx.W = mine + kp.l_W; cx.part = mine + kp.l_part; cx.stash = mine + kp.l_stash;
         const int T = WAVE * TW;
         for (int i = threadIdx.x; i < N * SEGW; i += T) cx.seg[i] = ws[kp.ws_seg + i];

@@ -204,7 +204,7 @@ void fill_lds_layout(KParams& k, int mKs, int mKf, int mKd, bool shape_const, bo
     if (shape_const) {
         k.l_dyn = o; o += even(mKd * N * DYNP);
         k.l_dync = o; o += even(mKd * DYNC);
-        k.l_qd = o; o += even(N);
+        k.l_qd = 0;   // q_dyn lives in the pad double of the segment records (mpc_kernels.hpp load_problem)
     } else {
         k.l_dyn = o; o += even(mKd * N * DYNW);
         k.l_dync = k.l_dyn; k.l_qd = k.l_dyn;
