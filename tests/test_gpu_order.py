@@ -25,7 +25,7 @@ def test_results_do_not_depend_on_the_dispatch_order(N, B):
     assert not plain.last_shape()["ordered"]
     t_plain = plain.last_timing()["solve_ms"]
     e0 = plain.last_eval_counts(B)
-    bs = BatchSolver(cfg)                      # the library's default: longest first once there is a previous call
+    bs = BatchSolver(cfg, order="longest_first")   # (also the library's default) longest first once there is a previous call
     r1 = bs.solve(sc["p"])
     assert not bs.last_shape()["ordered"]       # first call: nothing to go by
     r2 = bs.solve(sc["p"])
@@ -53,7 +53,7 @@ def test_small_batches_and_the_switch():
     cfg = MpcConfig()
     B = 2048                                    # fewer than 16 problems per CU: everything starts at once, no permutation
     sc = scenes.make_batch(cfg, B, n_dyn=4, seed=5, dyn_clearance=0.1, box_clearance=0.3)
-    bs = BatchSolver(cfg, latency_batch=0)
+    bs = BatchSolver(cfg, latency_batch=0, order="longest_first")
     bs.solve(sc["p"]); bs.solve(sc["p"])
     assert not bs.last_shape()["ordered"]
     with pytest.raises(Exception):
