@@ -101,11 +101,11 @@ def first_divergence(tg, to):
     (20, "last_trial", 40, 6, 12, 0, None, "latency", True)])
 def test_decision_trace_matches_oracle(N, fallback, max_inner, max_outer, min_fd, min_sd, early_tol, kernel, cold):
     """Benchmark-family scenes (hard constraints active: F2 > 0, penalty growing); from a non-zero initial guess, or cold.  The
-    oracle evaluates the L-BFGS operator in the form the kernel uses for the horizon (Gram at N_hor = 20, two-loop at 40)."""
+    oracle evaluates the L-BFGS operator in the form the kernel uses for the horizon (the Gram form at both compiled horizons)."""
     CAP, B = 240, 48
     cfg = make_cfg(N, solver_linesearch_fallback=fallback, solver_max_inner_iterations=max_inner,
                    solver_max_outer_iterations=max_outer)
-    od = cfg.solver_dict(); od["lbfgs_gram"] = 1 if N == 20 else 0
+    od = cfg.solver_dict(); od["lbfgs_gram"] = 1 if N in (20, 40) else 0
     ocfg = oracle.OracleConfig.from_dict(od)
     assert ocfg.ls_fallback == (1 if fallback == "half_step" else 0)
     bs = BatchSolver(cfg, library=variant_path("trace"), latency_batch=0 if kernel == "throughput" else None)

@@ -76,10 +76,10 @@ def flops_per_solve_kernel_launch(N, Ks, Kf, Kd, n_psi, n_grad) -> float:
     f_psi = flops_per_eval(N, Ks, Kf, Kd, False)
     f_grad = flops_per_eval(N, Ks, Kf, Kd, True)
     n_iter = n_psi - n_grad                       # one gradient-free evaluation (Lipschitz check) per PANOC iteration
-    # L-BFGS step per PANOC iteration.  Gram form (N_hor = 20, round 3): pass 1 = 2 mem rows x 2N x 2 products, the two scalar
+    # L-BFGS step per PANOC iteration.  Gram form (N_hor = 20 and 40, round 3): pass 1 = 2 mem rows x 2N x 2 products, the two scalar
     # recurrences 2 x mem x (2 mem rows), pass 2 = 2 mem rows x 2N; two-loop form: 4 x mem dot products / updates of length 2N.
     mem = 10
-    lbfgs = (2 * (2 * mem) * (2 * N) * 2 + 2 * (2 * mem) * (2 * N) + 2 * 2 * mem * 2 * mem) if N == 20 else 2 * (4 * mem * 2 * N)
+    lbfgs = (2 * (2 * mem) * (2 * N) * 2 + 2 * (2 * mem) * (2 * N) + 2 * 2 * mem * 2 * mem) if N in (20, 40) else 2 * (4 * mem * 2 * N)
     algebra = n_iter * (lbfgs + 20 * 2 * N) + n_grad * (8 * 2 * N)
     return float(((n_psi - n_grad) * f_psi + n_grad * f_grad + algebra).sum())
 

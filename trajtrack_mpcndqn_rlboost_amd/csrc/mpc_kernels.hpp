@@ -133,7 +133,10 @@ struct KParams {
 // ------------------------------------------------------------------------------------------------
 struct FixedLds { int hd, seg, pos, stash, part, W, rho, gg, S, Y, old, end; };
 __host__ __device__ constexpr int even_c(int x) { return (x + 1) & ~1; }
-__host__ __device__ constexpr bool gram_shape(int N, int mem) { return MPC_LBFGS_GRAM && N == 20 && mem == 10; }
+#ifndef MPC_GRAM40
+#define MPC_GRAM40 1   // the Gram form at N_hor = 40 as well (with the stash-free 168-register kernel: see stash_stride_c)
+#endif
+__host__ __device__ constexpr bool gram_shape(int N, int mem) { return MPC_LBFGS_GRAM && (N == 20 || (MPC_GRAM40 && N == 40)) && mem == 10; }
 // Item-lane partials (eval_point): every item lane beyond the vector lanes parks PARTW = 5 doubles.  With a compiled horizon that
 // nearly divides the wavefront (N_hor = 20: 60 item lanes) the split is uniform and the last lanes idle -- the rule of eval_point.
 __host__ __device__ constexpr int part_doubles_c(int N, int mem) {
@@ -150,7 +153,11 @@ __host__ __device__ constexpr int part_doubles_c(int N, int mem) {
 // wavefronts per CU -- measured: 2.58 resident wavefronts per SIMD on a 21-round batch (tools/occupancy_probe.sh), where 12 per
 // CU would show 2.8 -- and 12 wavefronts need <= 12 800 B.  Without (v, w) (640 B) and with q_dyn in the pad double of the
 // segment records (320 B) the N_hor = 40 carve is 12 480 B.
-__host__ __device__ constexpr int stash_stride_c(int N, int mem) { return (MPC_STASH_DIET && N == 40 && mem == 10) ? 4 : 6; }
+// With the Gram form at N_hor = 40 (its matrices: 1240 B) the four Simpson values stay in registers as well (stride 0): 11 200 B
+// + 1160 B = 12 360 B, still 12 per CU.
+__host__ __device__ constexpr int stash_stride_c(int N, int mem) {
+    return (MPC_STASH_DIET && N == 40 && mem == 10) ? (gram_shape(N, mem) ? 0 : 4) : 6;
+}
 __host__ __device__ constexpr int stash_doubles_c(int N, int mem) {
     int need = N * stash_stride_c(N, mem);
     if (gram_shape(N, mem)) {
@@ -158,7 +165,11 @@ __host__ __device__ constexpr int stash_doubles_c(int N, int mem) {
         int scratch = even_c(G * CL * 4) + even_c(G2 * CR);      // pass-1 operands (r, y) + row coefficients
         const int p2 = (G2 - 1) * N * 2;                          // partials of pass 2 (they reuse the operand area)
         if (p2 > scratch) scratch = p2;
-        if (scratch - N * 2 > need) need = scratch - N * 2;
+        // the scratch starts at the positions and runs through the stash into the region of the item partials / hinge sums
+        // that follows it: all three are dead between two evaluations
+        const int after = part_doubles_c(N, mem) > 2 * 32 ? part_doubles_c(N, mem) : 2 * 32;
+        const int room = N * 2 + (stash_stride_c(N, mem) == 0 ? after : 0);
+        if (scratch - room > need) need = scratch - room;
     }
     return need;
 }
@@ -842,9 +853,11 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     }
     PROF_MARK(0);  // headings
     const double sixth = KC(K_SIXTH);
+    double kCx = 0.0, kSy = 0.0, kdCw = 0.0, kdSw = 0.0;   // stash stride 0: the Simpson values stay here
     {
     const double Cx = (c0 + 4.0 * cm + c2) * sixth, Sy = (s0 + 4.0 * sm + s2) * sixth;
     const double dCw = -ts * (2.0 * sm + s2) * sixth, dSw = ts * (2.0 * cm + c2) * sixth;
+    if (STW == 0) { kCx = Cx; kSy = Sy; kdCw = dCw; kdSw = dSw; }
     double pX, pY;
     // lanes beyond the horizon carry v = 0 and finite phasors: their increments are (signed) zeros without a select, and an
     // inclusive PREFIX never reads them into a vector lane
@@ -858,9 +871,11 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         cx.pos[2 * lane] = X; cx.pos[2 * lane + 1] = Y;
         // rollout quantities needed again only after the item phase (per-step terms, adjoint): parked in LDS so
         // that they do not occupy registers across the item loops
-        double* st = cx.stash + lane * STW;
-        st[0] = Cx; st[1] = Sy; st[2] = dCw; st[3] = dSw;
-        if (STW == 6) { st[4] = v; st[5] = w; }
+        if (STW >= 4) {
+            double* st = cx.stash + lane * STW;
+            st[0] = Cx; st[1] = Sy; st[2] = dCw; st[3] = dSw;
+            if (STW == 6) { st[4] = v; st[5] = w; }
+        }
     }
     }
     wave_sync();
@@ -1167,8 +1182,9 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         double gv = 2.0 * HD(H_QVEL) * (v - cx.vref) + 2.0 * HD(H_RV) * v + da - da_n;
         double gw = 2.0 * HD(H_RW) * w + db - db_n;
         // adjoint of the rollout: suffix sums instead of a serial backward sweep
-        double Cx = 0.0, Sy = 0.0, dCw = 0.0, dSw = 0.0;
-        if (c_vl) { const double* st = cx.stash + lane * STW; Cx = st[0]; Sy = st[1]; dCw = st[2]; dSw = st[3]; }
+        // (kept in registers they are finite beyond the horizon, where v = 0 and the adjoint sums Ax, Ay are 0: same bits)
+        double Cx = kCx, Sy = kSy, dCw = kdCw, dSw = kdSw;
+        if (STW >= 4 && c_vl) { const double* st = cx.stash + lane * STW; Cx = st[0]; Sy = st[1]; dCw = st[2]; dSw = st[3]; }
         const double Ax = P::template suffix<RV>(Gx, lane), Ay = P::template suffix<RV>(Gy, lane);
         const double T = ts * v * (-Sy * Ax + Cx * Ay);   // v = 0 and finite factors beyond the horizon: a (signed) zero there
         const double Bx = P::template suffix<RV>(T, lane) - T;
@@ -1743,12 +1759,14 @@ struct PanocLbfgsGram {
     }
 };
 
-// The Gram form pays when a horizon leaves most of the wavefront idle in the two-loop reductions AND pass 2 can split the rows
-// over lane groups (64 / N >= 2): measured -7 % at N_hor = 20, but +7 % at N_hor = 40 (one lane group does all 2 mem rows in
-// pass 2, the reductions already use 40 of 64 lanes) -- profiles/r03_lbfgs_gram_ab.txt.  So: Gram for compiled horizons up to
-// 32, two-loop otherwise (N_hor = 40 and the runtime-horizon kernel, as in rounds 1-2).
+// Where the Gram form is used.  N_hor = 20: -7 % against the two-loop recursion (profiles/r03_lbfgs_gram_ab.txt).  N_hor = 40: the
+// first measurement said +7 % -- the 1.2 KB of Gram matrices had cost a resident wavefront per CU (LDS comes in 1280-byte granules);
+// at EQUAL residency it is 4 % faster there too, and with the stash-free carve (stash_stride_c: 12 368 B = 12 per CU) the kernel
+// went from 954 to 913 ms at B = 16 384.  One lane group does all 2 mem rows in pass 2 there (64 / N = 1).  The runtime-horizon
+// kernel keeps the two-loop form.
 template <int NT> struct GramFor { static constexpr bool value = MPC_LBFGS_GRAM && NT != 0 && WAVE / (NT ? NT : 1) >= 2; };
 template <bool DUO, int NT> struct LbfgsOf { using type = PanocLbfgs; };
+template <> struct LbfgsOf<false, 40> { using type = std::conditional<gram_shape(40, 10), PanocLbfgsGram, PanocLbfgs>::type; };
 template <> struct LbfgsOf<false, 20> { using type = std::conditional<GramFor<20>::value, PanocLbfgsGram, PanocLbfgs>::type; };
 
 // ALM / PM outer step: y+ <- y + c (F1(u) - Proj_C(F1(u) + y/c)); ||y+ - y||
