@@ -87,7 +87,7 @@ def decision_trace(N, fallback, max_inner, max_outer, CAP=240, B=48, cold=False,
     from trajtrack_mpcndqn_rlboost_amd.solver import variant_path
     D, SC = [0, 1, 7, 8, 9], [2, 3, 4, 5, 6, 10, 11]
     cfg = MpcConfig(N_hor=N, solver_linesearch_fallback=fallback, solver_max_inner_iterations=max_inner, solver_max_outer_iterations=max_outer)
-    d = cfg.solver_dict(); d["lbfgs_gram"] = 1 if N == 20 else 0
+    d = cfg.solver_dict(); d["lbfgs_gram"] = 1 if N in (20, 40) else 0
     ocfg = oracle.OracleConfig.from_dict(d)
     bs = BatchSolver(cfg, library=variant_path("trace"), latency_batch=0 if kernel == "throughput" else None); bs.set_trace(CAP)
     sc = scenes.make_batch(cfg, B, n_dyn=8, seed=77 + N)
