@@ -481,7 +481,8 @@ def main():
                                         f"bench.py on the same parameter vectors ({pmc_here['pmc_passes_wall_s']:.0f} s for the three "
                                         "counter passes)") if in_run else
                                        (os.path.relpath(ROOFLINE_JSON, ROOT) + ": separate rocprofv3 --pmc passes on this "
-                                        f"workload; NOT re-measured in this run ({pmc_err})") if pmc else None),
+                                        f"workload; NOT re-measured in this run ({pmc_err})") if pmc else
+                                       f"not measured: {pmc_err}; no committed counter passes for this workload"),
                     "note": "state is register/LDS/L2 resident: the kernel is VALU-issue bound (see secondary); traffic = "
                             "L2<->fabric bytes of the kernel's own cold state (L-BFGS ring, previous iterate), DESIGN.md section 2",
                     "flops": {"bound": "valu_f64_flops", "achieved": tf, "peak": FP64_VECTOR_PEAK_TF, "unit": "TFLOP/s",
