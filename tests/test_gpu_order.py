@@ -45,7 +45,7 @@ def test_results_do_not_depend_on_the_dispatch_order(N, B):
     assert bs.last_shape()["ordered"]
     assert np.array_equal(r4.solution, r0.solution[perm]) and np.array_equal(r4.status, r0.status[perm])
     print(f"\nN_hor {N}, B {B}: as given {t_plain:.1f} ms, longest first {t_ord:.1f} ms")
-    assert t_ord < 1.02 * t_plain               # good hints never cost (measured: -10 .. -25 % on this family)
+    assert t_ord < 1.05 * t_plain               # good hints do not cost (measured: -14 % and -30 % on these two batches)
     plain.close(); bs.close()
 
 
