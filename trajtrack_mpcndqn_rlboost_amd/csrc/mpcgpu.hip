@@ -517,7 +517,8 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
     h->last_ordered = 0;
     int resident = 0;
     {   // wavefronts resident at once: registers (4 per SIMD for the 128-VGPR build, else MPC_MIN_WAVES) and the LDS carve
-        const int by_regs = 4 * (h->last_pairing ? 2 : h->last_min_waves), by_lds = (int)(160 * 1024 / (lds * (h->last_pairing ? 2 : 1)));
+        const size_t granule = 1280, wg_lds = (lds * (h->last_pairing ? 2 : 1) + granule - 1) / granule * granule;   // LDS is handed out in 1280-byte granules
+        const int by_regs = 4 * (h->last_pairing ? 2 : h->last_min_waves), by_lds = (int)(160 * 1024 / wg_lds);
         resident = (by_regs < by_lds ? by_regs : by_lds) * h->num_cus * (h->last_pairing ? 2 : 1);
     }
     if (h->order == 1 && h->evals_B == B && B > resident) {
