@@ -71,7 +71,8 @@ def hard_constraints(cfg, p, u, with_parts=False):
     gv = np.concatenate(g) if g else np.zeros(0)
     if with_parts:
         F2 = np.array([S + np.maximum(r, 0.0).sum() for r in ih_rows])
-        return gv, F2
+        n_dyn_entries = N * sum(1 for i in range(cfg.Ndynobs) if np.any(dyn[i]))
+        return gv, F2, n_dyn_entries
     return gv
 
 
@@ -95,7 +96,7 @@ def check_solution(cfg, ocfg, p, u, y, run_scipy=True, active_tol=1e-3):
     chi = np.r_[np.full(N, cfg.lin_acc_max), np.full(N, cfg.ang_acc_max)]
     o = oracle.cost_grad(ocfg, u, p)
     f0, gf, F1, F2 = o["f"], o["grad"], o["F1"], o["F2"]
-    g0, F2_restated = hard_constraints(cfg, p, u, with_parts=True)
+    g0, F2_restated, n_dyn_entries = hard_constraints(cfg, p, u, with_parts=True)
     # the inequality form describes the oracle's F2 (pinned by the reference-generated fixtures)
     assert np.allclose(F2_restated, F2, rtol=1e-9, atol=1e-12), (F2_restated, F2)
     out = dict(f=f0)
@@ -107,6 +108,11 @@ def check_solution(cfg, ocfg, p, u, y, run_scipy=True, active_tol=1e-3):
     gL = gf + A.T @ y
     act = np.where(g0 > -active_tol)[0]
     out["n_active_hard"] = int(act.size)
+    # dynamic ellipses first, then static polygons (order of `hard_constraints`).  The static constraint the solver sees is
+    # the PRODUCT of squared hinges: F2 <= delta admits a penetration of centimetres near a polygon edge (flat constraint),
+    # which the inequality form used here does not -- `g_static_max` lets the callers tell those answers apart.
+    out["n_active_dyn"] = int((act < n_dyn_entries).sum())
+    out["g_static_max"] = float(g0[n_dyn_entries:].max()) if g0.size > n_dyn_entries else -np.inf
     if act.size:
         J = np.empty((act.size, n))
         h = 1e-6
@@ -117,6 +123,7 @@ def check_solution(cfg, ocfg, p, u, y, run_scipy=True, active_tol=1e-3):
         mu, _ = nnls(J[:, free].T, -gL[free]) if free.any() else (np.zeros(act.size), 0.0)
         gL = gL + J.T @ mu
         out["mu_max"] = float(mu.max())
+        out["mu_dyn_max"] = float(mu[act < n_dyn_entries].max()) if (act < n_dyn_entries).any() else 0.0
     out["pg_residual"] = float(np.abs(u - np.clip(u - gL, lo, hi)).max())
     if not run_scipy:
         return out

@@ -75,6 +75,46 @@ def test_baseline_configurations_converged_solves_match_oracle(N, n_dyn, B, min_
     bs.close()
 
 
+# Round 4.  (a) The "avoidance" family (scenes.FAMILIES): 1-3 discs COVER the reference path, the box covers it in 30 % of the
+# problems, the detour leads to the free side of the corridor -- the problems this MPC exists for.  (b) Config 3 with a robust
+# set of converged problems: at N_hor = 40 WHICH problems meet the AKKT test within 500 inner iterations is decided by rounding
+# (the oracle against itself with every parameter moved by one ulp: 52 and 52 of 256 converge on the "on_track" family, 8 in
+# common), so the tolerance is asserted with the inner cap raised to 5000 (`solver_max_inner_iterations`, the optional key of
+# the yaml surface; mean 2400 iterations are used) where 93 % converge on both sides; the default caps are covered by the test
+# above.  Next to every GPU-vs-oracle figure the test prints the oracle-vs-1-ulp-perturbed-oracle figure on the same sample.
+@pytest.mark.parametrize("N,family,B,cfgkw,min_both,min_agree", [
+    (20, "avoidance", 8192, {}, 77, 0.9),
+    (40, "on_track", 4096, dict(solver_max_inner_iterations=5000), 48, 0.9)])
+def test_avoidance_and_long_iteration_families_match_oracle(N, family, B, cfgkw, min_both, min_agree):
+    cfg = make_cfg(N, **cfgkw)
+    ocfg = oracle_cfg(cfg)
+    bs = BatchSolver(cfg)
+    sc = scenes.make_family(cfg, B, family, seed=4321)
+    res = bs.solve(sc["p"])
+    assert bs.last_shape()["max_dyn"] == 8 and bs.last_shape()["max_static"] == 5
+    S = 256
+    pick = np.random.default_rng(N).choice(B, S, replace=False)
+    uo, _, ro, _ = oracle.solve_batch(ocfg, sc["p"][pick])
+    up, _, rp, _ = oracle.solve_batch(ocfg, np.nextafter(sc["p"][pick], np.inf))      # the oracle's own sensitivity
+    both = (res.status[pick] == 0) & (ro["status"] == 0)
+    both_p = (rp["status"] == 0) & (ro["status"] == 0)
+    du = np.max(np.abs(res.solution[pick] - uo), axis=1)
+    dp = np.max(np.abs(up - uo), axis=1)
+    agree = np.mean((res.status[pick] == 0) == (ro["status"] == 0))
+    agree_p = np.mean((rp["status"] == 0) == (ro["status"] == 0))
+    print(f"\n[{family} N={N} B={B} {cfgkw}] status histogram (whole batch) {np.bincount(res.status, minlength=3).tolist()}; sample of {S}: "
+          f"converged GPU {np.sum(res.status[pick] == 0)}, oracle {np.sum(ro['status'] == 0)}, on both {both.sum()}, |du|inf max "
+          f"{du[both].max():.2e} median {np.median(du[both]):.2e}, agreement on which converge {agree:.3f}  ||  oracle vs oracle with "
+          f"every parameter moved by one ulp: on both {both_p.sum()}, |du|inf max {dp[both_p].max():.2e} median "
+          f"{np.median(dp[both_p]):.2e}, agreement {agree_p:.3f}")
+    assert both.sum() >= min_both, (both.sum(), S)
+    assert du[both].max() <= U_TOL
+    assert agree >= min_agree
+    assert np.array_equal(res.num_outer_iterations[pick][both], ro["outer_iters"][both])
+    assert np.mean(res.status == 0) >= 0.30                       # >= 30 % of the cold-start solves converge
+    bs.close()
+
+
 def first_divergence(tg, to):
     """Index of the first PANOC step whose discrete decisions differ (min(len) when none does)."""
     n = min(len(tg), len(to))
@@ -220,6 +260,39 @@ def test_one_call_site_build_is_bitwise_equal_to_the_product_build(N, B, fam):
     assert np.array_equal(ra.status, rb.status)
     assert np.array_equal(np.asarray(ea), np.asarray(eb))
     assert len(set(ra.status.tolist())) >= (2 if fam == "passing" else 1)
+    a.close(); b.close()
+
+
+# (N_hor, family, config overrides, batch, floor of converged-on-both, |du| bound, floor of equal statuses, floor of equal inner counts)
+# Measured with the oracle's two modes on the same scenes (CPU): N_hor = 20 "on_track": 505 of 512 converge in both forms, |du|inf
+# 2.7e-7, 87 % with the same iteration count; N_hor = 40 (inner cap 5000, see the test above): 463 of 512, |du|inf 1.8e-6, and the
+# iteration COUNTS differ by a median of 58 % -- with 80 unknowns the slow tail of the inner iteration is chaotic under rounding,
+# the limit point is not -- so no count assertion there.
+@pytest.mark.parametrize("N,family,cfgkw,B,min_both,du_tol,min_status,min_inner", [
+    (20, "on_track", {}, 2048, 1900, 1e-6, 0.95, 0.8),
+    (20, "passing", {}, 2048, 600, 2e-6, 0.95, 0.6),
+    (40, "on_track", dict(solver_max_inner_iterations=5000), 2048, 1600, 1e-5, 0.9, None)])
+def test_gram_form_of_the_lbfgs_operator_against_the_two_loop_build_on_the_gpu(N, family, cfgkw, B, min_both, du_tol, min_status, min_inner):
+    """The product evaluates d = H (gamma fpr) in Gram form (PanocLbfgsGram); `make variants` keeps the two-loop recursion of the
+    `lbfgs` crate (oracle/mpc_oracle.c:406-449) as libmpcgpu_twoloop.so.  Same operator, another summation order: the two builds
+    solve the same batch on the GPU and must agree on the statuses, on the converged control sequences and -- rounding differences
+    take a while to flip a decision -- on most iteration counts."""
+    cfg = make_cfg(N, **cfgkw)
+    sc = scenes.make_family(cfg, B, family, seed=99 + N)
+    a = BatchSolver(cfg, latency_batch=0)
+    b = BatchSolver(cfg, library=variant_path("twoloop"), latency_batch=0)
+    ra, rb = a.solve(sc["p"]), b.solve(sc["p"])
+    both = (ra.status == 0) & (rb.status == 0)
+    du = np.max(np.abs(ra.solution - rb.solution), axis=1)
+    same_status = np.mean(ra.status == rb.status)
+    same_inner = np.mean(ra.num_inner_iterations[both] == rb.num_inner_iterations[both])
+    print(f"\n[gram vs two-loop, GPU, N={N} {family} {cfgkw} B={B}] converged {np.sum(ra.status == 0)} / {np.sum(rb.status == 0)}, on both "
+          f"{both.sum()}: |du|inf max {du[both].max():.2e}; same status {same_status:.4f}; same inner-iteration count among those {same_inner:.4f}")
+    assert both.sum() >= min_both
+    assert du[both].max() <= du_tol
+    assert same_status >= min_status
+    if min_inner is not None:
+        assert same_inner >= min_inner
     a.close(); b.close()
 
 

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import load_golden, make_cfg, oracle_cfg  # noqa: E402
 from support import kkt  # noqa: E402
-from test_solution_kkt import assert_kkt  # noqa: E402
+from test_solution_kkt import active_hard_candidates, assert_kkt  # noqa: E402
 from trajtrack_mpcndqn_rlboost_amd import BatchSolver, scenes  # noqa: E402
 
 pytestmark = pytest.mark.gpu
@@ -44,6 +44,36 @@ def test_converged_gpu_solutions_are_local_minima_of_the_reference_problem(name)
         for k in worst:
             worst[k] = max(worst[k], r[k])
     print(f"\n[kkt] {name}: {take} of {len(conv)} converged solves checked; worst {worst}")
+
+
+@pytest.mark.parametrize("N,B,kw", [(20, 8192, {}), (40, 8192, dict(on_track=True))])
+def test_gpu_solutions_on_an_active_hard_ellipse_are_kkt_points_with_positive_multipliers(N, B, kw):
+    """Obstacle avoidance is what this MPC is for: the "grazing" family (scenes.FAMILIES; one disc of radius 1.6 m covers the
+    reference path, src/main.py:31,77-85, soft weights 10 through set_obstacle_weights) makes converged plans rest ON the hard
+    ellipse (mpc_generator.py:229-241,272).  At least 16 such GPU answers per horizon are examined by scipy: the dynamic
+    constraint is active, its non-negative-least-squares multiplier is > 0, and the point is a KKT point of the reference's
+    constrained problem (feasible to delta, residual <= 1e-3, SLSQP neither moves it nor lowers f)."""
+    cfg = make_cfg(N)
+    ocfg = oracle_cfg(cfg)
+    sc = scenes.make_family(cfg, B, "grazing", seed=21, **kw)
+    bs = BatchSolver(cfg)
+    res = bs.solve(sc["p"])
+    bs.close()
+    rows = active_hard_candidates(cfg, ocfg, sc["p"], res.solution, res.lagrange_multipliers, res.status, res.f2_norm, want=16)
+    n_inside = int(((res.status == 0) & (res.f2_norm > 0.0)).sum())
+    assert len(rows) >= 16, (len(rows), n_inside, np.bincount(res.status, minlength=3).tolist())
+    worst = dict(pg_residual=0.0, scipy_move=0.0, scipy_f_gain_rel=-1.0)
+    mus, nact = [], []
+    for i in rows:
+        r = kkt.check_solution(cfg, ocfg, sc["p"][i], res.solution[i], res.lagrange_multipliers[i])
+        assert r["n_active_dyn"] >= 1 and r["mu_dyn_max"] > 0.0, r
+        assert_kkt(r, f"N={N} grazing problem {i}")
+        mus.append(r["mu_dyn_max"]); nact.append(r["n_active_hard"])
+        for k in worst:
+            worst[k] = max(worst[k], r[k])
+    print(f"\n[kkt, active hard constraint] N={N}: status histogram {np.bincount(res.status, minlength=3).tolist()}, converged with "
+          f"F2 > 0: {n_inside}; {len(rows)} checked: active constraints per solution {np.bincount(nact).tolist()}, multipliers "
+          f"min {min(mus):.3g} median {np.median(mus):.3g} max {max(mus):.3g}; worst {worst}")
 
 
 def test_closed_loop_ticks_are_local_minima_too():

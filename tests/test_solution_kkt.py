@@ -55,6 +55,35 @@ def test_an_active_hard_constraint_gets_a_non_negative_multiplier():
     assert seen >= 1
 
 
+def active_hard_candidates(cfg, ocfg, p, u, y, status, f2_norm, want):
+    """Converged answers that rest ON a hard ellipse: status 0 and F2 > 0 (the penalty method approaches the constraint from
+    inside), the dynamic constraint active in the inequality form, its NNLS multiplier > 0, and no centimetre-deep
+    penetration of a static polygon that the product-of-hinges form tolerates (kkt.check_solution: `g_static_max`)."""
+    rows = []
+    for i in np.where((status == 0) & (f2_norm > 0.0))[0]:
+        r = kkt.check_solution(cfg, ocfg, p[i], u[i], y[i], run_scipy=False)
+        if r["n_active_dyn"] >= 1 and r["g_static_max"] <= 1e-3 and r.get("mu_dyn_max", 0.0) > 1e-3:
+            rows.append(int(i))
+        if len(rows) >= want:
+            break
+    return rows
+
+
+def test_oracle_solutions_on_an_active_hard_ellipse_are_kkt_points_with_positive_multipliers():
+    """The "grazing" family (scenes.FAMILIES): one disc covers the reference path, soft weights 10 (set_obstacle_weights), so
+    converged plans rest on the hard ellipse (mpc_generator.py:229-241,272).  CPU twin of the GPU test of the same name."""
+    cfg = make_cfg(20)
+    ocfg = oracle_cfg(cfg)
+    sc = scenes.make_family(cfg, 1024, "grazing", seed=21)
+    u, y, res, _ = oracle.solve_batch(ocfg, sc["p"])
+    rows = active_hard_candidates(cfg, ocfg, sc["p"], u, y, res["status"], res["f2_norm"], want=4)
+    assert len(rows) >= 4, rows
+    for i in rows:
+        r = kkt.check_solution(cfg, ocfg, sc["p"][i], u[i], y[i])
+        assert r["n_active_dyn"] >= 1 and r["mu_dyn_max"] > 0.0, r
+        assert_kkt(r, f"grazing problem {i}")
+
+
 def test_a_capped_solve_is_visibly_not_a_kkt_point():
     """The check discriminates: answers that stopped at the iteration cap on the benchmark family fail it by orders of magnitude."""
     cfg = make_cfg(20)

@@ -43,7 +43,8 @@ def work_mode_weights(cfg: MpcConfig) -> np.ndarray:
 def make_batch(cfg: MpcConfig, B: int, n_dyn: int = 8, seed: int = 1234, n_other: int = 0,
                with_box: bool = True, with_walls: bool = True, v_init_range=(0.0, 1.2),
                dyn_clearance: Optional[float] = None, box_clearance: Optional[float] = None,
-               on_track: bool = False) -> Dict[str, np.ndarray]:
+               on_track: bool = False, n_block=None, block_overlap=(0.1, 0.6), block_first_step: int = 8,
+               box_overlap=None, box_overlap_share: float = 1.0, dyn_weight=1e3) -> Dict[str, np.ndarray]:
     """Returns dict(p=[B, np] float64, start=[B,3], ref=[B,N,3]).
 
     ``v_init_range``: range of the previously applied linear speed (p[6]).  Close to the reference speed
@@ -57,7 +58,19 @@ def make_batch(cfg: MpcConfig, B: int, n_dyn: int = 8, seed: int = 1234, n_other
     flat at the box edge, so the penalty method leaves ||F2|| > 1e-4 at the iteration caps).  A number = the inflated
     box stands beside the path with that gap (metres); it is still evaluated at every step of every iteration.
     ``on_track``: the robot starts aligned with a straight reference (what a tick in the middle of a closed-loop run
-    looks like) instead of up to 0.45 rad off a reference with a corner."""
+    looks like) instead of up to 0.45 rad off a reference with a corner.
+    ``n_block``: None, or (lo, hi) = the "avoidance" family: that many of the discs (drawn per problem) stand ON the
+    reference path -- their hard ellipse (radius 1.6 m, ``src/main.py:31,77-85``) covers the path by ``block_overlap``
+    metres at a step >= ``block_first_step`` and they drift along the path, always on the side of the nearer corridor wall,
+    so the detour leads towards the middle of the corridor (>= 2 m of free width) and the hard constraint
+    (``mpc_generator.py:229-241,272``) is active at the optimum.  The other discs follow ``dyn_clearance``.
+    ``box_overlap``: None, or (lo, hi) = the inflated box covers the path by that many metres (same side rule) in a share
+    ``box_overlap_share`` of the problems (the product-of-squared-hinges constraint is flat at the box edge: few of those
+    converge); in the others it stands beside the path as with ``box_clearance``.
+    ``dyn_weight``: the soft-term weights q_dyn the tracker passes (``set_obstacle_weights(dyn_weights=...)``,
+    ``trajectory_generator.py:59,96-113``; default 1e3), a number or (lo, hi) = log-uniform per problem.  With the default
+    the soft margin (weight 1e3 on an ellipse 0.2 m wider) keeps the plan OUTSIDE the hard ellipse; with a weight below
+    ~50 the path-deviation cost wins and the plan rests ON the hard ellipse (active constraint, positive multiplier)."""
     N = int(cfg.N_hor)
     off = cfg.offsets()
     assert n_dyn <= cfg.Ndynobs and n_other <= cfg.Nother
@@ -127,7 +140,17 @@ def make_batch(cfg: MpcConfig, B: int, n_dyn: int = 8, seed: int = 1234, n_other
         by = ref[np.arange(B), kb, 1] + lat * np.cos(ref[np.arange(B), kb, 2])
         hx = 0.5 * rng.uniform(1.0, 2.0, B) + INFLATE
         hy = 0.5 * rng.uniform(1.0, 2.0, B) + INFLATE
-        if box_clearance is not None:   # beside the path: centre beyond the box's circumscribed radius + gap
+        if box_overlap is not None:     # partly ON the path: the nearer edge lies that far beyond the path (axis-aligned box, path ~ along x)
+            yb = ref[np.arange(B), kb, 1]
+            side = np.where(yb >= 5.0, 1.0, -1.0)
+            on = rng.random(B) < box_overlap_share          # the others keep the box beside the path (box_clearance)
+            lat_on = side * (hy - rng.uniform(box_overlap[0], box_overlap[1], B))
+            gap = 0.3 if box_clearance is None else box_clearance
+            lat_off = np.where(lat >= 0.0, 1.0, -1.0) * (np.hypot(hx, hy) + gap)
+            th_b = ref[np.arange(B), kb, 2]
+            bx = np.where(on, ref[np.arange(B), kb, 0], ref[np.arange(B), kb, 0] - lat_off * np.sin(th_b))
+            by = np.where(on, yb + lat_on, yb + lat_off * np.cos(th_b))
+        elif box_clearance is not None:   # beside the path: centre beyond the box's circumscribed radius + gap
             side = np.where(lat >= 0.0, 1.0, -1.0)
             lat = side * (np.hypot(hx, hy) + box_clearance)
             bx = ref[np.arange(B), kb, 0] - lat * np.sin(ref[np.arange(B), kb, 2])
@@ -136,11 +159,19 @@ def make_batch(cfg: MpcConfig, B: int, n_dyn: int = 8, seed: int = 1234, n_other
         o += 1
 
     # ---- dynamic discs crossing the neighbourhood of the path within the horizon
+    n_blk = np.zeros(B, dtype=int) if n_block is None else rng.integers(n_block[0], n_block[1] + 1, B)
     for i in range(n_dyn):
         kc = rng.integers(4, N, B)
         lat = rng.uniform(-3.0, 3.0, B)
         if dyn_clearance is not None:   # passing family: lateral offset beyond radius + gap, either side
             lat = np.sign(lat) * (DYN_OBS_SIZE + dyn_clearance + np.abs(lat) / 3.0 * 1.5)
+        if n_block is not None:         # avoidance family: the first n_blk discs cover the path, on the side of the nearer wall
+            blk_i = i < n_blk
+            kcb = rng.integers(min(block_first_step, N - 1), N, B)
+            ovl = rng.uniform(block_overlap[0], block_overlap[1], B)
+            away = np.where((ref[np.arange(B), kcb, 1] - 5.0) * np.cos(ref[np.arange(B), kcb, 2]) >= 0.0, 1.0, -1.0)
+            kc = np.where(blk_i, kcb, kc)
+            lat = np.where(blk_i, away * (DYN_OBS_SIZE - ovl), lat)
         jx, jy = rng.uniform(-0.5, 0.5, B), rng.uniform(-0.5, 0.5, B)
         if dyn_clearance is not None:
             jx, jy = 0.0 * jx, 0.0 * jy
@@ -165,8 +196,41 @@ def make_batch(cfg: MpcConfig, B: int, n_dyn: int = 8, seed: int = 1234, n_other
         p[:, off["od"] + i * 6 * N: off["od"] + (i + 1) * 6 * N] = blk.reshape(B, 6 * N)
 
     p[:, off["qstc"]:off["qstc"] + N] = 1e3
-    p[:, off["qdyn"]:off["qdyn"] + N] = 1e3
+    if np.ndim(dyn_weight) == 0:
+        p[:, off["qdyn"]:off["qdyn"] + N] = float(dyn_weight)
+    else:
+        p[:, off["qdyn"]:off["qdyn"] + N] = np.exp(rng.uniform(np.log(dyn_weight[0]), np.log(dyn_weight[1]), B))[:, None]
     return dict(p=p, start=np.stack([x, y, th], axis=1), ref=ref)
+
+
+# Named scene families (tests, bench.py legs, reports).  Every one has the same horizon, table sizes and active-row counts as
+# the benchmark family; what changes is where the obstacles stand relative to the reference path.
+FAMILIES: Dict[str, dict] = {
+    # discs anywhere within 3 m of the path, box on the path: mostly no collision-free plan, solves stop at the caps
+    "benchmark": dict(),
+    # discs and box beside the path (>= 0.1 / 0.3 m): a collision-free plan exists along the reference
+    "passing": dict(dyn_clearance=0.1, box_clearance=0.3),
+    # a tick in the middle of a closed-loop run: aligned with a straight reference, at the reference speed
+    "on_track": dict(dyn_clearance=0.1, box_clearance=0.3, on_track=True, v_init_range=(1.0, 1.2)),
+    # 1-3 discs COVER the path by 0.1-0.6 m (hard radius 1.6 m) with the detour towards the free side of the corridor, the box
+    # covers it by 2-30 cm in 30 % of the problems; the robot moves at 0.8-1.2 m/s (a run in progress: with the previous
+    # speed far from the reference speed it is the acceleration constraints that stop the ALM loop, not the obstacles).
+    # ~45 % of cold-start solves converge at N_hor = 20, > 85 % of those with a positive soft-margin term at the optimum.
+    "avoidance": dict(dyn_clearance=0.1, box_clearance=0.3, n_block=(1, 3), block_overlap=(0.1, 0.6),
+                      box_overlap=(0.02, 0.3), box_overlap_share=0.3, v_init_range=(0.8, 1.2)),
+    # one disc covers the path by 5-50 mm and the tracker passes soft weights of 10 instead of 1e3 (set_obstacle_weights):
+    # the plan then rests ON the hard ellipse.  The penalty method needs c >= mu / delta for a multiplier mu, so only small
+    # multipliers converge within 10 outer iterations: ~1-2 % of the solves end Converged with F2 > 0 (active hard constraint).
+    "grazing": dict(dyn_clearance=0.1, box_clearance=0.3, n_block=(1, 1), block_overlap=(0.005, 0.05), dyn_weight=10.0,
+                    v_init_range=(0.8, 1.2)),
+}
+
+
+def make_family(cfg: MpcConfig, B: int, family: str, n_dyn: int = 8, seed: int = 1234, **overrides) -> Dict[str, np.ndarray]:
+    """``make_batch`` with the keyword set of a named family (``FAMILIES``)."""
+    kw = dict(FAMILIES[family])
+    kw.update(overrides)
+    return make_batch(cfg, B, n_dyn=n_dyn, seed=seed, **kw)
 
 
 def shifted_warm_start(u_prev: np.ndarray) -> np.ndarray:
