@@ -36,10 +36,18 @@ Rank 0 prints ONE JSON line (contract in the task description) with extra object
   config.convergent -- the same step on the "passing" scene family (same N, obstacle counts and batch; a
                    collision-free plan exists), where about half of the solves converge: the headline family is the
                    one SURVEY.md 8(d) prescribes and it is cap-limited (see status_histogram).
-  config.batch_sweep -- see above; every batch also `ordered`.
-  config.ordered -- the headline batch with the library's default dispatch order (MPCGPU_OPT_ORDER = 1: longest first by the
-                   evaluation counts of the previous call).  The headline `value` itself starts the problems as given: a bench
-                   step repeats the same batch, which makes those hints perfect.
+  config.avoidance -- the same step on the "avoidance" family (scenes.FAMILIES: 1-3 discs COVER the reference path, the box covers
+                   it in 30 % of the problems, the detour leads to the free side of the corridor): the problems this MPC is for.
+  config.closed_loop -- DeviceTracker at 8192 robots on scene 1 with 4 constant-velocity discs (src/main.py:160-222 semantics): 30
+                   ticks after 5 warm-up ticks, cold and warm start, MPCGPU_OPT_ORDER off and on -- the hints are REAL there
+                   (tick k orders tick k + 1); tools/closed_loop.py.
+  config.batch_sweep -- see above; every batch also `ordered_perfect_hints`.
+  config.ordered_perfect_hints -- the headline batch with the library's default dispatch order (MPCGPU_OPT_ORDER = 1: longest
+                   first by the evaluation counts of the previous call).  A bench step repeats the SAME batch, which makes those
+                   hints perfect: an UPPER BOUND for a receding-horizon loop (config.closed_loop shows what real hints give).
+                   The headline `value` itself starts the problems as given.
+  The side legs (convergent, avoidance, batch_sweep, closed_loop, counter passes, cpu_baseline) run on one rank only unless
+  --full is given: an N-rank run is bounded by the headline leg (plus the ordered leg), not by 8 x every side leg.
   cpu_baseline  -- the oracle (plain-C restatement, "port") on the host cores this process may use, on a bounded
                    sample.
 """
@@ -61,7 +69,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VECTOR_PEAK_TF = 78.6   # MI355X vector FP64: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
-ROOFLINE_JSON = os.path.join(ROOT, "profiles", "r03_roofline_bench.json")
+ROOFLINE_JSON = os.path.join(ROOT, "profiles", "r04_roofline_bench.json")
 SWEEP_BATCHES = (32768, 8192)   # reference batches reported next to the headline (round 1's bench batch; SURVEY.md 8(d)'s metric batch)
 
 
@@ -84,6 +92,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-convergent", action="store_true", help="skip the second leg (profiling runs)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the reference-batch legs (profiling runs)")
     ap.add_argument("--no-pmc", action="store_true", help="do not re-measure the counter-based roofline fields in this run")
+    ap.add_argument("--no-closed-loop", action="store_true", help="skip the closed-loop leg")
+    ap.add_argument("--side-batch", type=int, default=32768, help="problems per GPU of the convergent / avoidance legs")
+    ap.add_argument("--full", action="store_true", help="run the side legs on every rank of a multi-GPU run as well")
     ap.add_argument("--p-file", default=None, help=argparse.SUPPRESS)   # counter passes: the parent's parameter vectors (.npy)
     return ap.parse_args(argv)
 
@@ -133,7 +144,7 @@ def pmc_in_run(args, p_host):
             json.dump({"N_hor": args.horizon, "n_dyn": args.n_dyn, "batch_per_gpu": args.batch, "steps": 1, "warmup": 1,
                        "command": "bench.py's own counter passes (pmc_in_run)"}, fh)
         child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--cpu-seconds", "0",
-                 "--no-convergent", "--no-sweep", "--no-pmc", "--batch", str(args.batch), "--n-dyn", str(args.n_dyn),
+                 "--no-convergent", "--no-sweep", "--no-pmc", "--no-closed-loop", "--batch", str(args.batch), "--n-dyn", str(args.n_dyn),
                  "--horizon", str(args.horizon), "--p-file", pfile]
         env = dict(os.environ, TMPDIR="/tmp")
         env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
@@ -336,13 +347,25 @@ def main():
         vals = [float(v.item()) for v in allv]
         return max(vals), vals
 
+    # Scene generation.  ONE host buffer serves every family: the first touch of a fresh 2.8 GB numpy array (page faults) costs
+    # more than generating its content, so the buffer is allocated once -- page-locked when there is a GPU, which also populates
+    # it in bulk -- and every family is generated into (a slice of) it and uploaded.
+    t_gen = time.perf_counter()
+    host_buf = None if args.p_file else torch.empty((B, cfg.num_params), dtype=torch.float64, pin_memory=not stub).numpy()
+
+    def family_on_device(family, b, seed):
+        scenes.make_family(cfg, b, family, n_dyn=args.n_dyn, seed=seed, out=host_buf[:b])
+        return torch.from_numpy(host_buf[:b]).to(dev, copy=True)
     # every rank owns its own B robots of the global scene set (weak scaling): global problem g = rank*B + i
     if args.p_file:   # counter pass of a parent bench.py: its parameter vectors, not a second scene generation
         sc = {"p": np.load(args.p_file)}
         assert sc["p"].shape == (B, cfg.num_params), sc["p"].shape
+        p = torch.from_numpy(sc["p"]).to(dev)
     else:
-        sc = scenes.make_batch(cfg, B, n_dyn=args.n_dyn, seed=1234 + 7919 * rank)
-    p = torch.from_numpy(sc["p"]).to(dev)
+        p = family_on_device("benchmark", B, 1234 + 7919 * rank)
+        sc = {"p": None}            # the host copy is reused by the other families; cpu_baseline / counter passes read p back
+    gen_s = time.perf_counter() - t_gen
+    side = world == 1 or args.full   # side legs: one rank (or --full)
     leg = timed_leg(p, args.steps, args.warmup)
     elapsed, per_rank_s = over_ranks(leg["elapsed"])
 
@@ -357,30 +380,37 @@ def main():
         item = {"value": world * b * steps / o_el, "unit": "solves/s", "steps": steps, "ms_per_step": 1e3 * o_el / steps,
                 "kernel_ms": ol["kernel_ms"], "status_histogram": np.bincount(ol["status"], minlength=3).tolist(),
                 "how": "MPCGPU_OPT_ORDER = 1 (the library's default): problems started longest first by the evaluation counts of the "
-                       "previous step; the step repeats the same batch, so the hints are perfect (upper bound for a closed loop)"}
+                       "previous step; the step repeats the same batch, so the hints are PERFECT: an upper bound (config.closed_loop "
+                       "has the figure with the real hints of a receding-horizon loop)"}
         if own and hasattr(sv, "close"):
             sv.close()
         return item
 
     ordered_head = None
-    if not args.no_sweep:
+    if side and not args.no_sweep:
         solver.set_order("longest_first")
         ordered_head = ordered_leg(p, min(args.steps, 5), solver, out)
         solver.set_order("as_given")
 
-    conv = None
-    if not args.no_convergent:
-        scc = scenes.make_batch(cfg, B, n_dyn=args.n_dyn, seed=4321 + 7919 * rank, dyn_clearance=0.1, box_clearance=0.3)
-        pc = torch.from_numpy(scc["p"]).to(dev)
-        cleg = timed_leg(pc, min(args.steps, 5), min(args.warmup, 1))
-        c_elapsed, _ = over_ranks(cleg["elapsed"])
-        conv = dict(leg=cleg, elapsed=c_elapsed, steps=min(args.steps, 5))
-        del pc
+    # side legs on other scene families (same N_hor, obstacle counts; `--side-batch` problems per GPU)
+    Bs = min(B, args.side_batch)
+    side_legs = {}
+    if side and not args.no_convergent and not args.p_file:
+        for fam, seed in (("passing", 4321), ("avoidance", 8642)):
+            pc = family_on_device(fam, Bs, seed + 7919 * rank)
+            sv_s, o_s = new_solver(), new_out(Bs)
+            cleg = timed_leg(pc, min(args.steps, 5), min(args.warmup, 1), sv_s, o_s)
+            c_elapsed, _ = over_ranks(cleg["elapsed"])
+            side_legs[fam] = dict(leg=cleg, elapsed=c_elapsed, steps=min(args.steps, 5))
+            if hasattr(sv_s, "close"):
+                sv_s.close()
+            del pc, o_s
+    conv = side_legs.get("passing")
 
     # reference batches of the same workload (the first b problems of this rank's shard): plain launches, and -- for the
     # metric batch -- the pipelined form.  Bounded step counts: these legs must not dominate the run.
     sweep = []
-    if not args.no_sweep:
+    if side and not args.no_sweep:
         side_steps, side_warm = min(args.steps, 5), min(args.warmup, 1)
         for b in SWEEP_BATCHES:
             if b >= B:
@@ -394,7 +424,7 @@ def main():
                               "kernel_ms": sl["kernel_ms"], "status_histogram": np.bincount(sl["status"], minlength=3).tolist()}}
             if hasattr(sv, "close"):
                 sv.close()
-            item["ordered"] = ordered_leg(pb, side_steps)
+            item["ordered_perfect_hints"] = ordered_leg(pb, side_steps)
             if b == SWEEP_BATCHES[-1]:
                 pl = pipelined_leg(pb, 4 * side_steps, side_warm)
                 p_el, _ = over_ranks(pl["elapsed"])
@@ -404,6 +434,23 @@ def main():
                                      "how": "two half shards, two handles, two streams; launches enqueued back to back "
                                             "(reserved shape: no read-back, no host synchronisation inside the timed region)"}
             sweep.append(item)
+
+    closed = None
+    if side and not args.no_closed_loop and not stub and not args.p_file and N == 20:
+        from tools.closed_loop import device_closed_loop
+        closed = {"workload": "DeviceTracker, 8192 robots per GPU, scene 1 (corridor + inflated box on the path, src/pkg_dqn/utils/map.py:292-305) "
+                              "with 4 constant-velocity discs (src/main.py:77-85), one solve per control tick (src/main.py:160-222), 30 timed "
+                              "ticks after 5 warm-up ticks; wall time per tick by HIP events around the whole tick (predictions, window, "
+                              "assembly, solve, rollouts); nothing read back inside the loop",
+                  "runs": []}
+        for warm in (False, True):
+            for order in ("as_given", "longest_first"):
+                r = device_closed_loop(cfg, 8192, 30, 5, 4, warm, order, device=dev_index)
+                r.pop("_final_states")
+                per_tick = r.pop("status_histogram_per_tick")
+                r["status_histogram_first_tick"], r["status_histogram_last_tick"] = per_tick[0], per_tick[-1]
+                closed["runs"].append(r)
+        barrier()
 
     if rank == 0:
         status, inner = leg["status"], leg["inner"]
@@ -445,23 +492,43 @@ def main():
         if conv is not None:
             cl = conv["leg"]
             line["config"]["convergent"] = {
-                "workload": "same N_hor, obstacle counts and batch; 'passing' family (scenes.make_batch dyn_clearance=0.1, "
+                "workload": f"same N_hor and obstacle counts, batch {Bs} per GPU; 'passing' family (scenes.FAMILIES: dyn_clearance=0.1, "
                             "box_clearance=0.3): discs and box beside the path, a collision-free plan exists",
-                "value": world * B * conv["steps"] / conv["elapsed"], "unit": "solves/s", "steps": conv["steps"],
+                "batch_per_gpu": Bs,
+                "value": world * Bs * conv["steps"] / conv["elapsed"], "unit": "solves/s", "steps": conv["steps"],
                 "ms_per_step": 1e3 * conv["elapsed"] / conv["steps"], "kernel_ms": cl["kernel_ms"],
                 "status_histogram": np.bincount(cl["status"], minlength=3).tolist(),
                 "converged_fraction": float((cl["status"] == 0).mean()),
                 "mean_inner_iterations": float(cl["inner"].mean()),
                 "mean_psi_evaluations": float(cl["n_psi"].mean()),
                 "converged_solves_per_s": world * int((cl["status"] == 0).sum()) * conv["steps"] / conv["elapsed"]}
+        if "avoidance" in side_legs:
+            av = side_legs["avoidance"]
+            al = av["leg"]
+            line["config"]["avoidance"] = {
+                "workload": f"same N_hor and obstacle counts, batch {Bs} per GPU; 'avoidance' family (scenes.FAMILIES): 1-3 of the 8 discs "
+                            "(hard radius 1.6 m) cover the reference path by 0.1-0.6 m, the inflated box covers it by 2-30 cm in 30 % of "
+                            "the problems, the detour leads to the free side of the corridor; previous speed 0.8-1.2 m/s",
+                "batch_per_gpu": Bs,
+                "value": world * Bs * av["steps"] / av["elapsed"], "unit": "solves/s", "steps": av["steps"],
+                "ms_per_step": 1e3 * av["elapsed"] / av["steps"], "kernel_ms": al["kernel_ms"],
+                "status_histogram": np.bincount(al["status"], minlength=3).tolist(),
+                "converged_fraction": float((al["status"] == 0).mean()),
+                "mean_inner_iterations": float(al["inner"].mean()),
+                "mean_psi_evaluations": float(al["n_psi"].mean()),
+                "converged_solves_per_s": world * int((al["status"] == 0).sum()) * av["steps"] / av["elapsed"]}
+        if closed is not None:
+            line["config"]["closed_loop"] = closed
         if sweep:
             line["config"]["batch_sweep"] = sweep
         if ordered_head is not None:
-            line["config"]["ordered"] = ordered_head
+            line["config"]["ordered_perfect_hints"] = ordered_head
+        line["config"]["scene_generation_s"] = gen_s
         if not stub:
             from tools.roofline import flops_per_solve_kernel_launch, load_pmc_for
             pmc = load_pmc_for(ROOFLINE_JSON, N, args.n_dyn, B)
-            pmc_here, pmc_err = (None, "disabled (--no-pmc)") if (args.no_pmc or world > 1) else pmc_in_run(args, sc["p"])
+            p_host = sc["p"] if sc["p"] is not None else p.cpu().numpy()
+            pmc_here, pmc_err = (None, "disabled (--no-pmc)") if (args.no_pmc or world > 1) else pmc_in_run(args, p_host)
             in_run = pmc_here is not None
             if in_run:
                 pmc = pmc_here
@@ -503,7 +570,7 @@ def main():
                                                else os.path.relpath(ROOFLINE_JSON, ROOT)}
             line["roofline"] = roof
         if args.cpu_seconds > 0 and world == 1 and not stub:
-            line["cpu_baseline"] = cpu_baseline(cfg, sc["p"], args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(cfg, p[:16384].cpu().numpy(), args.cpu_seconds)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -19,7 +19,7 @@ def _env(**kw):
 
 def test_bench_self_launches_two_ranks_when_run_without_a_launcher():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--batch", "64", "--cpu-seconds", "0"],
+                        "--batch", "64", "--cpu-seconds", "0", "--full"],
                        env=_env(MPCGPU_BENCH_BACKEND="gloo", MPCGPU_BENCH_STUB="1"), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -31,8 +31,21 @@ def test_bench_self_launches_two_ranks_when_run_without_a_launcher():
     # whole-job value = all ranks' problems / max-over-ranks time
     assert abs(line["value"] - 2 * 64 * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["value"]
     assert line["value"] <= sum(line["per_rank_solves_per_s"]) * (1 + 1e-9)
-    assert line["config"]["convergent"]["value"] > 0
+    assert line["config"]["convergent"]["value"] > 0 and line["config"]["avoidance"]["value"] > 0      # --full: side legs on every rank
+    assert "ordered_perfect_hints" in line["config"] and "ordered" not in line["config"]
     assert "roofline" not in line and "cpu_baseline" not in line  # the stub measures nothing
+
+
+def test_multi_rank_run_without_full_is_bounded_by_the_headline_leg():
+    """An N-rank run reports the headline leg only (the side legs belong to the one-rank run, or to --full)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "64", "--cpu-seconds", "0"],
+                       env=_env(MPCGPU_BENCH_BACKEND="gloo", MPCGPU_BENCH_STUB="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    for k in ("convergent", "avoidance", "batch_sweep", "closed_loop", "ordered_perfect_hints"):
+        assert k not in line["config"], k
 
 
 def test_bench_refuses_a_world_size_that_disagrees_with_gpus():

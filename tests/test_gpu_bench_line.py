@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 def test_bench_line_contract_and_in_run_counters():
     B = 4096
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", str(B), "--steps", "2", "--warmup", "1",
-                        "--cpu-seconds", "2", "--no-convergent", "--no-sweep"], cwd=ROOT, stdout=subprocess.PIPE,
+                        "--cpu-seconds", "2", "--no-convergent", "--no-sweep", "--no-closed-loop"], cwd=ROOT, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]

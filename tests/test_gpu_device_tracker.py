@@ -170,3 +170,34 @@ def test_rl_reference_and_hint_switch_kernels_match_the_host_forms():
         seen_on += int((on_h & ~prev).sum()); seen_off += int((~on_h & prev).sum())
     assert seen_on > 50 and seen_off > 5                                # both transitions were exercised
     bs.close()
+
+
+def test_set_up_calls_in_the_middle_of_a_run_touch_only_their_robot():
+    """`update_static_constraints` may be called at any time (src/interface_mpc.py:60-63) and re-planning one robot must not move
+    the others: after some ticks, robot 0 gets a new map and robot 1 a new plan; every other robot keeps the state, reference
+    index, last action and activity flag the device has advanced it to, robot 1 alone starts over."""
+    cfg = make_cfg(20, solver_max_inner_iterations=30, solver_max_outer_iterations=2)
+    B = 12
+    dev = DeviceTracker(cfg, B)
+    host = BatchedTracker(cfg, B, solver=dev.solver)
+    _setup(cfg, B, np.random.default_rng(3), host, dev)
+    for _ in range(5):
+        dev.step()
+    torch.cuda.synchronize()
+    before = {k: getattr(dev, k).clone() for k in ("states", "idx_ref", "last_actions", "active", "stc", "goals", "ref_len")}
+    assert float((before["states"][:, 0] - 0.6).abs().min()) > 1e-3          # everybody has moved
+    dev.update_static_constraints(0, [[(1.0, 1.0), (2.0, 1.0), (2.0, 2.0), (1.0, 2.0)]])
+    long_path = [(0.5, 3.0)] + [(0.5 + 3.0 * j, 3.0 + (j % 2)) for j in range(1, 12)]        # longer than any reference so far
+    dev.initialization(1, np.array([0.5, 3.0, 0.1]), np.array([long_path[-1][0], long_path[-1][1], 0.0]), long_path, "work")
+    dev.view()
+    torch.cuda.synchronize()
+    others = [i for i in range(B) if i != 1]
+    for k in ("states", "idx_ref", "last_actions", "active", "goals", "ref_len"):
+        assert torch.equal(getattr(dev, k)[others], before[k][others]), k
+    assert torch.equal(dev.stc[1:], before["stc"][1:]) and not torch.equal(dev.stc[0], before["stc"][0])
+    assert torch.equal(dev.states[1].cpu(), torch.tensor([0.5, 3.0, 0.1], dtype=torch.float64))
+    assert int(dev.idx_ref[1]) == 0 and int(dev.active[1]) == 1 and float(dev.last_actions[1].abs().sum()) == 0.0
+    assert int(dev.ref_len[1]) > int(before["ref_len"].max()) and dev.ref.shape[1] == int(dev.ref_len[1])
+    out = dev.step()                                                           # and the run goes on
+    torch.cuda.synchronize()
+    assert int((out["status"] >= 0).sum()) == B

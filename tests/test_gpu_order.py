@@ -44,8 +44,8 @@ def test_results_do_not_depend_on_the_dispatch_order(N, B):
     r4 = bs.solve(np.ascontiguousarray(sc["p"][perm]))
     assert bs.last_shape()["ordered"]
     assert np.array_equal(r4.solution, r0.solution[perm]) and np.array_equal(r4.status, r0.status[perm])
+    # a figure, not an assertion (timing belongs to bench.py / tools/closed_loop.py; measured: -14 % and -30 % on these two batches)
     print(f"\nN_hor {N}, B {B}: as given {t_plain:.1f} ms, longest first {t_ord:.1f} ms")
-    assert t_ord < 1.05 * t_plain               # good hints do not cost (measured: -14 % and -30 % on these two batches)
     plain.close(); bs.close()
 
 
@@ -60,3 +60,21 @@ def test_small_batches_and_the_switch():
         bs.set_order("shortest_first")
     bs.set_order("as_given")
     bs.close()
+
+
+def test_closed_loop_with_real_hints_gives_the_same_trajectories():
+    """tools/closed_loop.device_closed_loop (bench.py's `config.closed_loop`): the evaluation counts of tick k order tick k + 1.
+    The robots must end exactly where the as-given launches take them, cold and warm start."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tools.closed_loop import device_closed_loop
+    cfg = MpcConfig(solver_max_inner_iterations=60, solver_max_outer_iterations=3)
+    for warm in (False, True):
+        a = device_closed_loop(cfg, 6144, 3, 2, 4, warm, "as_given")
+        b = device_closed_loop(cfg, 6144, 3, 2, 4, warm, "longest_first")
+        assert a["ordered_ticks"] == 0 and b["ordered_ticks"] == 3
+        assert np.array_equal(a["_final_states"], b["_final_states"])
+        assert a["status_histogram_per_tick"] == b["status_histogram_per_tick"]
+        assert len(a["status_histogram_per_tick"]) == 3 and sum(a["status_histogram_per_tick"][0]) == 6144
+        assert a["mean_x_after"] > 0.7 and a["value"] > 0 and a["start"] == ("warm" if warm else "cold")

@@ -1,49 +1,167 @@
 #!/usr/bin/env python3
-"""Closed-loop run of the batched tracker on the MI355X: B robots drive the reference's scene 1 (corridor, inflated
-box on the path, src/pkg_dqn/utils/map.py:292-305) while discs cross it; one GPU solve per control tick.
-usage: closed_loop.py [B] [ticks] [n_dyn] [warm]"""
-import os, sys, time
-import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-from trajtrack_mpcndqn_rlboost_amd import BatchedTracker, MpcConfig
-from trajtrack_mpcndqn_rlboost_amd.feeders import constant_velocity_prediction, DYN_OBS_SIZE
+"""Closed-loop run of the batched tracker on the MI355X: B robots drive the reference's scene 1 (corridor, inflated box on the
+path, src/pkg_dqn/utils/map.py:292-305) while discs cross it; one GPU solve per control tick -- the loop of src/main.py:160-222
+(pure-MPC branch) / src/scenario_simulator.py:211-250 for B robots at once.
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-T = int(sys.argv[2]) if len(sys.argv) > 2 else 80
-K = int(sys.argv[3]) if len(sys.argv) > 3 else 2
-cfg = MpcConfig()
-rng = np.random.default_rng(5)
-walls = [[(0.0, 1.5), (0.0, 1.6), (9.0, 1.6), (9.0, 1.5)], [(0.0, 8.4), (0.0, 8.5), (9.0, 8.5), (9.0, 8.4)],
+`device_closed_loop` is the DEVICE-RESIDENT form (DeviceTracker: window search, assembly, solve and rollouts enqueued on one
+stream, the constant-velocity predictions of src/main.py:77-85 formed by torch kernels, nothing read back inside the timed
+ticks); bench.py reports it as `config.closed_loop`.  The hints of MPCGPU_OPT_ORDER are REAL here: the evaluation counts of tick
+k order tick k + 1.
+
+usage: closed_loop.py [B] [ticks] [n_dyn] [warm] [host]      ("host": the host-assembly loop of rounds 1-3, BatchedTracker)"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WALLS = [[(0.0, 1.5), (0.0, 1.6), (9.0, 1.6), (9.0, 1.5)], [(0.0, 8.4), (0.0, 8.5), (9.0, 8.5), (9.0, 8.4)],
          [(11.0, 1.5), (11.0, 1.6), (16.0, 1.6), (16.0, 1.5)], [(11.0, 8.4), (11.0, 8.5), (16.0, 8.5), (16.0, 8.4)]]
-inflate = lambda poly, m=0.8: [(min(x for x, _ in poly) - m, min(y for _, y in poly) - m), (max(x for x, _ in poly) + m, min(y for _, y in poly) - m),
-                               (max(x for x, _ in poly) + m, max(y for _, y in poly) + m), (min(x for x, _ in poly) - m, max(y for _, y in poly) + m)]
-box = [(7.5, 3.0), (7.5, 4.0), (8.5, 4.0), (8.5, 3.0)]
-static = [inflate(w) for w in walls] + [inflate(box)]
-WARM = len(sys.argv) > 4 and sys.argv[4] == "warm"
-bt = BatchedTracker(cfg, B, warm_start=WARM)
-y0 = rng.uniform(3.0, 4.0, B)
-for i in range(B):
-    bt.initialization(i, np.array([0.6, y0[i], 0.0]), np.array([15.4, 3.5, 0.0]),
-                      [(0.6, y0[i]), (6.0, 5.6), (10.0, 5.6), (15.4, 3.5)], "work")
-    bt.update_static_constraints(i, static)
-# discs: start right of the box, move left/down slowly (different per robot world)
-pos = np.stack([rng.uniform(10.0, 14.0, (B, K)), rng.uniform(4.5, 7.0, (B, K))], axis=-1)
-vel = np.stack([rng.uniform(-0.12, -0.04, (B, K)), rng.uniform(-0.03, 0.03, (B, K))], axis=-1)
-inside_box = np.zeros(B, bool); hit_disc = np.zeros(B, bool)
-t0 = time.time(); solve_ms = []
-for t in range(T):
-    pred = constant_velocity_prediction(pos - vel, pos, steps=cfg.N_hor)         # [B, K, N, 6]
-    bt.set_dynamic_constraints(pred)
-    actions, _, cost = bt.step("work")
-    solve_ms.append(bt.solver.last_timing()["solve_ms"])
-    pos = pos + vel
-    x, y = bt.states[:, 0], bt.states[:, 1]
-    inside_box |= (x > 7.5) & (x < 8.5) & (y > 3.0) & (y < 4.0)
-    hit_disc |= (np.hypot(pos[..., 0] - x[:, None], pos[..., 1] - y[:, None]) < 0.8).any(axis=1)   # physical radius 0.8
-wall = time.time() - t0
-d_goal = np.hypot(bt.states[:, 0] - 15.4, bt.states[:, 1] - 3.5)
-print(f"B={B} ticks={T} discs={K} {'warm' if WARM else 'cold'} start: wall {wall:.1f}s  kernel {np.mean(solve_ms):.1f} ms/tick  ({B * T / (np.sum(solve_ms) * 1e-3):.0f} solves/s in-kernel)")
-print(f"  progress: mean x {bt.states[:, 0].mean():.2f} m (start 0.6), within 0.5 m of goal: {(d_goal < 0.5).mean():.2f}, still active {bt.active.mean():.2f}")
-print(f"  safety  : entered the (un-inflated) box {inside_box.mean():.3f}, touched a disc (0.8 m) {hit_disc.mean():.3f}")
-print(f"  last tick status histogram {np.bincount(bt.last_result.status, minlength=4).tolist()} mean inner it {bt.last_result.num_inner_iterations.mean():.0f}")
+BOX = [(7.5, 3.0), (7.5, 4.0), (8.5, 4.0), (8.5, 3.0)]
+
+
+def inflate(poly, m=0.8):
+    xs, ys = [x for x, _ in poly], [y for _, y in poly]
+    return [(min(xs) - m, min(ys) - m), (max(xs) + m, min(ys) - m), (max(xs) + m, max(ys) + m), (min(xs) - m, max(ys) + m)]
+
+
+def scene_one(B, K, seed=5):
+    """Start rows, the common path / goal, static polygons, disc positions and velocities (one private copy of the scene per robot)."""
+    rng = np.random.default_rng(seed)
+    y0 = rng.uniform(3.0, 4.0, B)
+    pos = np.stack([rng.uniform(10.0, 14.0, (B, K)), rng.uniform(4.5, 7.0, (B, K))], axis=-1)
+    vel = np.stack([rng.uniform(-0.12, -0.04, (B, K)), rng.uniform(-0.03, 0.03, (B, K))], axis=-1)
+    static = [inflate(w) for w in WALLS] + [inflate(BOX)]
+    return y0, pos, vel, static
+
+
+def setup(tracker, B, y0, static):
+    for i in range(B):
+        tracker.initialization(i, np.array([0.6, y0[i], 0.0]), np.array([15.4, 3.5, 0.0]),
+                               [(0.6, y0[i]), (6.0, 5.6), (10.0, 5.6), (15.4, 3.5)], "work")
+        tracker.update_static_constraints(i, static)
+
+
+def device_closed_loop(cfg, B=8192, ticks=30, warmup_ticks=5, n_dyn=4, warm=False, order="longest_first", device=0, seed=5):
+    """Returns a dict: per-tick wall time (HIP events around the whole tick), solves/s, status histogram of every timed tick,
+    mean inner iterations, progress and safety figures.  `warm`: previous plan shifted by one step as initial guess
+    (the reference passes initial_guess=None, i.e. cold: src/interface_mpc.py:82)."""
+    import torch
+    from trajtrack_mpcndqn_rlboost_amd import BatchSolver
+    from trajtrack_mpcndqn_rlboost_amd.device_tracker import DeviceTracker
+    from trajtrack_mpcndqn_rlboost_amd.feeders import DYN_OBS_SIZE
+    N = int(cfg.N_hor)
+    dev = torch.device("cuda", device)
+    solver = BatchSolver(cfg, device=device, order=order)
+    dt = DeviceTracker(cfg, B, device=device, solver=solver)
+    y0, pos_h, vel_h, static = scene_one(B, n_dyn, seed)
+    setup(dt, B, y0, static)
+    pos = torch.from_numpy(pos_h).to(dev)
+    vel = torch.from_numpy(vel_h).to(dev)
+    k = torch.arange(1, N + 1, dtype=torch.float64, device=dev)
+    pred = torch.zeros(B, n_dyn, N, 6, dtype=torch.float64, device=dev)
+    pred[..., 2] = DYN_OBS_SIZE; pred[..., 3] = DYN_OBS_SIZE; pred[..., 5] = 1.0
+
+    def predictions():      # est_dyn_obs_positions (src/main.py:77-85): current + (k + 1) * (current - last)
+        delta = pos - (pos - vel)
+        pred[..., 0] = pos[..., None, 0] + delta[..., None, 0] * k
+        pred[..., 1] = pos[..., None, 1] + delta[..., None, 1] * k
+        return pred
+    total = warmup_ticks + ticks
+    hist = torch.zeros(total, 4, dtype=torch.int64, device=dev)
+    inner = torch.zeros(total, dtype=torch.float64, device=dev)
+    inside_box = torch.zeros(B, dtype=torch.bool, device=dev)
+    hit_disc = torch.zeros(B, dtype=torch.bool, device=dev)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(total + 1)]
+    guess = None
+    ordered = []
+    for t in range(total):
+        ev[t].record()
+        dt.set_dynamic_constraints(predictions())
+        out = dt.step(initial_guess=guess)
+        if t == 0:           # the first tick found the batch's shape (count read-back); the following ticks read nothing back
+            torch.cuda.synchronize()
+            sh = solver.last_shape()
+            solver.reserve_shape(max_static=sh["max_static"], max_fleet=sh["max_fleet"], max_dyn=sh["max_dyn"],
+                                 var_shape=not sh["shape_const"], axis_aligned=sh["axis_aligned"])
+            solver.reserve_batch(B)
+        ordered.append(bool(solver.last_shape()["ordered"]))
+        hist[t] = torch.bincount(out["status"].to(torch.int64), minlength=4)[:4]
+        inner[t] = out["inner_it"].to(torch.float64).mean()
+        if warm:
+            u = out["u"].view(B, N, 2)
+            guess = torch.cat([u[:, 1:], u[:, -1:]], dim=1).reshape(B, 2 * N).contiguous()
+        pos += vel
+        x, y = dt.states[:, 0], dt.states[:, 1]
+        inside_box |= (x > 7.5) & (x < 8.5) & (y > 3.0) & (y < 4.0)
+        hit_disc |= (torch.hypot(pos[..., 0] - x[:, None], pos[..., 1] - y[:, None]) < 0.8).any(dim=1)
+    ev[total].record()
+    torch.cuda.synchronize()
+    tick_ms = [ev[t].elapsed_time(ev[t + 1]) for t in range(total)]
+    timed = tick_ms[warmup_ticks:]
+    hist_h = hist.cpu().numpy()
+    res = {"batch": B, "ticks": ticks, "warmup_ticks": warmup_ticks, "n_dyn": n_dyn, "start": "warm" if warm else "cold",
+           "order": order, "ordered_ticks": int(sum(ordered[warmup_ticks:])),
+           "ms_per_tick": float(np.mean(timed)), "ms_per_tick_min_max": [float(min(timed)), float(max(timed))],
+           "value": B * ticks / (sum(timed) * 1e-3), "unit": "solves/s",
+           "status_histogram_per_tick": hist_h[warmup_ticks:, :3].tolist(),
+           "status_histogram_total": hist_h[warmup_ticks:, :3].sum(axis=0).tolist(),
+           "converged_fraction": float(hist_h[warmup_ticks:, 0].sum() / (B * ticks)),
+           "mean_inner_iterations": float(inner[warmup_ticks:].mean()),
+           "mean_x_after": float(dt.states[:, 0].mean()), "still_active": float(dt.active.to(torch.float64).mean()),
+           "entered_box": float(inside_box.to(torch.float64).mean()), "touched_disc": float(hit_disc.to(torch.float64).mean()),
+           "lds_bytes_per_wavefront": solver.last_shape()["lds_bytes"], "wavefronts_per_simd": solver.last_shape()["waves_per_simd"]}
+    res["_final_states"] = dt.states.cpu().numpy()
+    solver.close()
+    return res
+
+
+def host_loop(B, T, K, warm):
+    from trajtrack_mpcndqn_rlboost_amd import BatchedTracker, MpcConfig
+    from trajtrack_mpcndqn_rlboost_amd.feeders import constant_velocity_prediction
+    cfg = MpcConfig()
+    bt = BatchedTracker(cfg, B, warm_start=warm)
+    y0, pos, vel, static = scene_one(B, K)
+    setup(bt, B, y0, static)
+    inside_box = np.zeros(B, bool); hit_disc = np.zeros(B, bool)
+    t0 = time.time(); solve_ms = []
+    for t in range(T):
+        pred = constant_velocity_prediction(pos - vel, pos, steps=cfg.N_hor)         # [B, K, N, 6]
+        bt.set_dynamic_constraints(pred)
+        bt.step("work")
+        solve_ms.append(bt.solver.last_timing()["solve_ms"])
+        pos = pos + vel
+        x, y = bt.states[:, 0], bt.states[:, 1]
+        inside_box |= (x > 7.5) & (x < 8.5) & (y > 3.0) & (y < 4.0)
+        hit_disc |= (np.hypot(pos[..., 0] - x[:, None], pos[..., 1] - y[:, None]) < 0.8).any(axis=1)   # physical radius 0.8
+    wall = time.time() - t0
+    d_goal = np.hypot(bt.states[:, 0] - 15.4, bt.states[:, 1] - 3.5)
+    print(f"[host assembly] B={B} ticks={T} discs={K} {'warm' if warm else 'cold'} start: wall {wall:.1f}s  kernel {np.mean(solve_ms):.1f} ms/tick  "
+          f"({B * T / (np.sum(solve_ms) * 1e-3):.0f} solves/s in-kernel)")
+    print(f"  progress: mean x {bt.states[:, 0].mean():.2f} m (start 0.6), within 0.5 m of goal: {(d_goal < 0.5).mean():.2f}, still active {bt.active.mean():.2f}")
+    print(f"  safety  : entered the (un-inflated) box {inside_box.mean():.3f}, touched a disc (0.8 m) {hit_disc.mean():.3f}")
+    print(f"  last tick status histogram {np.bincount(bt.last_result.status, minlength=4).tolist()} mean inner it {bt.last_result.num_inner_iterations.mean():.0f}")
+    return bt.states.copy()
+
+
+if __name__ == "__main__":
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    T = int(sys.argv[2]) if len(sys.argv) > 2 else 80
+    K = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    WARM = "warm" in sys.argv[4:]
+    if "host" in sys.argv[4:]:
+        host_loop(B, T, K, WARM)
+    else:
+        from trajtrack_mpcndqn_rlboost_amd import MpcConfig
+        for order in ("as_given", "longest_first"):
+            r = device_closed_loop(MpcConfig(), B, T, 5, K, WARM, order)
+            r.pop("_final_states")
+            per_tick = r.pop("status_histogram_per_tick")
+            print(f"[device loop] order {order:13s} {r['start']} start: {r['ms_per_tick']:.1f} ms/tick ({r['value']:.0f} solves/s), ordered ticks "
+                  f"{r['ordered_ticks']}/{T}, status total {r['status_histogram_total']}, first / last tick {per_tick[0]} / {per_tick[-1]}, "
+                  f"mean inner {r['mean_inner_iterations']:.0f}, mean x {r['mean_x_after']:.2f} m, entered box {r['entered_box']:.3f}, "
+                  f"touched a disc {r['touched_disc']:.3f}")

@@ -57,7 +57,8 @@ struct Handle {
     bool capturing = false;  // the launch stream of the current call is being captured into a hipGraph: no event records
     bool reserved = false;
     int res_shape[4] = {0, 0, 0, 0};  // max static, fleet, dynamic rows; 0 = shape-constant rows, 1 = they may change shape, 2 = shape-constant AND axis-aligned
-    hipStream_t last_stream = nullptr;  // launch stream of the last solve (mpcgpu_last_eval_counts waits for it)
+    hipStream_t last_stream = nullptr;  // launch stream of the last solve: compared only, never dereferenced (it may be gone by now)
+    bool last_captured = false;         // the last solve was recorded into a hipGraph (no completion event exists for it)
     std::unordered_map<const void*, int> lds_attr;  // kernel -> largest dynamic-LDS size opted into (hipFuncSetAttribute once, not per launch)
 };
 
@@ -389,7 +390,11 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
                      const double* y0, const double* c0, double* u, double* cost, int32_t* status, int32_t* inner_it,
                      int32_t* outer_it, double* fpr, double* f2norm, double* y_out, double* ms, hipStream_t s) {
     h->capturing = stream_is_capturing(s);
+    // The evaluation counts the previous call left in `evals` order this launch (MPCGPU_OPT_ORDER) only when that call was
+    // enqueued on the SAME stream: another stream gives no ordering between its solve kernel and the kernels that read the counts.
+    const bool same_stream_as_last = h->last_stream == s && h->last_B > 0;
     h->last_stream = s;
+    h->last_captured = h->capturing;
     BatchPtrs io{};
     // Small batches take the latency kernel: one problem per workgroup of four wavefronts, compaction fused, carve from the
     // configured maxima -- one launch, nothing read back.  Results are bitwise those of the throughput kernel.
@@ -431,7 +436,9 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
         io.outer_it = outer_it; io.fpr = fpr; io.f2norm = f2norm; io.y_out = y_out; io.ms = ms;
         // (A) up to two problems per compute unit, nothing promised: ONE launch -- four wavefronts per problem, compaction fused,
         //     tables for the configured maxima, nothing read back.
-        if (B <= 2 * h->num_cus && !h->reserved) {
+        // Inside a stream capture without a reservation the whole latency range takes this form (the mid-batch form below reads
+        // the row counts back, which a capture cannot do): up to four problems per compute unit then run in two rounds.
+        if ((B <= 2 * h->num_cus || h->capturing) && !h->reserved) {
             KParams kt = h->kp;
             fill_team_layout(kt, TEAM_WAVES, h->cfg.Nstcobs, h->cfg.Nother, h->cfg.Ndynobs);
             const size_t lds_t = kt.l_total * sizeof(double);
@@ -521,7 +528,7 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
         const int by_regs = 4 * (h->last_pairing ? 2 : h->last_min_waves), by_lds = (int)(160 * 1024 / wg_lds);
         resident = (by_regs < by_lds ? by_regs : by_lds) * h->num_cus * (h->last_pairing ? 2 : 1);
     }
-    if (h->order == 1 && h->evals_B == B && B > resident) {
+    if (h->order == 1 && h->evals_B == B && B > resident && same_stream_as_last) {
         if (int r = ensure(h, h->perm, (size_t)B * sizeof(int32_t))) return r;
         if (int r = ensure(h, h->bins, ORD_BINS * sizeof(int))) return r;
         // bin width: 1024 bins over the largest possible evaluation count (about 12 per PANOC step)
@@ -818,10 +825,13 @@ int32_t mpcgpu_last_eval_counts(void* handle, int32_t B, int32_t* n_psi, int32_t
     if (!h) return -1;
     if (B != h->last_B || !h->evals.ptr) return fail(h, -4, "no solve of %d problems precedes this call (last: %d)", B, h->last_B);
     HIP_OK(h, hipSetDevice(h->device));
-    // the counters are written by the solve kernel: wait for the stream THAT launch went to (and for the caller's, if another)
-    HIP_OK(h, hipStreamSynchronize(h->last_stream));
+    // The counters are written by the solve kernel: wait for the EVENT recorded behind it (the launch stream is the caller's and may
+    // have been destroyed since; a stream handle is never touched here unless the caller passes it now).  A solve that was captured
+    // into a hipGraph has no such event: its replays are ordered by the stream the caller names, plus a device-wide wait.
+    if (!h->last_captured && h->timing_valid) HIP_OK(h, hipEventSynchronize(h->ev[3]));
+    else HIP_OK(h, hipDeviceSynchronize());
     hipStream_t s = pick_stream(h, stream);
-    if (s != h->last_stream) HIP_OK(h, hipStreamSynchronize(s));
+    if (s != h->last_stream || h->last_captured) HIP_OK(h, hipStreamSynchronize(s));
     int32_t* tmp = new (std::nothrow) int32_t[(size_t)B * 2];
     if (!tmp) return fail(h, -3, "out of host memory");
     hipError_t e = hipMemcpy(tmp, h->evals.ptr, (size_t)B * 2 * sizeof(int32_t), hipMemcpyDeviceToHost);

@@ -94,25 +94,35 @@ __global__ __launch_bounds__(128) void rl_reference_kernel(int B, const double* 
     double x = s0[0], y = s0[1], th = s0[2], v = s0[3], w = s0[4];
     const int a = (int)action[b];
     // step 0: the chosen acceleration pair (agent.py:124-145): index // 3 picks the linear, index % 3 the angular acceleration
-    v = v + ts * (a / 3 == 0 ? lim.acc_max : 0.0) + ts * (a / 3 == 2 ? lim.acc_min : 0.0);
-    w = w + ts * (a % 3 == 0 ? lim.angacc_max : 0.0) + ts * (a % 3 == 2 ? lim.angacc_min : 0.0);
+    // Every product is a statement of its own: this file is built with -ffp-contract=on, which fuses an expression the way it is
+    // written -- `th + ts * w` would become one FMA and the rollout would no longer be the host's numpy form (multiply, round, add).
+    const double av0 = ts * (a / 3 == 0 ? lim.acc_max : 0.0), av1 = ts * (a / 3 == 2 ? lim.acc_min : 0.0);
+    const double aw0 = ts * (a % 3 == 0 ? lim.angacc_max : 0.0), aw1 = ts * (a % 3 == 2 ? lim.angacc_min : 0.0);
+    v = v + av0; v = v + av1;
+    w = w + aw0; w = w + aw1;
     v = fmin(fmax(v, lim.speed_min), lim.speed_max);
     w = fmin(fmax(w, lim.angvel_min), lim.angvel_max);
     double sn, cs;
-    th = th + ts * w;
+    const double dth0 = ts * w;
+    th = th + dth0;
     sincos(th, &sn, &cs);
-    x = x + ts * v * cs;
-    y = y + ts * v * sn;
+    const double tv = ts * v;
+    const double dx0 = tv * cs, dy0 = tv * sn;
+    x = x + dx0;
+    y = y + dy0;
     double* o = rl_ref + (size_t)b * steps * 2;
     o[0] = x; o[1] = y;
     const double speed = ref_speed > 0.0 ? ref_speed : lim.speed_max;
+    const double tsp = ts * speed;
 #pragma unroll 1
     for (int j = 1; j < steps; ++j) {                 // agent.py:86-100: constant speed, turn rate decaying by 5 % per step
         w = w * 0.95;
-        th = th + ts * w;
+        const double dth = ts * w;
+        th = th + dth;
         sincos(th, &sn, &cs);
-        x = x + ts * speed * cs;
-        y = y + ts * speed * sn;
+        const double dx = tsp * cs, dy = tsp * sn;
+        x = x + dx;
+        y = y + dy;
         o[2 * j] = x; o[2 * j + 1] = y;
     }
 }
@@ -172,7 +182,10 @@ __global__ __launch_bounds__(64) void hint_switch_kernel(int B, int N, int O, in
     if (consulted) {
         const double px = states[3 * b], py = states[3 * b + 1];
         bool counted = false, returned = false;
-        for (int r = 0; r < N && !returned; ++r) {
+        // HintSwitcher.switch walks zip(original_traj, new_traj) (src/main_pre.py:37): min(N, rl_steps) rows -- with a 40-step
+        // horizon and the 20-step proposal the last 20 rows of the original reference are never tested
+        const int rows = N < rl_steps ? N : rl_steps;
+        for (int r = 0; r < rows && !returned; ++r) {
             for (int o = 0; o < O && !returned; ++o) {
                 if (!valid[(size_t)b * O + o]) continue;
                 const double* ring = poly + (size_t)o * V * 2;

@@ -6,7 +6,10 @@ Per tick (``step``): termination test, speed rule and assembly written directly 
 the arrays below -- bitwise the record the compaction kernel makes of ``BatchedTracker.assemble()``), the batched solve, and the
 post-solve rollouts (``trajectory_generator.py:325-339``) -- all enqueued on one stream, nothing read back.  ``local_refs`` is the
 window search of ``get_local_ref_traj`` (``trajectory_generator.py:206-232``) as a kernel.  Set-up calls (``initialization``,
-``update_static_constraints``) run on the host exactly like the host tracker's and are uploaded before the next tick.
+``update_static_constraints``) run on the host exactly like the host tracker's and are uploaded before the next tick -- per
+robot and per field: ``update_static_constraints(i)`` rewrites robot i's half-plane rows and nothing else (it may be called at any
+time, ``src/interface_mpc.py:60-63``), ``initialization(i)`` re-plans robot i alone; the other robots keep the state the device has
+advanced them to.
 """
 from __future__ import annotations
 
@@ -52,7 +55,7 @@ class DeviceTracker:
         self._h_ref = [np.zeros((1, 3))] * B
         self._h_states, self._h_goals = np.zeros((B, 3)), np.zeros((B, 3))
         self._h_stc = np.zeros((B, config.Nstcobs * config.nstcobs))
-        self._dirty = True
+        self._init_rows, self._stc_rows = set(), set()      # robots whose set-up calls wait for their upload
 
     def set_mode(self, mode: str):
         self.base_speed, self.tuning = work_mode(self.config, mode)
@@ -62,27 +65,39 @@ class DeviceTracker:
         base_speed, _ = work_mode(self.config, mode)
         self._h_states[i], self._h_goals[i] = init_state, goal_state
         self._h_ref[i] = global_reference_trajectory(self.config.ts, ref_path_list, self._h_states[i], base_speed)
-        self._dirty = True
+        self._init_rows.add(int(i))
 
     def update_static_constraints(self, i: int, obstacle_list):
         self._h_stc[i] = static_obstacle_params(obstacle_list, self.config.Nstcobs, self.config.nstcobs)
-        self._dirty = True
+        self._stc_rows.add(int(i))
 
     def _upload(self):
-        if not self._dirty:
-            return
+        """Rows touched by set-up calls since the last tick, and only those: the device arrays are the truth for every robot
+        that is running (the host mirrors hold what the set-up calls were given, not where the robots are now)."""
         torch = self._torch
-        cap = max(len(r) for r in self._h_ref)
-        ref = np.zeros((self.B, cap, 3))
-        for i, r in enumerate(self._h_ref):
-            ref[i, :len(r)] = r
-        self.ref = torch.from_numpy(ref).to(self.device)
-        self.ref_len = torch.tensor([len(r) for r in self._h_ref], dtype=torch.int32, device=self.device)
-        self.states.copy_(torch.from_numpy(self._h_states))
-        self.goals.copy_(torch.from_numpy(self._h_goals))
-        self.stc.copy_(torch.from_numpy(self._h_stc))
-        self.last_actions.zero_(); self.idx_ref.zero_(); self.active.fill_(1)
-        self._dirty = False
+        if self._stc_rows:
+            rows = sorted(self._stc_rows)
+            self.stc[torch.tensor(rows, device=self.device)] = torch.from_numpy(self._h_stc[rows]).to(self.device)
+            self._stc_rows.clear()
+        if self._init_rows:
+            rows = sorted(self._init_rows)
+            idx = torch.tensor(rows, device=self.device)
+            need = max(len(self._h_ref[i]) for i in rows)
+            if need > self.ref.shape[1]:        # longer reference than any so far: grow the table, the others keep their rows
+                grown = torch.zeros(self.B, need, 3, dtype=torch.float64, device=self.device)
+                grown[:, :self.ref.shape[1]] = self.ref
+                self.ref = grown
+            block = np.zeros((len(rows), self.ref.shape[1], 3))
+            for j, i in enumerate(rows):
+                block[j, :len(self._h_ref[i])] = self._h_ref[i]
+            self.ref[idx] = torch.from_numpy(block).to(self.device)
+            self.ref_len[idx] = torch.tensor([len(self._h_ref[i]) for i in rows], dtype=torch.int32, device=self.device)
+            self.states[idx] = torch.from_numpy(self._h_states[rows]).to(self.device)
+            self.goals[idx] = torch.from_numpy(self._h_goals[rows]).to(self.device)
+            self.last_actions[idx] = 0.0
+            self.idx_ref[idx] = 0
+            self.active[idx] = 1
+            self._init_rows.clear()
 
     def set_dynamic_constraints(self, predictions):
         """``predictions`` [B, K, N, 6] (tensor on this device or array): rows of the first K dynamic-obstacle slots."""

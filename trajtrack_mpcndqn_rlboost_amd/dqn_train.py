@@ -174,6 +174,30 @@ class DqnTrainer:
             self.sync_target()
         return self._g_loss
 
+    def load_optimizer_state(self, sd: Dict) -> None:
+        """Restore Adam's moments and step counts.  Once ``enable_graph`` has captured the update, the graph is bound to the
+        optimiser's state TENSORS: ``Optimizer.load_state_dict`` would replace them with new ones that the replayed graph never
+        sees (the restored moments would be ignored and later checkpoints would save the stale copies), so the loaded values
+        are copied IN PLACE into the tensors the graph updates."""
+        if not hasattr(self, "_graph"):
+            self.optimizer.load_state_dict(sd)
+            return
+        params = [p for g in self.optimizer.param_groups for p in g["params"]]
+        ids = [i for g in sd["param_groups"] for i in g["params"]]
+        if len(ids) != len(params):
+            raise ValueError(f"optimizer checkpoint holds {len(ids)} parameters, this optimizer {len(params)}")
+        with torch.no_grad():
+            for p, i in zip(params, ids):
+                st, src = self.optimizer.state[p], sd["state"].get(i)
+                for k in ("exp_avg", "exp_avg_sq", "step"):
+                    if src is None:
+                        st[k].zero_()
+                    else:
+                        st[k].copy_(torch.as_tensor(src[k]).to(device=st[k].device, dtype=st[k].dtype))
+        for g, gs in zip(self.optimizer.param_groups, sd["param_groups"]):
+            if g["lr"] != gs["lr"]:
+                raise ValueError("the captured graph holds the learning rate it was captured with; checkpoint differs")
+
     def sync_target(self) -> None:
         """Hard target update (SB3 ``polyak_update`` with tau = 1)."""
         self.q_net_target.load_state_dict(self.q_net.state_dict())
@@ -295,7 +319,7 @@ class DqnLearner:
     def load_state_dict(self, d: Dict) -> None:
         tr = self.trainer
         tr.q_net.load_state_dict(d["q_net"]); tr.q_net_target.load_state_dict(d["q_net_target"])
-        tr.optimizer.load_state_dict(d["optimizer"])
+        tr.load_optimizer_state(d["optimizer"])     # in place when the update has been captured into a graph
         tr.num_updates, tr.num_target_syncs = d["num_updates"], d["num_target_syncs"]
         self.num_timesteps, self.n_calls, self.n_updates = d["num_timesteps"], d["n_calls"], d["n_updates"]
         self.gen.set_state(d["generator"].cpu())   # a generator state is a host ByteTensor, also for a device generator
@@ -318,7 +342,8 @@ class DqnLearner:
         torch.save(self.state_dict(include_buffer), path)
 
     def load(self, path: str) -> None:
-        self.load_state_dict(torch.load(path, map_location=self.device, weights_only=False))
+        # tensors, numbers, lists and dicts only (the generator state is a ByteTensor): no pickled code is executed
+        self.load_state_dict(torch.load(path, map_location=self.device, weights_only=True))
 
     def save_model(self, path: str) -> None:
         """The policy alone (the reference's final_model / best_model): the Q-network's weights."""

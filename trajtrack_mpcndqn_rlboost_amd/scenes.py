@@ -44,7 +44,8 @@ def make_batch(cfg: MpcConfig, B: int, n_dyn: int = 8, seed: int = 1234, n_other
                with_box: bool = True, with_walls: bool = True, v_init_range=(0.0, 1.2),
                dyn_clearance: Optional[float] = None, box_clearance: Optional[float] = None,
                on_track: bool = False, n_block=None, block_overlap=(0.1, 0.6), block_first_step: int = 8,
-               box_overlap=None, box_overlap_share: float = 1.0, dyn_weight=1e3) -> Dict[str, np.ndarray]:
+               box_overlap=None, box_overlap_share: float = 1.0, dyn_weight=1e3,
+               out: Optional[np.ndarray] = None) -> Dict[str, np.ndarray]:
     """Returns dict(p=[B, np] float64, start=[B,3], ref=[B,N,3]).
 
     ``v_init_range``: range of the previously applied linear speed (p[6]).  Close to the reference speed
@@ -70,12 +71,18 @@ def make_batch(cfg: MpcConfig, B: int, n_dyn: int = 8, seed: int = 1234, n_other
     ``dyn_weight``: the soft-term weights q_dyn the tracker passes (``set_obstacle_weights(dyn_weights=...)``,
     ``trajectory_generator.py:59,96-113``; default 1e3), a number or (lo, hi) = log-uniform per problem.  With the default
     the soft margin (weight 1e3 on an ellipse 0.2 m wider) keeps the plan OUTSIDE the hard ellipse; with a weight below
-    ~50 the path-deviation cost wins and the plan rests ON the hard ellipse (active constraint, positive multiplier)."""
+    ~50 the path-deviation cost wins and the plan rests ON the hard ellipse (active constraint, positive multiplier).
+    ``out``: a C-contiguous float64 [B, np] array to fill instead of allocating one."""
     N = int(cfg.N_hor)
     off = cfg.offsets()
     assert n_dyn <= cfg.Ndynobs and n_other <= cfg.Nother
     rng = np.random.default_rng(seed)
-    p = np.zeros((B, cfg.num_params))
+    if out is None:
+        p = np.zeros((B, cfg.num_params))
+    else:       # a caller-owned buffer (bench.py: one pinned allocation for every family -- first-touch page faults of a fresh
+        p = out  # 2.8 GB array cost more than generating its content)
+        assert p.shape == (B, cfg.num_params) and p.dtype == np.float64 and p.flags["C_CONTIGUOUS"]
+        p[...] = 0.0
     step = cfg.lin_vel_max * cfg.high_speed * cfg.ts  # 0.24 m
 
     # ---- start pose and reference polyline (straight, one corner)
