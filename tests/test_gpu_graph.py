@@ -93,3 +93,36 @@ def test_broken_axis_promise_is_reported_and_overwrites_every_output():
     torch.cuda.synchronize()
     assert (out["status"].cpu().numpy() != 4).all()
     bs.close()
+
+
+@pytest.mark.parametrize("B", [256, 768])
+def test_small_batches_capture_without_a_reservation(B):
+    """The latency range (up to four problems per compute unit) needs no mpcgpu_reserve_shape to be captured: inside a capture
+    the whole range takes the one-launch form (compaction fused, tables for the configured maxima, nothing read back) -- also
+    above two problems per compute unit, where the eager rule would read the batch's row counts back for its mid-batch form."""
+    cfg = make_cfg(20, solver_max_inner_iterations=60, solver_max_outer_iterations=3)
+    dev = torch.device("cuda", 0)
+    sc = scenes.make_batch(cfg, B, n_dyn=6, seed=15, dyn_clearance=0.1, box_clearance=0.3)
+    p = torch.from_numpy(sc["p"]).to(dev)
+    ref_solver = BatchSolver(cfg)
+    ref = _out(B, 40, dev)
+    ref_solver.solve_device(p, ref, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert ref_solver.last_shape()["latency_kernel"]
+    bs = BatchSolver(cfg)
+    bs.reserve_batch(B)
+    out = _out(B, 40, dev)
+    bs.solve_device(p, out, stream=torch.cuda.current_stream().cuda_stream)     # one eager call: LDS opt-in of the kernel
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        bs.solve_device(p, out, stream=torch.cuda.current_stream().cuda_stream)
+    assert bs.last_shape()["latency_kernel"]
+    for t in out.values():
+        t.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    for k in ("u", "cost", "status", "inner_it", "outer_it", "fpr", "f2norm", "y"):
+        assert torch.equal(out[k], ref[k]), k
+    bs.close(); ref_solver.close()
