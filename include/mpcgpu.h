@@ -153,7 +153,9 @@ int32_t mpcgpu_reserve_shape(void* handle, int32_t max_static, int32_t max_fleet
 
 /* Size the library-owned device buffers (workspace records, counters) for batches of up to B problems now, so that later
  * mpcgpu_solve_batch_dev calls allocate nothing (required before a call is captured into a hipGraph; growth is otherwise
- * automatic and drains the device first). */
+ * automatic and drains the device first).  For a batch of the latency range (up to four problems per compute unit) without a
+ * reservation it also opts the one-launch latency kernel into its LDS size: inside a capture that whole range takes the
+ * one-launch form (tables for the configured maxima, nothing read back). */
 int32_t mpcgpu_reserve_batch(void* handle, int32_t B);
 
 /*

@@ -18,9 +18,7 @@
 #include <stdint.h>
 #include <type_traits>
 
-#ifndef MPC_ITEM_LOOP
-#define MPC_ITEM_LOOP _Pragma("unroll 1")  // item loops: keep the loads of one iteration in flight, not of all
-#endif
+#define MPC_ITEM_LOOP _Pragma("unroll 1")  // item loops: keep the loads of one iteration in flight, not of all (other policies: +-1 %, round 2)
 
 namespace mpcgpu {
 
@@ -48,13 +46,10 @@ struct Prof {
 #define PROF_COUNT(i)
 #endif
 
-// Row sums of the hinge matrix H[i][k] = max(0, inside_ellipse(row i, step k)) (the hard dynamic-obstacle constraint F2):
-// 1 = every item lane adds its positive terms to D_i in LDS (ds_add_f64: the lanes of one instruction are served in a fixed
-// order, so the sum is deterministic and the same in every kernel that runs this code); 0 = rounds 1-2: the matrix is stored
-// (Kd x N doubles of LDS) and lane i sums its row in a serial loop.
-#ifndef MPC_H_ATOMIC
-#define MPC_H_ATOMIC 1
-#endif
+// Row sums of the hinge matrix H[i][k] = max(0, inside_ellipse(row i, step k)) (the hard dynamic-obstacle constraint F2): every
+// item lane adds its positive terms to D_i in LDS (ds_add_f64: the lanes of one instruction are served in a fixed order, so the
+// sum is deterministic and the same in every kernel that runs this code).  Rounds 1-2 stored the matrix (Kd x N doubles of LDS)
+// and lane i summed its row in a serial loop.
 __device__ __forceinline__ void lds_add(double* p, double v) {
     __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)p, v);
 }
@@ -76,16 +71,7 @@ constexpr int MAX_MEM = 16;
 // (the 6 nearest segments of a step at N_hor = 20; the pruned loop then ran in 0.1 % of the evaluations).  1 = the 3 nearest:
 // the pruned loop runs in 2.2 % of the evaluations and one unconditional trip per evaluation is gone: -3.0 % kernel time at
 // N_hor = 20, -1.6 % at N_hor = 40, same bits (the same segments win in the same order; profiles/r03_step_loop_ab.txt).
-#ifndef MPC_STASH_DIET
-#define MPC_STASH_DIET 1
-#endif
-#ifndef MPC_HMASK
-#define MPC_HMASK 1
-#endif
-#ifndef MPC_SEG_WIN
-#define MPC_SEG_WIN 1
-#endif
-constexpr int SEG_WIN = MPC_SEG_WIN;
+constexpr int SEG_WIN = 1;
 
 // header slots (doubles); 0..17 are p[0..17] of the reference layout
 enum { H_X0 = 0, H_Y0 = 1, H_TH0 = 2, H_XG = 3, H_YG = 4, H_THG = 5, H_VINIT = 6, H_WINIT = 7, H_QVEL = 9, H_RV = 11, H_RW = 12,
@@ -133,10 +119,8 @@ struct KParams {
 // ------------------------------------------------------------------------------------------------
 struct FixedLds { int hd, seg, pos, stash, part, W, rho, gg, S, Y, old, end; };
 __host__ __device__ constexpr int even_c(int x) { return (x + 1) & ~1; }
-#ifndef MPC_GRAM40
-#define MPC_GRAM40 1   // the Gram form at N_hor = 40 as well (with the stash-free 168-register kernel: see stash_stride_c)
-#endif
-__host__ __device__ constexpr bool gram_shape(int N, int mem) { return MPC_LBFGS_GRAM && (N == 20 || (MPC_GRAM40 && N == 40)) && mem == 10; }
+// (N_hor = 40 as well since the stash-free 168-register kernel: see stash_stride_c)
+__host__ __device__ constexpr bool gram_shape(int N, int mem) { return MPC_LBFGS_GRAM && (N == 20 || N == 40) && mem == 10; }
 // Item-lane partials (eval_point): every item lane beyond the vector lanes parks PARTW = 5 doubles.  With a compiled horizon that
 // nearly divides the wavefront (N_hor = 20: 60 item lanes) the split is uniform and the last lanes idle -- the rule of eval_point.
 __host__ __device__ constexpr int part_doubles_c(int N, int mem) {
@@ -156,7 +140,7 @@ __host__ __device__ constexpr int part_doubles_c(int N, int mem) {
 // With the Gram form at N_hor = 40 (its matrices: 1240 B) the four Simpson values stay in registers as well (stride 0): 11 200 B
 // + 1160 B = 12 360 B, still 12 per CU.
 __host__ __device__ constexpr int stash_stride_c(int N, int mem) {
-    return (MPC_STASH_DIET && N == 40 && mem == 10) ? (gram_shape(N, mem) ? 0 : 4) : 6;
+    return (N == 40 && mem == 10) ? (gram_shape(N, mem) ? 0 : 4) : 6;
 }
 __host__ __device__ constexpr int stash_doubles_c(int N, int mem) {
     int need = N * stash_stride_c(N, mem);
@@ -173,7 +157,6 @@ __host__ __device__ constexpr int stash_doubles_c(int N, int mem) {
     }
     return need;
 }
-static_assert(MPC_H_ATOMIC, "the fixed LDS carve reserves room for the hinge ROW SUMS only (the stored hinge matrix of rounds 1-2 is gone)");
 constexpr int HW_ROWS = 32;   // doubles reserved for the hinge row sums D_i; the weights W_i follow at this offset (Ndynobs <= 32)
 __host__ __device__ constexpr FixedLds fixed_lds(int N, int mem, bool lbfgs_in_lds) {
     FixedLds f{};
@@ -281,28 +264,11 @@ __device__ __forceinline__ double row_suffix(double x) {
 // Row totals are chained with row_bcast15 / row_bcast31 (2 DPP moves + 1 add each; rows without a source read 0 through
 // bound_ctrl, their lanes are not used) and the total is read from the last lane: 17 / 20 VALU instructions for 2 / 4 rows
 // instead of 20 / 27 with one v_readlane pair per row.
-// EXPERIMENT (MPC_MFMA_SUM = 1, off in the product): the same totals on the matrix pipe.  v_mfma_f64_4x4x4 (4 blocks) with a
-// matrix of ones as second operand adds, for every lane position of a row, the four rows; a second one adds the four lanes of
-// every quad (operand layout measured with tools/probes/mfma_f64_layout.hip: A[b][i][k] in lane 16k + 4b + i, B[b][k][j] in
-// lane 16k + 4b + j, D[b][i][j] in lane 16i + 4b + j); two DPP steps add the four quads: lanes 12..15 of every row hold the
-// total of all 64 lanes.  2 MFMA + 6 VALU + 2 v_readlane instead of 17-20 VALU -- but a DIFFERENT summation order, i.e.
-// different rounding of every inner product: results are no longer bitwise those of the DPP build.  Measured on the
-// issue-bound step-loop kernel (round 3, profiles/r03_step_loop_ab.txt): 1.63 instead of 1.60 ms per 10^6 evaluations at
-// N_hor = 20 (+1.5 %), -1 % at N_hor = 40, same status histograms and iteration counts: an f64 MFMA holds the issue port
-// for its four passes, two of them cost what the DPP steps they replace cost.  Not used.
-#ifndef MPC_MFMA_SUM
-#define MPC_MFMA_SUM 0
-#endif
-__device__ __forceinline__ double mfma_allsum(double x) {  // every lane outside the summed set must carry 0
-    const double d1 = __builtin_amdgcn_mfma_f64_4x4x4f64(x, 1.0, 0.0, 0, 0, 0);
-    double d2 = __builtin_amdgcn_mfma_f64_4x4x4f64(1.0, d1, 0.0, 0, 0, 0);
-    d2 += dpp0<DPP_ROW_SHR0 + 4>(d2);
-    d2 += dpp0<DPP_ROW_SHR0 + 8>(d2);
-    return d2;
-}
+// (The same totals on the matrix pipe -- two v_mfma_f64_4x4x4 with matrices of ones + two DPP steps -- were measured in rounds 1
+// and 3: no gain on the chain-bound kernel, +1.5 % time on the issue-bound one: an f64 MFMA holds the issue port for its four
+// passes.  DESIGN.md section 7; the experiment's code is in the history, commit 802f579.)
 template <int ROWS>
 __device__ __forceinline__ double wave_sum_u(double x) {
-    if (MPC_MFMA_SUM) return readlane_d(mfma_allsum(x), 15);
     x = row_prefix(x);  // lane 15 of each row = row total
     if (ROWS == 1) return readlane_d(x, 15);
     if (ROWS == 3) {    // rows 1 and 3 only, then rows 2-3: lane 47 = r2 + (r1 + r0)
@@ -317,7 +283,6 @@ __device__ __forceinline__ double wave_sum_u(double x) {
 // two sums over lanes 0..31 for the price of one: b travels in rows 2-3 (v_permlane32_swap), one DPP sequence serves both.
 // Bitwise the same totals as wave_sum_u<2>(a), wave_sum_u<2>(b).
 __device__ __forceinline__ void wave_sum2_u(double a, double b, double& sa, double& sb) {
-    if (MPC_MFMA_SUM) { sa = readlane_d(mfma_allsum(a), 15); sb = readlane_d(mfma_allsum(b), 15); return; }
     const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
     const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
     double x = __hiloint2double((int)hi[0], (int)lo[0]);  // lanes 0..31: a, lanes 32..63: b (lanes 0..31 of it)
@@ -864,9 +829,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     P::template prefix2<RV>(ts * v * Cx, ts * v * Sy, pX, pY);
     const double X = HD(H_X0) + pX;
     const double Y = HD(H_Y0) + pY;
-#if MPC_H_ATOMIC
     if (lane < cx.Kd) cx.H[lane] = zero_here();   // row sums of the hard-constraint hinges, accumulated by the item lanes below
-#endif
     if (c_vl) {
         cx.pos[2 * lane] = X; cx.pos[2 * lane + 1] = Y;
         // rollout quantities needed again only after the item phase (per-step terms, adjoint): parked in LDS so
@@ -892,7 +855,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     // the steps of the second half of the horizon have ONE item lane each and a trip is a single row (N_hor = 40: -1.5 % kernel
     // time); with three lanes per step (N_hor = 20: three trips of three rows) the ballots cost what the skipped trips save
     // (+1 %, measured) and the rows are walked as in rounds 1-3.
-    constexpr bool HM = MPC_HMASK && !UNIFORM;
+    constexpr bool HM = !UNIFORM;
     unsigned hmask = 0u;
     const int minLPS = UNIFORM ? PW / N : (PW - N) / N + 1;
     const int ntrip = HM ? (cx.Kd + minLPS - 1) / minLPS : 0;
@@ -1000,11 +963,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
                 const double Ih = 1.0 - a2 * d.ihx - b2 * d.ihy;
                 inside = Ih > 0.0;
                 anyh |= inside;
-#if MPC_H_ATOMIC
                 if (Ih > 0.0) lds_add(cx.H + i, Ih);      // D_i = sum_k max(0, Ih(i, k)): accumulated where the terms arise
-#else
-                cx.H[i * N + k] = Ih > 0.0 ? Ih : 0.0;
-#endif
                 const double Is = 1.0 - a2 * d.isx - b2 * d.isy;
                 if (Is > 0.0) {
                     cost_l += d.wgt * Is * Is;
@@ -1050,12 +1009,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     double F2e = 0.0;
     if (lane < cx.Kd) {
         double D = 0.0;
-#if MPC_H_ATOMIC
         if (any_h) D = cx.H[lane];
-#else
-        if (any_h)
-            for (int k = 0; k < N; ++k) D += cx.H[lane * N + k];
-#endif
         F2e = S + D;
     }
     const double F2pad = cx.pad_d ? S + (any_hp ? P::template sum<RV>(hp) : 0.0) : 0.0;
@@ -1507,18 +1461,9 @@ struct PanocLbfgs {
 // loop: y_p.z needs s_q of the older pairs).  The others -- and the diagonal, which only enters through rho -- are stored as
 // ZERO, so a row's running product stops changing by itself once its turn has passed: no per-step masking or latching.
 // Exact-arithmetic identical to the two-loop recursion; measured against it over whole solves: 5e-12 relative (oracle, mode 2).
-#ifndef MPC_LB_SCHED
-#define MPC_LB_SCHED 2  // pass 1: the scheduler may not pull the LDS operands of more than this many pairs ahead (registers)
-#endif
-#ifndef MPC_LB_BLOCK
-#define MPC_LB_BLOCK 8
-#endif
-#ifndef MPC_LB_PREFETCH1
-#define MPC_LB_PREFETCH1 1  // pass 1: request the rows before the new pair is formed
-#endif
-#ifndef MPC_LB_PREFETCH2
-#define MPC_LB_PREFETCH2 1  // pass 2: request the rows before the recurrences
-#endif
+constexpr int LB_SCHED = 2;   // pass 1: the scheduler may not pull the LDS operands of more than this many pairs ahead (registers)
+constexpr int LB_BLOCK = 8;   // pass 1: rows held in registers at a time
+// (both passes request their rows before anything that depends on the new pair / the recurrences: measured in round 3)
 struct PanocLbfgsGram {
     int active = 0, head = 0;
     bool first = true;
@@ -1568,8 +1513,8 @@ struct PanocLbfgsGram {
         const int row_a = ro.isy * mem + ro.slot_a;
         const double2* mrow = reinterpret_cast<const double2*>(m.LM + (row_a * N + ro.g * D.CL) * 2);
         constexpr int GT = MEMT ? (WAVE / 2) / (MEMT ? MEMT : 1) : 1;
-        constexpr int CLT = (NT && MEMT && MPC_LB_PREFETCH1) ? (NT + GT - 1) / GT : 0;   // pairs per lane (compile-time shape)
-        constexpr int BL = CLT <= MPC_LB_BLOCK ? CLT : (CLT + 1) / 2;   // held in registers at a time (else two blocks)
+        constexpr int CLT = (NT && MEMT) ? (NT + GT - 1) / GT : 0;   // pairs per lane (compile-time shape)
+        constexpr int BL = CLT <= LB_BLOCK ? CLT : (CLT + 1) / 2;   // held in registers at a time (else two blocks)
         double2 mq[BL ? BL : 1];
         if (CLT) {
 #pragma unroll
@@ -1599,7 +1544,7 @@ struct PanocLbfgsGram {
 #pragma unroll
             for (int t = 0; t < BL; ++t) {
                 mac(mq[t], ro.g * CLT + t);
-                if (MPC_LB_SCHED && (t % MPC_LB_SCHED) == MPC_LB_SCHED - 1) __builtin_amdgcn_sched_barrier(0);
+                if ((t % LB_SCHED) == LB_SCHED - 1) __builtin_amdgcn_sched_barrier(0);
             }
             if (BL < CLT) {
 #pragma unroll
@@ -1663,7 +1608,7 @@ struct PanocLbfgsGram {
         // nothing computed here, so with a compile-time shape they are requested before the recurrences
         const int g2 = lane / N, k2 = lane - g2 * N;
         const int g2a = g2 < D.G2 ? g2 : D.G2 - 1;
-        constexpr int CRT0 = (NT && MEMT && MPC_LB_PREFETCH2) ? (2 * MEMT + WAVE / (NT ? NT : 1) - 1) / (WAVE / (NT ? NT : 1)) : 0;
+        constexpr int CRT0 = (NT && MEMT) ? (2 * MEMT + WAVE / (NT ? NT : 1) - 1) / (WAVE / (NT ? NT : 1)) : 0;
         constexpr int CRT = CRT0 <= 8 ? CRT0 : 0;  // long horizons: one lane group takes all rows, too many to hold in registers
         {   // zero materialised here: hoisted out of the solver loop it would sit in a spill slot, and its reload would wait for
             // the row loads below (scratch and global loads share one counter)

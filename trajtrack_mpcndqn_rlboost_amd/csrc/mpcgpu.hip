@@ -232,7 +232,7 @@ void fill_team_layout(KParams& k, int tw, int mKs, int mKf, int mKd) {
     const int base = o;
     k.l_pos = o; o += N * 2;
     k.l_stash = o; o += stash_doubles(k);
-    const int h_rows = MPC_H_ATOMIC ? even(k.mKd) : even(k.mKd * N);
+    const int h_rows = even(k.mKd);
     const int h_sz = h_rows + even(k.mKd), part_sz = part_doubles(k);
     k.l_H = o; k.l_W = o + h_rows; k.l_part = o;
     o += h_sz > part_sz ? h_sz : part_sz;
@@ -881,6 +881,20 @@ int32_t mpcgpu_reserve_batch(void* handle, int32_t B) {
     if (int r = ensure(h, h->evals, (size_t)B * 2 * sizeof(int32_t))) return r;
     if (int r = ensure(h, h->perm, (size_t)B * sizeof(int32_t))) return r;
     if (int r = ensure(h, h->bins, ORD_BINS * sizeof(int))) return r;
+    // A batch of the latency range is captured in its one-launch form (tables for the configured maxima: more than 64 KiB of
+    // dynamic LDS for the yaml's slot counts), whatever form an eager call of the same size takes: opt that kernel in now.
+    const int team_cap = h->team_max_batch >= 0 ? h->team_max_batch : 4 * h->num_cus;
+    if (B <= team_cap && !use_duo(h) && !h->reserved) {
+        KParams kt = h->kp;
+        fill_team_layout(kt, TEAM_WAVES, h->cfg.Nstcobs, h->cfg.Nother, h->cfg.Ndynobs);
+        const size_t lds_t = kt.l_total * sizeof(double);
+        if (lds_t + 256 <= 160 * 1024) {
+            const void* kern = compiled_horizon(h) == 20 ? (const void*)solve_kernel_team<20, TEAM_WAVES>
+                             : compiled_horizon(h) == 40 ? (const void*)solve_kernel_team<40, TEAM_WAVES>
+                                                         : (const void*)solve_kernel_team<0, TEAM_WAVES>;
+            if (int r = opt_in_lds(h, kern, lds_t)) return r;
+        }
+    }
     return 0;
 }
 
