@@ -65,6 +65,7 @@ constexpr int DYNW = 9;        // workspace record per (dyn row, step): cx, cy, 
 constexpr int DYNP = 2;        // shape-constant LDS record per (row, step): cx, cy
 constexpr int DYNC = 7;        // shape-constant LDS record per row: cosA, sinA, ihx, ihy, isx, isy, alpha
                                // (the item weight q_dyn[k] * alpha is formed where it is used: q_dyn is one value per step)
+constexpr int DYNL = 4;        // linear centre tables: per row x0, y0, dx, dy (centre of step k = fma(d, k, c0) + residual)
 constexpr int PARTW = 5;       // doubles per item-lane partial  (gx, gy, best, bgx, bgy)
 constexpr int MAX_MEM = 16;
 // Reference segments per item lane that are evaluated unconditionally before the suffix-circle test takes over.  Rounds 1-3: 2
@@ -77,10 +78,11 @@ constexpr int SEG_WIN = 1;
 enum { H_X0 = 0, H_Y0 = 1, H_TH0 = 2, H_XG = 3, H_YG = 4, H_THG = 5, H_VINIT = 6, H_WINIT = 7, H_QVEL = 9, H_RV = 11, H_RW = 12,
        H_QN = 13, H_QTHN = 14, H_QRPD = 15, H_ACC = 16, H_WACC = 17 };
 enum { H_KS = 18, H_KF = 19, H_KD = 20, H_CTH0 = 21, H_STH0 = 22, H_NPF = 23, H_NPD = 24, H_VAR = 25 /* 1: some dynamic row changes shape over the horizon */,
-       H_ENTRY = 26 /* .. +Ndynobs (<= 32) */, H_ROT = 60 /* 1: some active dynamic row is rotated (angle != 0) */ };
+       H_ENTRY = 26 /* .. +Ndynobs (<= 32) */, H_ROT = 60 /* 1: some active dynamic row is rotated (angle != 0) */,
+       H_NLIN = 61 /* 1: some active dynamic row does not move on a straight line (see LINEAR CENTRE TABLES) */ };
 // batch-wide reductions written by the compaction kernel
 enum { CNT_KS = 0, CNT_KF = 1, CNT_KD = 2, CNT_VARSHAPE = 3, CNT_ROTATED = 4 /* some active dynamic row is not an axis-aligned ellipse (angle != 0) */,
-       CNT_WORDS = 8 };
+       CNT_NONLINEAR = 5 /* some active dynamic row is not a straight-line prediction */, CNT_WORDS = 8 };
 
 struct KParams {
     int N, Nother, Nstcobs, Ndynobs, np, mem;
@@ -94,11 +96,11 @@ struct KParams {
     // parameter-vector offsets (mpc_generator.py:179-188)
     int r0, c0, os0, od0, qs0, qd0;
     // workspace (global) layout per problem, doubles
-    int ws_stride, ws_vref, ws_seg, ws_stc, ws_fxy, ws_dyn, ws_qd, ws_alpha, ws_lbs, ws_lby, ws_lold;
+    int ws_stride, ws_vref, ws_seg, ws_stc, ws_fxy, ws_dyn, ws_qd, ws_alpha, ws_dynl, ws_dynr, ws_lbs, ws_lby, ws_lold;
     // LDS layout (doubles), strides use the batch maxima mKs/mKf/mKd
     int mKs, mKf, mKd;
     int reserved;  // 1: the carve comes from mpcgpu_reserve_shape, problems are checked against it on the device
-    int l_seg, l_stc, l_fxy, l_dyn, l_dync, l_qd, l_pos, l_H, l_W, l_part, l_stash, l_hd, l_S, l_Y, l_rho, l_alpha, l_old, l_gg, l_total;
+    int l_seg, l_stc, l_fxy, l_dyn, l_dync, l_dynl, l_qd, l_pos, l_H, l_W, l_part, l_stash, l_hd, l_S, l_Y, l_rho, l_alpha, l_old, l_gg, l_total;
     int l_wstride, l_xch;  // team kernel (mpc_team.hpp): doubles per wavefront work block, offset of the exchange area
 };
 
@@ -139,11 +141,13 @@ __host__ __device__ constexpr int part_doubles_c(int N, int mem) {
 // segment records (320 B) the N_hor = 40 carve is 12 480 B.
 // With the Gram form at N_hor = 40 (its matrices: 1240 B) the four Simpson values stay in registers as well (stride 0): 11 200 B
 // + 1160 B = 12 360 B, still 12 per CU.
-__host__ __device__ constexpr int stash_stride_c(int N, int mem) {
-    return (N == 40 && mem == 10) ? (gram_shape(N, mem) ? 0 : 4) : 6;
+// `minw`: wavefronts per SIMD the kernel is compiled for.  The 128-register build of the long horizon (minw = 4, round 4) has no
+// registers to carry anything through the item phase: it parks all six values like the short horizon does.
+__host__ __device__ constexpr int stash_stride_c(int N, int mem, int minw = 3) {
+    return (N == 40 && mem == 10 && minw < 4) ? (gram_shape(N, mem) ? 0 : 4) : 6;
 }
-__host__ __device__ constexpr int stash_doubles_c(int N, int mem) {
-    int need = N * stash_stride_c(N, mem);
+__host__ __device__ constexpr int stash_doubles_c(int N, int mem, int minw = 3) {
+    int need = N * stash_stride_c(N, mem, minw);
     if (gram_shape(N, mem)) {
         const int R = 2 * mem, G = 32 / mem, CL = (N + G - 1) / G, G2 = 64 / N, CR = (R + G2 - 1) / G2;
         int scratch = even_c(G * CL * 4) + even_c(G2 * CR);      // pass-1 operands (r, y) + row coefficients
@@ -152,19 +156,19 @@ __host__ __device__ constexpr int stash_doubles_c(int N, int mem) {
         // the scratch starts at the positions and runs through the stash into the region of the item partials / hinge sums
         // that follows it: all three are dead between two evaluations
         const int after = part_doubles_c(N, mem) > 2 * 32 ? part_doubles_c(N, mem) : 2 * 32;
-        const int room = N * 2 + (stash_stride_c(N, mem) == 0 ? after : 0);
+        const int room = N * 2 + (stash_stride_c(N, mem, minw) == 0 ? after : 0);
         if (scratch - room > need) need = scratch - room;
     }
     return need;
 }
 constexpr int HW_ROWS = 32;   // doubles reserved for the hinge row sums D_i; the weights W_i follow at this offset (Ndynobs <= 32)
-__host__ __device__ constexpr FixedLds fixed_lds(int N, int mem, bool lbfgs_in_lds) {
+__host__ __device__ constexpr FixedLds fixed_lds(int N, int mem, bool lbfgs_in_lds, int minw = 3) {
     FixedLds f{};
     int o = 0;
     f.hd = o; o += 64;
     f.seg = o; o += even_c(N * 9);
     f.pos = o; o += N * 2;
-    f.stash = o; o += stash_doubles_c(N, mem);
+    f.stash = o; o += stash_doubles_c(N, mem, minw);
     // hinge row sums + weights and the item-lane partials are never live together (LDS operations of one wavefront execute in
     // order): one region
     f.part = o; f.W = o + HW_ROWS;
@@ -593,7 +597,7 @@ __device__ __forceinline__ void prep_problem(const KParams& kp, const Src& p, do
     }
     // ---- dynamic obstacles: lane i checks row i
     int Kd;
-    bool varshape = false, rotated = false;
+    bool varshape = false, rotated = false, nonlinear = false;
     __shared__ int s_entry[WAVE];  // original row -> entry (or -1 for padded rows)
     {
         bool nz = false;
@@ -631,18 +635,42 @@ __device__ __forceinline__ void prep_problem(const KParams& kp, const Src& p, do
             d[7] = 1.0 / ((ry + kp.social + 1e-6) * (ry + kp.social + 1e-6));
             d[8] = p[kp.qd0 + k] * p[q0 + 5];  // q_dyn[k] * alpha
             if (k == 0) ws[kp.ws_alpha + e] = p[q0 + 5];
+            // LINEAR CENTRE TABLES (round 4).  A constant-velocity prediction (est_dyn_obs_positions, src/main.py:77-85) puts the
+            // centres of a row on a straight line up to rounding.  With c0 = the first centre and d = (last - first) / (N - 1) the
+            // predictor lin_k = fma(d, k, c0) misses the stored centre by a few ulps; that residual is an exactly representable
+            // bfloat16 (<= 8 significant bits, exponent in range), and lin_k + residual gives the stored double back EXACTLY (the
+            // exact sum is a double).  Per row 4 doubles + 4 bytes per step instead of 16 bytes per step: 5.0 -> 0.9 KB of LDS at
+            // N_hor = 40 with 8 rows -- lossless; a row that does not fit (scanner predictions, curved paths) flags the problem and
+            // the batch keeps the stored centres.
+            {
+                const int qr = kp.od0 + i * 6 * N, ql = qr + 6 * (N - 1);
+                const double x0 = p[qr], y0 = p[qr + 1];
+                const double inv = 1.0 / (double)(N - 1);
+                const double dxl = (p[ql] - x0) * inv, dyl = (p[ql + 1] - y0) * inv;
+                const double lx = __builtin_fma(dxl, (double)k, x0), ly = __builtin_fma(dyl, (double)k, y0);
+                const double rx_ = p[q0] - lx, ry_ = p[q0 + 1] - ly;
+                const float fx = (float)rx_, fy = (float)ry_;
+                const unsigned bx = __float_as_uint(fx), by = __float_as_uint(fy);
+                const bool fits = (double)fx == rx_ && (double)fy == ry_ && !(bx & 0xFFFFu) && !(by & 0xFFFFu) &&
+                                  lx + (double)fx == p[q0] && ly + (double)fy == p[q0 + 1];
+                nonlinear |= !fits;
+                reinterpret_cast<unsigned*>(ws + kp.ws_dynr)[e * N + k] = (bx >> 16) | (by & 0xFFFF0000u);
+                if (k == 0) { double* L = ws + kp.ws_dynl + e * DYNL; L[0] = x0; L[1] = y0; L[2] = dxl; L[3] = dyl; }
+            }
         }
     }
-    const bool any_var = __ballot(varshape) != 0ull, any_rot = __ballot(rotated) != 0ull;
+    const bool any_var = __ballot(varshape) != 0ull, any_rot = __ballot(rotated) != 0ull, any_nonlin = __ballot(nonlinear) != 0ull;
     if (lane == 0) {
         ws[H_KS] = (double)Ks; ws[H_KF] = (double)Kf; ws[H_KD] = (double)Kd; ws[H_VAR] = any_var ? 1.0 : 0.0;
         ws[H_ROT] = any_rot ? 1.0 : 0.0;
+        ws[H_NLIN] = any_nonlin ? 1.0 : 0.0;
         if (counts) {
             atomicMax(counts + CNT_KS, Ks);
             atomicMax(counts + CNT_KF, Kf);
             atomicMax(counts + CNT_KD, Kd);
             if (any_var) atomicMax(counts + CNT_VARSHAPE, 1);
             if (any_rot) atomicMax(counts + CNT_ROTATED, 1);
+            if (any_nonlin) atomicMax(counts + CNT_NONLINEAR, 1);
         }
     }
 }
@@ -668,6 +696,8 @@ struct Ctx {
     double vref;  // vector lane k: speed reference of step k
     // LDS tables
     double *seg, *stc, *fxy, *dyn, *dync, *pos, *H, *W, *part, *stash;
+    const double* dynl;        // linear centre tables: [Kd][DYNL]
+    const unsigned* dynr;      // ... and the residuals of every (row, step): bfloat16 x in the low half, y in the high half
 };
 constexpr int KC_BASE = 32;
 #define KC(i) (cx.hd[KC_BASE + (i)])
@@ -681,9 +711,10 @@ struct EvalOut {
     double F2e, F2pad;      // lane i < Kd: F2 of dynamic entry i; uniform: F2 of every padded row
 };
 
-template <int NT, bool SC, class P>
+template <int NT, bool SC, class P, bool LIN = false, int MINW = 3>
 __device__ __forceinline__ void load_problem(const KParams& kp, const double* __restrict__ ws, double* lds,
                                              Ctx& cx) {
+    static_assert(!LIN || SC, "linear centre tables belong to the shape-constant form");
     const int lane = P::lane();  // lane inside the problem; `lds` is this problem's carve
     const int N = NT ? NT : kp.N;
     cx.lane = lane;
@@ -693,7 +724,7 @@ __device__ __forceinline__ void load_problem(const KParams& kp, const double* __
     cx.isub = lane / N;
     // compiled horizon, one problem per wavefront: the fixed part of the carve sits at compile-time offsets (fixed_lds)
     constexpr bool FIXED = NT != 0 && !P::DUO;
-    constexpr FixedLds FL = fixed_lds(NT ? NT : 2, MemOf<NT>::value ? MemOf<NT>::value : 1, false);  // fields up to `gg` do not depend on where S, Y live
+    constexpr FixedLds FL = fixed_lds(NT ? NT : 2, MemOf<NT>::value ? MemOf<NT>::value : 1, false, MINW);  // fields up to `gg` do not depend on where S, Y live
     double* hd = lds + (FIXED ? FL.hd : kp.l_hd);
     if (lane < KC_BASE) hd[lane] = ws[lane];
     if (lane < 27) hd[KC_BASE + lane] = KTAB[lane];
@@ -705,6 +736,7 @@ __device__ __forceinline__ void load_problem(const KParams& kp, const double* __
     cx.vref = cx.vl ? ws[kp.ws_vref + lane] : 0.0;
     cx.stc = lds + kp.l_stc; cx.fxy = lds + kp.l_fxy;
     cx.dyn = lds + kp.l_dyn; cx.dync = lds + kp.l_dync;
+    cx.dynl = lds + kp.l_dynl; cx.dynr = reinterpret_cast<const unsigned*>(lds + kp.l_dyn);   // LIN: the residuals take the place of the centres
     if (FIXED) {
         cx.seg = lds + FL.seg; cx.pos = lds + FL.pos; cx.stash = lds + FL.stash; cx.H = lds + FL.part; cx.W = lds + FL.W; cx.part = lds + FL.part;
     } else {
@@ -720,9 +752,15 @@ __device__ __forceinline__ void load_problem(const KParams& kp, const double* __
             const int r = i / DYNC, f = i - r * DYNC;
             cx.dync[i] = f < 6 ? ws[kp.ws_dyn + (r * N) * DYNW + 2 + f] : ws[kp.ws_alpha + r];
         }
-        for (int i = lane; i < cx.Kd * N; i += P::W) {
-            const double* d = ws + kp.ws_dyn + i * DYNW;
-            cx.dyn[i * DYNP] = d[0]; cx.dyn[i * DYNP + 1] = d[1];
+        if (LIN) {
+            for (int i = lane; i < cx.Kd * DYNL; i += P::W) (lds + kp.l_dynl)[i] = ws[kp.ws_dynl + i];
+            for (int i = lane; i < cx.Kd * N; i += P::W)
+                reinterpret_cast<unsigned*>(lds + kp.l_dyn)[i] = reinterpret_cast<const unsigned*>(ws + kp.ws_dynr)[i];
+        } else {
+            for (int i = lane; i < cx.Kd * N; i += P::W) {
+                const double* d = ws + kp.ws_dyn + i * DYNW;
+                cx.dyn[i * DYNP] = d[0]; cx.dyn[i * DYNP + 1] = d[1];
+            }
         }
         // q_dyn of step i: the pad double of segment record i (after the copy of the records above: LDS writes keep their order)
         for (int i = lane; i < N; i += P::W) cx.seg[SEGW * i + 8] = ws[kp.ws_qd + i];
@@ -739,14 +777,24 @@ struct DynItem {
 // AXIS: every active dynamic row of the batch is an axis-aligned ellipse (angle 0, i.e. cos = 1 and sin = 0 exactly -- what the
 // reference's own prediction feeder produces, src/main.py:77-85): the rotation into the ellipse frame is the identity up to the
 // sign of b.  The general expressions give a = ex and b = -ey EXACTLY in that case (x*1 + y*0), so skipping them changes no bit.
-template <bool SC, bool AXIS = false>
+template <bool SC, bool AXIS = false, bool LIN = false>
 __device__ __forceinline__ DynItem dyn_item(const Ctx& cx, int i, int k, int N, double px, double py) {
     DynItem d;
     double ex, ey;
     if (SC) {
-        const double* e = cx.dyn + (i * N + k) * DYNP;
         const double* s = cx.dync + i * DYNC;
-        ex = px - e[0]; ey = py - e[1]; d.wgt = cx.seg[SEGW * k + 8] * s[6];  // q_dyn[k] * alpha: the same product prep_kernel forms for the general table
+        if (LIN) {   // centre = predictor + bfloat16 residual: bitwise the stored centre (prep_problem)
+            const double* L = cx.dynl + i * DYNL;
+            const unsigned r = cx.dynr[i * N + k];
+            const double kk = (double)k;
+            const double ecx = __builtin_fma(L[2], kk, L[0]) + (double)__uint_as_float(r << 16);
+            const double ecy = __builtin_fma(L[3], kk, L[1]) + (double)__uint_as_float(r & 0xFFFF0000u);
+            ex = px - ecx; ey = py - ecy;
+        } else {
+            const double* e = cx.dyn + (i * N + k) * DYNP;
+            ex = px - e[0]; ey = py - e[1];
+        }
+        d.wgt = cx.seg[SEGW * k + 8] * s[6];  // q_dyn[k] * alpha: the same product prep_kernel forms for the general table
         d.ca = s[0]; d.sa = s[1]; d.ihx = s[2]; d.ihy = s[3]; d.isx = s[4]; d.isy = s[5];
     } else {
         const double* e = cx.dyn + (i * N + k) * DYNW;
@@ -764,7 +812,7 @@ __device__ __forceinline__ DynItem dyn_item(const Ctx& cx, int i, int k, int N, 
 // ------------------------------------------------------------------------------------------------
 // psi(u; c, y), f(u), F1, F2 and (optionally) grad psi at the point held by the vector lanes.
 // ------------------------------------------------------------------------------------------------
-template <int NT, bool SC, class P, bool AXIS = false>
+template <int NT, bool SC, class P, bool AXIS = false, bool LIN = false, int MINW = 3>
 __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, double v, double w, double c, double icm,
                                            double ya, double yb, bool want_grad, bool want_f, EvalOut& out PROF_ARG) {
     const int N = NT ? NT : kp.N;
@@ -781,7 +829,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     const int c_ik = lane % N, c_isub = lane / N;
     const int LPS = UNIFORM ? PW / N : (PW - 1 - c_ik) / N + 1;
     constexpr int RV = P::RV, RI = P::RI;
-    const int STW = NT ? stash_stride_c(NT, MemOf<NT>::value) : stash_stride_c(kp.N, kp.mem);   // stash doubles per step
+    const int STW = NT ? stash_stride_c(NT, MemOf<NT>::value, MINW) : stash_stride_c(kp.N, kp.mem);   // stash doubles per step
     const double ts = here_s(kp.ts);
     const double fleetw = here_s(kp.fleetw);
     const double inf = __builtin_huge_val();
@@ -958,7 +1006,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         for (int t = 0, i = c_isub; HM ? t < ntrip : i < cx.Kd; ++t, i += LPS) {
             bool inside = false;
             if (!HM || i < cx.Kd) {
-                const DynItem d = dyn_item<SC, AXIS>(cx, i, k, N, px, py);
+                const DynItem d = dyn_item<SC, AXIS, LIN>(cx, i, k, N, px, py);
                 const double a2 = d.a * d.a, b2 = d.b * d.b;
                 const double Ih = 1.0 - a2 * d.ihx - b2 * d.ihy;
                 inside = Ih > 0.0;
@@ -1032,7 +1080,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
                 MPC_ITEM_LOOP
                 for (int t = 0, i = c_isub; HM ? t < ntrip : i < cx.Kd; ++t, i += LPS) {
                     if (HM && (!((hmask >> t) & 1u) || i >= cx.Kd)) continue;   // no lane of this trip is inside a hard ellipse
-                    const DynItem d = dyn_item<SC, AXIS>(cx, i, k, N, px, py);
+                    const DynItem d = dyn_item<SC, AXIS, LIN>(cx, i, k, N, px, py);
                     const double Ih = 1.0 - d.a * d.a * d.ihx - d.b * d.b * d.ihy;
                     if (Ih > 0.0) {
                         const double wi = cx.W[i];
@@ -1153,7 +1201,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
 // ------------------------------------------------------------------------------------------------
 // test-hook kernel: one evaluation per problem through eval_point
 // ------------------------------------------------------------------------------------------------
-template <int NT, bool SC, class P, bool AXIS = false>
+template <int NT, bool SC, class P, bool AXIS = false, bool LIN = false>
 __global__ __launch_bounds__(WAVE) void cost_grad_kernel(KParams kp, BatchPtrs io, const double* __restrict__ u,
                                                          const double* __restrict__ xi, double* psi, double* f,
                                                          double* grad, double* F1, double* F2, int B) {
@@ -1163,7 +1211,7 @@ __global__ __launch_bounds__(WAVE) void cost_grad_kernel(KParams kp, BatchPtrs i
     const int lane = P::lane(), N = NT ? NT : kp.N;
     const double* ws = io.ws + (size_t)b * kp.ws_stride;
     Ctx cx;
-    load_problem<NT, SC, P>(kp, ws, lds + P::half() * kp.l_total, cx);
+    load_problem<NT, SC, P, LIN>(kp, ws, lds + P::half() * kp.l_total, cx);
     const double* ub = u + (size_t)b * 2 * N;
     const double* xb = xi + (size_t)b * (1 + 2 * N);
     const double v = cx.vl ? ub[2 * lane] : 0.0, w = cx.vl ? ub[2 * lane + 1] : 0.0;
@@ -1173,7 +1221,7 @@ __global__ __launch_bounds__(WAVE) void cost_grad_kernel(KParams kp, BatchPtrs i
 #ifdef MPC_PROFILE
     Prof prof; prof.start();
 #endif
-    eval_point<NT, SC, P, AXIS>(kp, cx, v, w, c, 1.0 / fmax(c, 1.0), ya, yb, true, true, o PROF_PASS);
+    eval_point<NT, SC, P, AXIS, LIN>(kp, cx, v, w, c, 1.0 / fmax(c, 1.0), ya, yb, true, true, o PROF_PASS);
     if (lane == 0) {
         if (psi) psi[b] = o.psi;
         if (f) f[b] = o.f;
@@ -1744,7 +1792,7 @@ __device__ __forceinline__ bool alm_stalled(const Ctx& cx, const KParams& kp, in
 
 // The whole ALM / PANOC solve of problem P::problem() on the lanes P gives it.  `lds` is the workgroup's dynamic LDS.
 // The rare evaluations are states of a small machine; the PANOC steps run in a loop of their own (MPC_STEP_LOOP).
-template <int NT, bool SC, bool LBG, class P, bool AXIS = false>
+template <int NT, bool SC, bool LBG, class P, bool AXIS = false, bool LIN = false, int MINW = 3>
 __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& io, int B, double* lds) {
     if (P::problem() >= B) return;
     const int b = io.perm ? io.perm[P::problem()] : P::problem();   // every output below is indexed by the PROBLEM, not by the workgroup
@@ -1756,7 +1804,7 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
     // against it: a problem with more active rows than reserved must not touch the tables -- it is reported, not solved.
     if (kp.reserved) {
         const bool over = (int)P::uni(ws[H_KS]) > kp.mKs || (int)P::uni(ws[H_KF]) > kp.mKf || (int)P::uni(ws[H_KD]) > kp.mKd ||
-                          (SC && P::uni(ws[H_VAR]) != 0.0) || (AXIS && P::uni(ws[H_ROT]) != 0.0);
+                          (SC && P::uni(ws[H_VAR]) != 0.0) || (AXIS && P::uni(ws[H_ROT]) != 0.0) || (LIN && P::uni(ws[H_NLIN]) != 0.0);
         if (over) {
             const double nan = __builtin_nan("");
             if (lane < N) {
@@ -1776,14 +1824,14 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
         }
     }
     Ctx cx;
-    load_problem<NT, SC, P>(kp, ws, lds, cx);
+    load_problem<NT, SC, P, LIN, MINW>(kp, ws, lds, cx);
     // L-BFGS memory S, Y [mem][N][2]: in LDS (LBG = false) or in this problem's workspace record, i.e. in the
     // L2-resident HBM workspace (LBG = true: 6.4 KB less LDS per wavefront -> more resident wavefronts; the pairs are
     // streamed once per PANOC iteration, one pair ahead of the dot product that consumes them)
     constexpr int MEMT = MemOf<NT>::value;
     LbMem lm;
     constexpr bool FIXED = NT != 0 && !P::DUO;   // compile-time offsets of the fixed part of the carve (fixed_lds)
-    constexpr FixedLds FL = fixed_lds(NT ? NT : 2, MEMT ? MEMT : 1, !LBG);
+    constexpr FixedLds FL = fixed_lds(NT ? NT : 2, MEMT ? MEMT : 1, !LBG, MINW);
     lm.LM = LBG ? io.ws + (size_t)b * kp.ws_stride + kp.ws_lbs : lds + (FIXED ? FL.S : kp.l_S);  // [S; Y], contiguous in both layouts
     lm.LRHO = lds + (FIXED ? FL.rho : kp.l_rho);  // [mem]
     lm.LALPHA = lds + (FIXED ? FL.gg : kp.l_alpha);
@@ -1848,7 +1896,7 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
         PROF_MARK(10 + state);  // solver logic that led to this evaluation (by the state it was issued for)
         PROF_COUNT(16 + state);
         ++n_eval; n_eval_grad += want_grad ? 1 : 0;
-        eval_point<NT, SC, P, AXIS>(kp, cx, ev, ew, c, icm, ya, yb, want_grad, state == ST_OUTER, o PROF_PASS);
+        eval_point<NT, SC, P, AXIS, LIN, MINW>(kp, cx, ev, ew, c, icm, ya, yb, want_grad, state == ST_OUTER, o PROF_PASS);
         bool step_begin = false;
 
         if (state == ST_INIT0) {
@@ -1997,7 +2045,7 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
                     PROF_MARK(10 + ST_LIP);
                     PROF_COUNT(16 + ST_LIP);
                     ++n_eval;
-                    eval_point<NT, SC, P, AXIS>(kp, cx, hv, hw, c, icm, ya, yb, false, false, o PROF_PASS);
+                    eval_point<NT, SC, P, AXIS, LIN, MINW>(kp, cx, hv, hw, c, icm, ya, yb, false, false, o PROF_PASS);
                     const double cost_half = o.psi;
                     if (panoc_lip_test_fails(cx, cost_half, cost, ip, ig, nfpr) && lip_it < MAX_LIP_IT && Lip < KC(K_MAX_LIP)) {
                         lb.flush();  // invalidate the L-BFGS buffer
@@ -2023,7 +2071,7 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
                     PROF_MARK(10 + ST_LS);
                     PROF_COUNT(16 + ST_LS);
                     ++n_eval; ++n_eval_grad;
-                    eval_point<NT, SC, P, AXIS>(kp, cx, ev, ew, c, icm, ya, yb, true, false, o PROF_PASS);
+                    eval_point<NT, SC, P, AXIS, LIN, MINW>(kp, cx, ev, ew, c, icm, ya, yb, true, false, o PROF_PASS);
                     cost = P::uni(o.psi); gv = o.gv; gw = o.gw;
                     panoc_envelope_sums<P>(kp, vl, ev, ew, gamma, gv, gw, hv, hw, gg, d2h);
                     const double lhs = panoc_fbe(cost, gamma, ig, gg, d2h);
@@ -2108,10 +2156,10 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
     }
 }
 
-template <int NT, bool SC, bool LBG, int MINW, bool AXIS = false>
+template <int NT, bool SC, bool LBG, int MINW, bool AXIS = false, bool LIN = false>
 __global__ __launch_bounds__(WAVE, MINW) void solve_kernel_pair(KParams kp, BatchPtrs io, int B) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    solve_body<NT, SC, LBG, Solo<NT>, AXIS>(kp, io, B, lds);
+    solve_body<NT, SC, LBG, Solo<NT>, AXIS, LIN, MINW>(kp, io, B, lds);
 }
 // two problems per wavefront (grid = ceil(B / 2)); 2 wavefronts per SIMD = the same 16 resident problems per CU
 template <int NT, bool SC, bool LBG>

@@ -46,6 +46,9 @@ struct Handle {
     int last_B = 0;  // batch size of the last solve (for mpcgpu_last_eval_counts)
     bool shape_const = true;  // of the batch prepared last
     bool axis_aligned = false;  // ... and every active dynamic row of it has angle 0 (known only after a count read-back)
+    bool linear = false;        // ... and moves on a straight line (linear centre tables, mpc_kernels.hpp prep_problem)
+    int opt_linear = 1;         // MPCGPU_OPT_LINEAR_TABLES: 1 = use the linear centre tables where they pay (N_hor = 40, large batches)
+    bool last_linear = false;   // the last launch ran a kernel with linear centre tables
     int last_min_waves = 0;   // launch-bounds variant of the last solve (3 or 4 wavefronts per SIMD)
     int num_cus = 256;
     int team_max_batch = -1;  // MPCGPU_OPT_TEAM_BATCH: largest batch solved by the latency kernel (-1: 4 x number of CUs)
@@ -175,6 +178,8 @@ void fill_static_params(Handle* h) {
     k.ws_dyn = o; o += even(c.Ndynobs * N * DYNW);
     k.ws_qd = o; o += even(N);
     k.ws_alpha = o; o += even(c.Ndynobs);
+    k.ws_dynl = o; o += c.Ndynobs * DYNL;             // linear centre tables: row constants ...
+    k.ws_dynr = o; o += even((c.Ndynobs * N + 1) / 2);   // ... and one 32-bit residual word per (row, step)
     k.ws_lbs = o; o += c.lbfgs_mem * N * 2;   // L-BFGS memory when it is kept in the workspace (see LBFGS_IN_WORKSPACE)
     k.ws_lby = o; o += c.lbfgs_mem * N * 2;
     o += N * 2;                               // one row of zeros behind [S; Y] (Gram form: padded row of pass 2)
@@ -185,16 +190,18 @@ void fill_static_params(Handle* h) {
 // sizes of the fixed regions: mpc_kernels.hpp (part_doubles_c, stash_doubles_c, fixed_lds) -- shared with the kernels
 int part_doubles(const KParams& k) { return part_doubles_c(k.N, k.mem); }
 bool gram_layout(const KParams& k) { return gram_shape(k.N, k.mem); }
-int stash_doubles(const KParams& k) { return stash_doubles_c(k.N, k.mem); }
+int stash_doubles(const KParams& k, int minw = 3) { return stash_doubles_c(k.N, k.mem, minw); }
 
 // LDS carve for the batch maxima (doubles; every offset even => 16-byte aligned).
 // shape_const: every active dynamic row of the batch keeps (rx, ry, angle, alpha) over the horizon -> 2 doubles per
 // (row, step) + 6 per row instead of 9 per (row, step).
-void fill_lds_layout(KParams& k, int mKs, int mKf, int mKd, bool shape_const, bool lbfgs_in_lds) {
+// linear: straight-line rows -> 4 doubles per row + one 32-bit word per (row, step) instead of the centres.
+// minw: wavefronts per SIMD the kernel is compiled for (the stash of the long horizon depends on it: stash_stride_c).
+void fill_lds_layout(KParams& k, int mKs, int mKf, int mKd, bool shape_const, bool lbfgs_in_lds, bool linear = false, int minw = 3) {
     const int N = k.N;
     k.mKs = mKs; k.mKf = mKf; k.mKd = mKd;
     // fixed part first (compile-time offsets in the kernels with a compiled horizon), then the tables that follow the batch
-    const FixedLds f = fixed_lds(N, k.mem, lbfgs_in_lds);
+    const FixedLds f = fixed_lds(N, k.mem, lbfgs_in_lds, minw);
     k.l_hd = f.hd; k.l_seg = f.seg; k.l_pos = f.pos; k.l_stash = f.stash;
     k.l_H = f.part; k.l_W = f.W; k.l_part = f.part;
     k.l_rho = f.rho; k.l_alpha = f.gg; k.l_gg = f.gg;
@@ -202,7 +209,13 @@ void fill_lds_layout(KParams& k, int mKs, int mKf, int mKd, bool shape_const, bo
     int o = f.end;
     k.l_stc = o; o += mKs * STCW;
     k.l_fxy = o; o += mKf * N * 2;
-    if (shape_const) {
+    k.l_dynl = 0;
+    if (shape_const && linear) {
+        k.l_dyn = o; o += even((mKd * N + 1) / 2);   // residual words
+        k.l_dynl = o; o += mKd * DYNL;
+        k.l_dync = o; o += even(mKd * DYNC);
+        k.l_qd = 0;
+    } else if (shape_const) {
         k.l_dyn = o; o += even(mKd * N * DYNP);
         k.l_dync = o; o += even(mKd * DYNC);
         k.l_qd = 0;   // q_dyn lives in the pad double of the segment records (mpc_kernels.hpp load_problem)
@@ -278,7 +291,8 @@ int prepare(Handle* h, int B, const double* d_p, hipStream_t s, BatchPtrs& io, b
     if (allow_reserved && h->reserved) {
         mKs = h->res_shape[0]; mKf = h->res_shape[1]; mKd = h->res_shape[2];
         h->shape_const = h->res_shape[3] != 1;
-        h->axis_aligned = h->res_shape[3] == 2;
+        h->axis_aligned = h->res_shape[3] >= 2;
+        h->linear = h->res_shape[3] == 3;
         h->kp.reserved = 1;
     } else {
         if (h->capturing) return fail(h, -6, "stream capture needs mpcgpu_reserve_shape: the automatic LDS carve reads the batch's row counts back");
@@ -287,6 +301,7 @@ int prepare(Handle* h, int B, const double* d_p, hipStream_t s, BatchPtrs& io, b
         mKs = h->h_counts[CNT_KS]; mKf = h->h_counts[CNT_KF]; mKd = h->h_counts[CNT_KD];
         h->shape_const = h->h_counts[CNT_VARSHAPE] == 0;
         h->axis_aligned = h->shape_const && h->h_counts[CNT_ROTATED] == 0;
+        h->linear = h->axis_aligned && h->h_counts[CNT_NONLINEAR] == 0;
         h->kp.reserved = 0;
     }
     fill_lds_layout(h->kp, mKs, mKf, mKd, h->shape_const, !LBFGS_IN_WORKSPACE);
@@ -493,6 +508,19 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
     io.evals = (int32_t*)h->evals.ptr;
     h->last_B = B;
     if (!h->capturing) HIP_OK(h, hipEventRecord(h->ev[2], s));
+    // N_hor = 40 (round 4): when every active dynamic row of the batch is an axis-aligned disc on a straight line (the reference's
+    // own prediction feeder, src/main.py:77-85), the centres travel as linear tables (prep_problem: lossless, 0.9 instead of 5 KB)
+    // and the carve of the 128-register build -- stash included -- fits a compute unit 16 times: four wavefronts per SIMD instead
+    // of three.  Taken when the batch has more problems than the three-wavefront build keeps resident.
+    bool lin40 = false;
+    h->last_linear = false;
+    if (compiled_horizon(h) == 40 && h->opt_linear && h->shape_const && h->axis_aligned && h->linear && !h->last_pairing &&
+        LBFGS_IN_WORKSPACE && MPC_TRY_FOUR_WAVES && B > 4 * MPC_MIN_WAVES * h->num_cus) {
+        fill_lds_layout(h->kp, h->kp.mKs, h->kp.mKf, h->kp.mKd, true, false, true, 4);
+        if (h->kp.l_total * (int)sizeof(double) <= 10 * 1024) lin40 = true;
+        else fill_lds_layout(h->kp, h->kp.mKs, h->kp.mKf, h->kp.mKd, true, !LBFGS_IN_WORKSPACE);
+        h->last_shape[3] = h->kp.l_total * (int)sizeof(double);
+    }
     const size_t lds = h->kp.l_total * sizeof(double);
     // more than 64 KiB of dynamic LDS (long horizons with many time-varying obstacles) must be opted into per kernel
 #define LAUNCH_PAIR_WA(NT, SC, MINW, AX)                                                                           \
@@ -516,7 +544,7 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
 #define LAUNCH_PAIR(NT, SC) LAUNCH_PAIR_W(NT, SC, MPC_MIN_WAVES)
     const bool sc = h->shape_const;
     const bool four = MPC_TRY_FOUR_WAVES && lds <= 10 * 1024 && B > 4 * MPC_MIN_WAVES * h->num_cus;
-    h->last_min_waves = four && compiled_horizon(h) == 20 ? 4 : MPC_MIN_WAVES;
+    h->last_min_waves = (four && compiled_horizon(h) == 20) || lin40 ? 4 : MPC_MIN_WAVES;
     // MPCGPU_OPT_ORDER (mpc_order.hpp): longest first by the evaluation counts the previous call of this batch size left in
     // `evals` -- only when the batch is larger than what is resident at once (else everything starts together anyway).  The three
     // small kernels are part of the timed solve.
@@ -558,7 +586,14 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
             if (four) { if (sc) LAUNCH_PAIR_W(20, true, 4); else LAUNCH_PAIR_W(20, false, 4); }
             else if (sc) LAUNCH_PAIR(20, true); else LAUNCH_PAIR(20, false);
             break;
-        case 40: if (sc) LAUNCH_PAIR(40, true); else LAUNCH_PAIR(40, false); break;
+        case 40:
+            if (lin40) {
+                auto kern = solve_kernel_pair<40, true, LBFGS_IN_WORKSPACE, 4, true, true>;
+                if (int r_ = opt_in_lds(h, (const void*)kern, lds)) return r_;
+                hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE), lds, s, h->kp, io, B);
+                h->last_linear = true;
+            } else if (sc) LAUNCH_PAIR(40, true); else LAUNCH_PAIR(40, false);
+            break;
         default: if (sc) LAUNCH_PAIR(0, true); else LAUNCH_PAIR(0, false); break;
     }
 #undef LAUNCH_DUO
@@ -762,6 +797,10 @@ int32_t mpcgpu_cost_grad_batch(void* handle, int32_t B, const double* u, const d
     BatchPtrs io{};
     h->capturing = false;
     if (int r = prepare(h, B, (const double*)h->p.ptr, s, io, false)) return r;
+    // test hook of the linear centre tables: the same evaluation through the LIN instantiation (N_hor = 40)
+    const bool lin_cg = compiled_horizon(h) == 40 && h->opt_linear && h->shape_const && h->axis_aligned && h->linear && !h->last_pairing;
+    if (lin_cg) fill_lds_layout(h->kp, h->kp.mKs, h->kp.mKf, h->kp.mKd, true, !LBFGS_IN_WORKSPACE, true, 3);
+    h->last_linear = lin_cg;
     const size_t lds_cg = h->kp.l_total * sizeof(double);
 #define LAUNCH_CGA(NT, SC, PP, GRID, LDSB, AX)                                                                      \
     do {                                                                                                             \
@@ -782,7 +821,14 @@ int32_t mpcgpu_cost_grad_batch(void* handle, int32_t B, const double* u, const d
     } else if (h->shape_const) {
         switch (compiled_horizon(h)) {
             case 20: LAUNCH_CG1(20, true); break;
-            case 40: LAUNCH_CG1(40, true); break;
+            case 40:
+                if (lin_cg) {
+                    auto kern = cost_grad_kernel<40, true, Solo<40>, true, true>;
+                    if (int r_ = opt_in_lds(h, (const void*)kern, lds_cg)) return r_;
+                    hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE), lds_cg, s, h->kp, io, (const double*)h->u.ptr, (const double*)h->xi.ptr,
+                                       (double*)h->psi.ptr, (double*)h->f.ptr, (double*)h->grad.ptr, (double*)h->F1.ptr, (double*)h->F2.ptr, B);
+                } else LAUNCH_CG1(40, true);
+                break;
             default: LAUNCH_CG1(0, true); break;
         }
     } else {
@@ -862,7 +908,7 @@ int32_t mpcgpu_reserve_shape(void* handle, int32_t max_static, int32_t max_fleet
         return fail(h, -1, "reserved shape (%d, %d, %d) outside the configured maxima (%d, %d, %d)", max_static, max_fleet,
                     max_dyn, c.Nstcobs, c.Nother, c.Ndynobs);
     KParams probe = h->kp;
-    if (var_shape < 0 || var_shape > 2) return fail(h, -1, "var_shape must be 0 (shape-constant rows), 1 (rows may change shape) or 2 (shape-constant, axis-aligned), got %d", var_shape);
+    if (var_shape < 0 || var_shape > 3) return fail(h, -1, "var_shape must be 0 (shape-constant rows), 1 (rows may change shape), 2 (shape-constant, axis-aligned) or 3 (axis-aligned discs on straight lines), got %d", var_shape);
     fill_lds_layout(probe, max_static, max_fleet, max_dyn, var_shape != 1, !LBFGS_IN_WORKSPACE);
     if (probe.l_total * (int)sizeof(double) > 160 * 1024) return fail(h, -5, "reserved LDS carve of %d bytes exceeds 160 KiB", probe.l_total * 8);
     h->res_shape[0] = max_static; h->res_shape[1] = max_fleet; h->res_shape[2] = max_dyn; h->res_shape[3] = var_shape;
@@ -915,6 +961,10 @@ int32_t mpcgpu_set_option(void* handle, int32_t option, double value) {
             if (value == 1.0 && !duo_available(h)) return fail(h, -1, "two problems per wavefront are compiled for N_hor = 20 only (N_hor = %d)", h->kp.N);
             h->pairing = (int)value;
             return 0;
+        case MPCGPU_OPT_LINEAR_TABLES:
+            if (value != 0.0 && value != 1.0) return fail(h, -1, "linear tables must be 0 (off) or 1 (automatic), got %g", value);
+            h->opt_linear = (int)value;
+            return 0;
         case MPCGPU_OPT_ORDER:
             if (value != 0.0 && value != 1.0) return fail(h, -1, "order must be 0 (as given) or 1 (longest first by the previous call), got %g", value);
             h->order = (int)value;
@@ -958,6 +1008,7 @@ int32_t mpcgpu_last_table_kind(void* handle) {
     Handle* h = (Handle*)handle;
     if (!h) return -1;
     if (h->last_team) return 1;  // the latency kernel always carries the general tables
+    if (h->last_linear) return 3;
     return h->shape_const ? (h->axis_aligned ? 2 : 0) : 1;
 }
 

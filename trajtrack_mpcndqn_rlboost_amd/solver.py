@@ -22,12 +22,13 @@ _LIB = os.environ.get("MPCGPU_LIB", os.path.join(_PKG, "libmpcgpu.so"))  # overr
 
 STATUS_NAMES = ("Converged", "NotConvergedIterations", "NotConvergedOutOfTime", "NotFiniteComputation",
                 "ShapeExceeded")
-ABI_VERSION = 5
+ABI_VERSION = 6
 _STREAM_OWN = C.c_void_p(-1)      # MPCGPU_STREAM_OWN: the handle's own non-blocking stream
 OPT_LINESEARCH_FALLBACK = 1       # MPCGPU_OPT_LINESEARCH_FALLBACK
 OPT_PAIRING = 2                   # MPCGPU_OPT_PAIRING
 OPT_TEAM_BATCH = 3                # MPCGPU_OPT_TEAM_BATCH
 OPT_ORDER = 4                     # MPCGPU_OPT_ORDER
+OPT_LINEAR_TABLES = 5             # MPCGPU_OPT_LINEAR_TABLES
 
 
 def _stream_arg(stream):
@@ -212,7 +213,8 @@ class BatchSolver:
     """One handle of libmpcgpu.so = one generated solver of the reference, for batches of problems."""
 
     def __init__(self, config: Optional[MpcConfig] = None, device: int = 0, library: Optional[str] = None,
-                 pairing: Optional[int] = None, latency_batch: Optional[int] = None, order: Optional[str] = None):
+                 pairing: Optional[int] = None, latency_batch: Optional[int] = None, order: Optional[str] = None,
+                 linear_tables: Optional[bool] = None):
         """``pairing``: problems per wavefront of the solve kernel -- None = the library's rule (the faster layout: one),
         1 or 2 to force a layout (MPCGPU_OPT_PAIRING; 2 exists for N_hor = 20; env MPCGPU_PAIRING overrides None).
         ``latency_batch``: largest batch solved by the latency kernel (MPCGPU_OPT_TEAM_BATCH; None = the library's rule,
@@ -220,6 +222,8 @@ class BatchSolver:
         ``order``: in which order the throughput kernel starts the problems of a large batch (MPCGPU_OPT_ORDER): None /
         "longest_first" = by the evaluation counts of this handle's previous call of the same batch size (the library's
         default: robot i of this tick is robot i of the last one), "as_given" = workgroup g solves problem g (env MPCGPU_ORDER
+        overrides None).  Results do not depend on it (bitwise).
+        ``linear_tables``: False = never use the linear centre tables (MPCGPU_OPT_LINEAR_TABLES = 0; env MPCGPU_LINEAR_TABLES=0
         overrides None).  Results do not depend on it (bitwise)."""
         self.config = config if config is not None else MpcConfig()
         self._L = load_library(library)
@@ -255,6 +259,10 @@ class BatchSolver:
             order = os.environ["MPCGPU_ORDER"]
         if order is not None:
             self.set_order(order)
+        if linear_tables is None and os.environ.get("MPCGPU_LINEAR_TABLES"):
+            linear_tables = os.environ["MPCGPU_LINEAR_TABLES"] != "0"
+        if linear_tables is not None:
+            self._check(self._L.mpcgpu_set_option(self._h, OPT_LINEAR_TABLES, 1.0 if linear_tables else 0.0), "mpcgpu_set_option")
 
     def set_order(self, order: str):
         if order not in ("as_given", "longest_first"):
@@ -351,20 +359,23 @@ class BatchSolver:
         self._check(rc, "mpcgpu_solve_batch_dev")
 
     def reserve_shape(self, max_static: Optional[int] = None, max_fleet: Optional[int] = None,
-                      max_dyn: Optional[int] = None, var_shape: bool = True, axis_aligned: bool = False):
+                      max_dyn: Optional[int] = None, var_shape: bool = True, axis_aligned: bool = False, linear: bool = False):
         """Promise upper bounds on the active rows of the following ``solve_device`` batches (``None`` = the
         configured maximum): the launch then needs no count read-back -- it never blocks and can be captured into
         a hipGraph (after ``reserve_batch``).  ``var_shape=False``: every dynamic row keeps (rx, ry, angle, alpha) over
         the horizon (compact tables); with ``axis_aligned=True`` on top: every row has angle 0, what the reference's own
-        prediction feeder produces (src/main.py:77-85).  Problems that break a promise come back with status 4
-        (``ShapeExceeded``)."""
+        prediction feeder produces (src/main.py:77-85); ``linear=True`` on top of that: the centres of every row lie on a
+        straight line up to rounding (constant-velocity predictions; linear centre tables).  Problems that break a promise come
+        back with status 4 (``ShapeExceeded``)."""
         c = self.config
         if axis_aligned and var_shape:
             raise MpcGpuError("axis_aligned=True needs var_shape=False")
+        if linear and not axis_aligned:
+            raise MpcGpuError("linear=True needs axis_aligned=True")
         self._check(self._L.mpcgpu_reserve_shape(
             self._h, int(c.Nstcobs if max_static is None else max_static),
             int(c.Nother if max_fleet is None else max_fleet), int(c.Ndynobs if max_dyn is None else max_dyn),
-            1 if var_shape else (2 if axis_aligned else 0)), "mpcgpu_reserve_shape")
+            1 if var_shape else ((3 if linear else 2) if axis_aligned else 0)), "mpcgpu_reserve_shape")
 
     def reserve_batch(self, B: int):
         """Size the library-owned device buffers for batches of up to ``B`` problems now (needed before a
@@ -456,4 +467,5 @@ class BatchSolver:
                     ordered=bool(self._L.mpcgpu_last_ordered(self._h)),
                     latency_kernel=bool(self._L.mpcgpu_last_latency_kernel(self._h)),
                     shape_const=int(self._L.mpcgpu_last_table_kind(self._h)) != 1,
-                    axis_aligned=int(self._L.mpcgpu_last_table_kind(self._h)) == 2)
+                    axis_aligned=int(self._L.mpcgpu_last_table_kind(self._h)) >= 2,
+                    linear=int(self._L.mpcgpu_last_table_kind(self._h)) == 3)
