@@ -276,8 +276,7 @@ def main():
         nothing back -- the same kernel instantiation, no host synchronisation between the compaction and the solve."""
         sh = sv.last_shape()
         sv.reserve_shape(max_static=sh["max_static"], max_fleet=sh["max_fleet"], max_dyn=sh["max_dyn"],
-                         var_shape=not sh.get("shape_const", False), axis_aligned=sh.get("axis_aligned", False),
-                         linear=sh.get("linear", False))
+                         var_shape=not sh.get("shape_const", False), axis_aligned=sh.get("axis_aligned", False))
         sv.reserve_batch(b)
 
     def timed_leg(p, steps, warmup, sv=None, o=None):

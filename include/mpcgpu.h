@@ -144,9 +144,7 @@ int32_t mpcgpu_last_shape(void* handle, int32_t* max_static, int32_t* max_fleet,
  * of the following mpcgpu_solve_batch_dev calls, and what is known about the dynamic rows: var_shape = 1: a row may change
  * (rx, ry, angle, alpha) over the horizon (general tables); 0: every row keeps them (compact tables); 2: every row keeps them
  * AND is axis-aligned (angle 0 -- what the reference's own prediction feeder produces, src/main.py:77-85: the kernel without
- * the rotation into the ellipse frame, the same bits); 3 (ABI 6): every row is an axis-aligned disc / ellipse whose centres lie on a
- * STRAIGHT LINE up to rounding (constant-velocity predictions, src/main.py:77-85: centre k = fma(d, k, c0) + a residual that is an
- * exact bfloat16 -- checked per problem by the compaction kernel; lossless, the same bits).  The LDS carve is then taken from these bounds instead of a read-back (single-robot callers
+ * the rotation into the ellipse frame, the same bits).  The LDS carve is then taken from these bounds instead of a read-back (single-robot callers
  * of the reference reserve the configured maxima: a lone wavefront does not care about the size of its carve).
  * A problem that exceeds the reservation is not solved: status = MPCGPU_SHAPE_EXCEEDED, cost = NaN, u = 0.
  * All three bounds negative = drop the reservation.  Results do not depend on the carve (bitwise).
@@ -190,18 +188,23 @@ int32_t mpcgpu_reserve_batch(void* handle, int32_t B);
  *       0            as given (workgroup g solves problem g).
  *     Every problem is solved independently and writes the outputs of ITS index: results are bitwise the same in any order.
  *     The reference has no counterpart (one robot per solver.run call).
- *   MPCGPU_OPT_LINEAR_TABLES  (ABI 6) 1 (default): when every active dynamic row of a batch is an axis-aligned disc on a straight
- *       line (table kind 3 of mpcgpu_reserve_shape), N_hor = 40 and the batch exceeds 12 problems per compute unit, the centres
- *       travel as linear tables (0.9 instead of 5 KB of LDS per problem) and the 128-register build of the solve kernel runs with
- *       16 instead of 12 resident problems per compute unit.  0: always the stored centres.  Bitwise the same results.
+ *   MPCGPU_OPT_LINEAR_TABLES  (ABI 6) EXPERIMENT, effective only in the variant build libmpcgpu_linear40.so (-DMPC_LINEAR40=1; the
+ *       product build accepts and ignores it).  1 (default): at N_hor = 40, with shape-constant axis-aligned dynamic rows (table
+ *       kind 2) and a batch of more than 12 problems per compute unit, the centres of the dynamic rows travel as LINEAR TABLES: a
+ *       constant-velocity prediction (src/main.py:77-85) lies on a straight line up to rounding, centre k = fma(n_k, u, fma(d, k,
+ *       c0)) with a 16-bit integer n_k per coordinate and step -- lossless, checked per problem by the compaction kernel; 1.7
+ *       instead of 5 KB of LDS per problem, so that a 128-register build of the solve kernel keeps 16 instead of 12 problems
+ *       resident per compute unit; a problem with a row that does not fit is solved from the stored centres by a pick-up launch
+ *       right behind.  Bitwise the same results -- and measured SLOWER (the 128-register build spills: profiles/
+ *       r04_linear_tables_ab.txt), which is why the product does not carry it.  0: always the stored centres.
  */
 enum { MPCGPU_OPT_LINESEARCH_FALLBACK = 1, MPCGPU_OPT_PAIRING = 2, MPCGPU_OPT_TEAM_BATCH = 3, MPCGPU_OPT_ORDER = 4,
        MPCGPU_OPT_LINEAR_TABLES = 5 };
 int32_t mpcgpu_set_option(void* handle, int32_t option, double value);
 
 /* Register-allocation variant the last solve call was launched with: 3 (148 / 168 VGPRs) or 4 wavefronts per SIMD
- * (128 VGPRs; chosen when the LDS carve fits 16 times into a CU and the batch exceeds 12 problems per CU: N_hor = 20, and
- * N_hor = 40 with linear centre tables).  Both give bitwise identical results. */
+ * (128 VGPRs; chosen when the LDS carve fits 16 times into a CU and the batch exceeds 12 problems per CU: N_hor = 20).
+ * Both give bitwise identical results. */
 int32_t mpcgpu_last_waves_per_simd(void* handle);
 
 /* Wavefronts per problem of the latency kernel when the last solve call ran it (MPCGPU_OPT_TEAM_BATCH): 4, or 2 for batches
@@ -210,7 +213,7 @@ int32_t mpcgpu_last_latency_kernel(void* handle);
 
 /* Dynamic-obstacle tables of the last solve / cost_grad launch, in the coding of mpcgpu_reserve_shape's var_shape: 1 general
  * (some row changes shape over the horizon, or the latency kernel ran), 0 shape-constant, 2 shape-constant and axis-aligned,
- * 3 the launch ran with linear centre tables.
+ * 3 the launch ran with linear centre tables (variant build only, see MPCGPU_OPT_LINEAR_TABLES).
  * A caller that wants read-back-free launches of the same batches can reserve exactly what the automatic rule found. */
 int32_t mpcgpu_last_table_kind(void* handle);
 

@@ -87,7 +87,7 @@ def device_closed_loop(cfg, B=8192, ticks=30, warmup_ticks=5, n_dyn=4, warm=Fals
             torch.cuda.synchronize()
             sh = solver.last_shape()
             solver.reserve_shape(max_static=sh["max_static"], max_fleet=sh["max_fleet"], max_dyn=sh["max_dyn"],
-                                 var_shape=not sh["shape_const"], axis_aligned=sh["axis_aligned"], linear=sh["linear"])
+                                 var_shape=not sh["shape_const"], axis_aligned=sh["axis_aligned"])
             solver.reserve_batch(B)
         ordered.append(bool(solver.last_shape()["ordered"]))
         hist[t] = torch.bincount(out["status"].to(torch.int64), minlength=4)[:4]

@@ -54,7 +54,14 @@ __device__ __forceinline__ void lds_add(double* p, double v) {
     __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)p, v);
 }
 
+// Linear centre tables + the four-wavefront build of the N_hor = 40 solve kernel (round 4): measured SLOWER than the product
+// (profiles/r04_linear_tables_ab.txt: the 128-register build of that kernel spills 92 VGPRs), so it is compiled only into the
+// variant build libmpcgpu_linear40.so (`make variants`, -DMPC_LINEAR40=1), which tests/test_gpu_linear_tables.py keeps bitwise equal.
+#ifndef MPC_LINEAR40
+#define MPC_LINEAR40 0
+#endif
 constexpr int WAVE = 64;
+constexpr int PREP_STATIC_LDS = (32 + (MPC_LINEAR40 ? 64 : 0)) * 4;   // bytes of static LDS of prep_problem (s_entry, s_ue): part of every kernel that inlines it
 constexpr int HDR = 64;        // header doubles per problem in the workspace
 constexpr int SEGW = 9;        // LDS / workspace doubles per reference segment: s1x, s1y, dx, dy, 1/(|d|^2+1e-16), then the
                                // bounding circle (cx, cy, R) of ALL segments from this one to the last, + 1 pad: the odd
@@ -65,7 +72,7 @@ constexpr int DYNW = 9;        // workspace record per (dyn row, step): cx, cy, 
 constexpr int DYNP = 2;        // shape-constant LDS record per (row, step): cx, cy
 constexpr int DYNC = 7;        // shape-constant LDS record per row: cosA, sinA, ihx, ihy, isx, isy, alpha
                                // (the item weight q_dyn[k] * alpha is formed where it is used: q_dyn is one value per step)
-constexpr int DYNL = 4;        // linear centre tables: per row x0, y0, dx, dy (centre of step k = fma(d, k, c0) + residual)
+constexpr int DYNL = 6;        // linear centre tables: per row x0, y0, dx, dy, ux, uy (centre of step k = fma(n_k, u, fma(d, k, c0)), n_k a 16-bit integer)
 constexpr int PARTW = 5;       // doubles per item-lane partial  (gx, gy, best, bgx, bgy)
 constexpr int MAX_MEM = 16;
 // Reference segments per item lane that are evaluated unconditionally before the suffix-circle test takes over.  Rounds 1-3: 2
@@ -82,7 +89,8 @@ enum { H_KS = 18, H_KF = 19, H_KD = 20, H_CTH0 = 21, H_STH0 = 22, H_NPF = 23, H_
        H_NLIN = 61 /* 1: some active dynamic row does not move on a straight line (see LINEAR CENTRE TABLES) */ };
 // batch-wide reductions written by the compaction kernel
 enum { CNT_KS = 0, CNT_KF = 1, CNT_KD = 2, CNT_VARSHAPE = 3, CNT_ROTATED = 4 /* some active dynamic row is not an axis-aligned ellipse (angle != 0) */,
-       CNT_NONLINEAR = 5 /* some active dynamic row is not a straight-line prediction */, CNT_WORDS = 8 };
+       CNT_NONLINEAR = 5 /* some active dynamic row is not a straight-line prediction */,
+       CNT_NL_COUNT = 6 /* length of the list of such problems (nl_list_kernel) */, CNT_WORDS = 8 };
 
 struct KParams {
     int N, Nother, Nstcobs, Ndynobs, np, mem;
@@ -141,10 +149,14 @@ __host__ __device__ constexpr int part_doubles_c(int N, int mem) {
 // segment records (320 B) the N_hor = 40 carve is 12 480 B.
 // With the Gram form at N_hor = 40 (its matrices: 1240 B) the four Simpson values stay in registers as well (stride 0): 11 200 B
 // + 1160 B = 12 360 B, still 12 per CU.
-// `minw`: wavefronts per SIMD the kernel is compiled for.  The 128-register build of the long horizon (minw = 4, round 4) has no
-// registers to carry anything through the item phase: it parks all six values like the short horizon does.
+// `minw`: wavefronts per SIMD the kernel is compiled for.  The 128-register build of the long horizon (minw = 4, round 4) cannot
+// carry the four Simpson values through the item phase: it parks them (stride 4; (v, w) stay in registers -- with all six parked
+// the carve of the benchmark shape would be 10 704 B, over the 10 240 B that sixteen wavefronts per compute unit allow).
+#ifndef MPC_STW40_W4
+#define MPC_STW40_W4 4   // experiment knob of round 4 (6: all six values parked, 14 wavefronts per compute unit)
+#endif
 __host__ __device__ constexpr int stash_stride_c(int N, int mem, int minw = 3) {
-    return (N == 40 && mem == 10 && minw < 4) ? (gram_shape(N, mem) ? 0 : 4) : 6;
+    return (N == 40 && mem == 10) ? (minw >= 4 ? MPC_STW40_W4 : (gram_shape(N, mem) ? 0 : 4)) : 6;
 }
 __host__ __device__ constexpr int stash_doubles_c(int N, int mem, int minw = 3) {
     int need = N * stash_stride_c(N, mem, minw);
@@ -202,6 +214,8 @@ struct BatchPtrs {
     double* ws; int* counts;
     int32_t* evals;  // [B][2] psi evaluations / of those with gradient (library-owned; read by mpcgpu_last_eval_counts)
     const int32_t* perm;  // throughput kernel: workgroup g solves problem perm[g] (NULL: problem g) -- MPCGPU_OPT_ORDER, mpc_order.hpp
+    const int* nsel;      // != NULL: only the first *nsel entries of `perm` are problems of this launch (device-side count: the
+                          // launch that picks up the problems a linear-table launch left out)
     double* trace;   // -DMPC_TRACE builds only: [B][trace_cap][TRACE_W] decision trace, one record per PANOC step
     int trace_cap;
 };
@@ -598,7 +612,7 @@ __device__ __forceinline__ void prep_problem(const KParams& kp, const Src& p, do
     // ---- dynamic obstacles: lane i checks row i
     int Kd;
     bool varshape = false, rotated = false, nonlinear = false;
-    __shared__ int s_entry[WAVE];  // original row -> entry (or -1 for padded rows)
+    __shared__ int s_entry[32];  // original row -> entry (or -1 for padded rows); Ndynobs <= 32
     {
         bool nz = false;
         if (lane < kp.Ndynobs) {
@@ -635,29 +649,64 @@ __device__ __forceinline__ void prep_problem(const KParams& kp, const Src& p, do
             d[7] = 1.0 / ((ry + kp.social + 1e-6) * (ry + kp.social + 1e-6));
             d[8] = p[kp.qd0 + k] * p[q0 + 5];  // q_dyn[k] * alpha
             if (k == 0) ws[kp.ws_alpha + e] = p[q0 + 5];
-            // LINEAR CENTRE TABLES (round 4).  A constant-velocity prediction (est_dyn_obs_positions, src/main.py:77-85) puts the
-            // centres of a row on a straight line up to rounding.  With c0 = the first centre and d = (last - first) / (N - 1) the
-            // predictor lin_k = fma(d, k, c0) misses the stored centre by a few ulps; that residual is an exactly representable
-            // bfloat16 (<= 8 significant bits, exponent in range), and lin_k + residual gives the stored double back EXACTLY (the
-            // exact sum is a double).  Per row 4 doubles + 4 bytes per step instead of 16 bytes per step: 5.0 -> 0.9 KB of LDS at
-            // N_hor = 40 with 8 rows -- lossless; a row that does not fit (scanner predictions, curved paths) flags the problem and
-            // the batch keeps the stored centres.
-            {
-                const int qr = kp.od0 + i * 6 * N, ql = qr + 6 * (N - 1);
-                const double x0 = p[qr], y0 = p[qr + 1];
-                const double inv = 1.0 / (double)(N - 1);
-                const double dxl = (p[ql] - x0) * inv, dyl = (p[ql + 1] - y0) * inv;
-                const double lx = __builtin_fma(dxl, (double)k, x0), ly = __builtin_fma(dyl, (double)k, y0);
-                const double rx_ = p[q0] - lx, ry_ = p[q0 + 1] - ly;
-                const float fx = (float)rx_, fy = (float)ry_;
-                const unsigned bx = __float_as_uint(fx), by = __float_as_uint(fy);
-                const bool fits = (double)fx == rx_ && (double)fy == ry_ && !(bx & 0xFFFFu) && !(by & 0xFFFFu) &&
-                                  lx + (double)fx == p[q0] && ly + (double)fy == p[q0 + 1];
-                nonlinear |= !fits;
-                reinterpret_cast<unsigned*>(ws + kp.ws_dynr)[e * N + k] = (bx >> 16) | (by & 0xFFFF0000u);
-                if (k == 0) { double* L = ws + kp.ws_dynl + e * DYNL; L[0] = x0; L[1] = y0; L[2] = dxl; L[3] = dyl; }
-            }
         }
+#if MPC_LINEAR40
+        // LINEAR CENTRE TABLES (round 4).  A constant-velocity prediction (est_dyn_obs_positions, src/main.py:77-85) puts the
+        // centres of a row on a straight line up to rounding.  With c0 = the first centre and d = (last - first) / (N - 1) the
+        // predictor lin_k = fma(d, k, c0) misses the stored centre by a few units of the operands' last place; every such
+        // residual is an integer multiple n_k of u = the smallest ulp among the row's centres and predictor values, and
+        // fma(n_k, u, lin_k) gives the stored double back EXACTLY (the exact sum is that double).  Per row 6 doubles + one 16-bit
+        // integer per coordinate and step instead of 16 bytes per step: 5.0 -> 1.7 KB of LDS at N_hor = 40 with 8 rows --
+        // lossless.  A row that does not fit 16 bits (a curved or scanner prediction, a coordinate closer than ~1/4000 of the
+        // largest one to zero) flags the PROBLEM (H_NLIN): it is solved from the stored centres by a second launch.
+        __shared__ int s_ue[2 * 32];   // per original row: smallest binary exponent among its x (y) centres and predictor values
+        if (lane < kp.Ndynobs) { s_ue[2 * lane] = 4096; s_ue[2 * lane + 1] = 4096; }
+        wave_sync();
+        auto lin_of = [&](int i, int k, double& lx, double& ly, double& dxl, double& dyl, double& x0, double& y0) {
+            const int qr = kp.od0 + i * 6 * N, ql = qr + 6 * (N - 1);
+            x0 = p[qr]; y0 = p[qr + 1];
+            const double inv = 1.0 / (double)(N - 1);
+            dxl = (p[ql] - x0) * inv; dyl = (p[ql + 1] - y0) * inv;
+            lx = __builtin_fma(dxl, (double)k, x0); ly = __builtin_fma(dyl, (double)k, y0);
+        };
+        auto expo = [](double z) -> int {   // binary exponent of a normal double; zero does not constrain the unit; anything else: unusable
+            const int e = (int)((__double_as_longlong(z) >> 52) & 0x7ff);
+            return z == 0.0 ? 4096 : (e == 0 || e == 0x7ff) ? -4096 : e - 1023;
+        };
+        for (int t = lane; t < kp.Ndynobs * N; t += WAVE) {
+            const int i = t / N, k = t - i * N;
+            if (s_entry[i] < 0) continue;
+            double lx, ly, dxl, dyl, x0, y0;
+            lin_of(i, k, lx, ly, dxl, dyl, x0, y0);
+            const int q0 = kp.od0 + i * 6 * N + 6 * k;
+            const int ex = min(expo(p[q0]), expo(lx)), ey = min(expo(p[q0 + 1]), expo(ly));
+            atomicMin(&s_ue[2 * i], ex); atomicMin(&s_ue[2 * i + 1], ey);
+        }
+        wave_sync();
+        for (int t = lane; t < kp.Ndynobs * N; t += WAVE) {
+            const int i = t / N, k = t - i * N;
+            const int e = s_entry[i];
+            if (e < 0) continue;
+            double lx, ly, dxl, dyl, x0, y0;
+            lin_of(i, k, lx, ly, dxl, dyl, x0, y0);
+            const int q0 = kp.od0 + i * 6 * N + 6 * k;
+            // unit = 2^(exponent - 52); a row of zeros (or of unusable values) gets the unit 1 and fails below unless it is exact
+            auto unit = [](int ex, double& u, double& iu) {
+                const bool ok = ex > -900 && ex < 900;
+                u = ok ? __longlong_as_double((long long)(ex - 52 + 1023) << 52) : 1.0;
+                iu = ok ? __longlong_as_double((long long)(52 - ex + 1023) << 52) : 1.0;
+            };
+            double ux, iux, uy, iuy;
+            unit(s_ue[2 * i], ux, iux); unit(s_ue[2 * i + 1], uy, iuy);
+            const double nx = (p[q0] - lx) * iux, ny = (p[q0 + 1] - ly) * iuy;
+            const bool fits = fabs(nx) <= 32767.0 && fabs(ny) <= 32767.0 && nx == (double)(int)nx && ny == (double)(int)ny &&
+                              __builtin_fma(nx, ux, lx) == p[q0] && __builtin_fma(ny, uy, ly) == p[q0 + 1];
+            nonlinear |= !fits;
+            const int wx = fits ? (int)nx : 0, wy = fits ? (int)ny : 0;
+            reinterpret_cast<unsigned*>(ws + kp.ws_dynr)[e * N + k] = ((unsigned)wx & 0xFFFFu) | ((unsigned)wy << 16);
+            if (k == 0) { double* L = ws + kp.ws_dynl + e * DYNL; L[0] = x0; L[1] = y0; L[2] = dxl; L[3] = dyl; L[4] = ux; L[5] = uy; }
+        }
+#endif
     }
     const bool any_var = __ballot(varshape) != 0ull, any_rot = __ballot(rotated) != 0ull, any_nonlin = __ballot(nonlinear) != 0ull;
     if (lane == 0) {
@@ -680,6 +729,12 @@ __global__ __launch_bounds__(WAVE) void prep_kernel(KParams kp, BatchPtrs io, in
     prep_problem(kp, ParamVector{io.p + (size_t)b * kp.np}, io.ws + (size_t)b * kp.ws_stride, io.counts, threadIdx.x);
 }
 
+// problems whose dynamic rows do not fit the linear centre tables (H_NLIN), as a list for the pick-up launch
+__global__ __launch_bounds__(256) void nl_list_kernel(const double* __restrict__ ws, int ws_stride, int B, int* counts, int32_t* list) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B && ws[(size_t)b * ws_stride + H_NLIN] != 0.0) list[atomicAdd(counts + CNT_NL_COUNT, 1)] = b;
+}
+
 // ------------------------------------------------------------------------------------------------
 // per-wave problem context
 // ------------------------------------------------------------------------------------------------
@@ -697,7 +752,7 @@ struct Ctx {
     // LDS tables
     double *seg, *stc, *fxy, *dyn, *dync, *pos, *H, *W, *part, *stash;
     const double* dynl;        // linear centre tables: [Kd][DYNL]
-    const unsigned* dynr;      // ... and the residuals of every (row, step): bfloat16 x in the low half, y in the high half
+    const unsigned* dynr;      // ... and the residuals of every (row, step): signed 16-bit multiples of the row's unit, x low, y high
 };
 constexpr int KC_BASE = 32;
 #define KC(i) (cx.hd[KC_BASE + (i)])
@@ -783,12 +838,12 @@ __device__ __forceinline__ DynItem dyn_item(const Ctx& cx, int i, int k, int N, 
     double ex, ey;
     if (SC) {
         const double* s = cx.dync + i * DYNC;
-        if (LIN) {   // centre = predictor + bfloat16 residual: bitwise the stored centre (prep_problem)
+        if (LIN) {   // centre = fma(n, unit, predictor): bitwise the stored centre (prep_problem)
             const double* L = cx.dynl + i * DYNL;
-            const unsigned r = cx.dynr[i * N + k];
+            const int r = (int)cx.dynr[i * N + k];
             const double kk = (double)k;
-            const double ecx = __builtin_fma(L[2], kk, L[0]) + (double)__uint_as_float(r << 16);
-            const double ecy = __builtin_fma(L[3], kk, L[1]) + (double)__uint_as_float(r & 0xFFFF0000u);
+            const double ecx = __builtin_fma((double)((r << 16) >> 16), L[4], __builtin_fma(L[2], kk, L[0]));
+            const double ecy = __builtin_fma((double)(r >> 16), L[5], __builtin_fma(L[3], kk, L[1]));
             ex = px - ecx; ey = py - ecy;
         } else {
             const double* e = cx.dyn + (i * N + k) * DYNP;
@@ -1795,16 +1850,19 @@ __device__ __forceinline__ bool alm_stalled(const Ctx& cx, const KParams& kp, in
 template <int NT, bool SC, bool LBG, class P, bool AXIS = false, bool LIN = false, int MINW = 3>
 __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& io, int B, double* lds) {
     if (P::problem() >= B) return;
+    if (io.nsel && P::problem() >= *io.nsel) return;               // pick-up launch: only the listed problems
     const int b = io.perm ? io.perm[P::problem()] : P::problem();   // every output below is indexed by the PROBLEM, not by the workgroup
     const long long t_start = wall_clock64();
     const int lane = P::lane(), N = NT ? NT : kp.N, mem = kp.mem;
     lds += P::half() * kp.l_total;  // this problem's carve
     const double* ws = io.ws + (size_t)b * kp.ws_stride;
+    // a problem whose dynamic rows do not fit the linear centre tables is left to the pick-up launch that follows (stored centres)
+    if (LIN && P::uni(ws[H_NLIN]) != 0.0) return;
     // Launches with a RESERVED LDS carve (mpcgpu_reserve_shape: no count read-back before the launch) check every problem
     // against it: a problem with more active rows than reserved must not touch the tables -- it is reported, not solved.
     if (kp.reserved) {
         const bool over = (int)P::uni(ws[H_KS]) > kp.mKs || (int)P::uni(ws[H_KF]) > kp.mKf || (int)P::uni(ws[H_KD]) > kp.mKd ||
-                          (SC && P::uni(ws[H_VAR]) != 0.0) || (AXIS && P::uni(ws[H_ROT]) != 0.0) || (LIN && P::uni(ws[H_NLIN]) != 0.0);
+                          (SC && P::uni(ws[H_VAR]) != 0.0) || (AXIS && P::uni(ws[H_ROT]) != 0.0);
         if (over) {
             const double nan = __builtin_nan("");
             if (lane < N) {

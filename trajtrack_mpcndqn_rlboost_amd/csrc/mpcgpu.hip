@@ -37,7 +37,7 @@ struct Handle {
     bool timing_valid = false;
     std::string err;
     // grow-only device buffers
-    DevBuf ws, counts, evals, perm, bins, trace, p, u0, y0, c0, u, cost, status, inner, outer, fpr, f2, y, ms, xi, psi, f, grad, F1, F2;
+    DevBuf ws, counts, evals, perm, bins, nlist, trace, p, u0, y0, c0, u, cost, status, inner, outer, fpr, f2, y, ms, xi, psi, f, grad, F1, F2;
     int order = 1;      // MPCGPU_OPT_ORDER: 0 problems are dispatched as given, 1 longest first by the previous call's evaluation counts
     int evals_B = 0;    // batch size of the call whose evaluation counts `evals` holds (0: none)
     int last_ordered = 0;  // the last throughput launch used a permutation
@@ -291,8 +291,8 @@ int prepare(Handle* h, int B, const double* d_p, hipStream_t s, BatchPtrs& io, b
     if (allow_reserved && h->reserved) {
         mKs = h->res_shape[0]; mKf = h->res_shape[1]; mKd = h->res_shape[2];
         h->shape_const = h->res_shape[3] != 1;
-        h->axis_aligned = h->res_shape[3] >= 2;
-        h->linear = h->res_shape[3] == 3;
+        h->axis_aligned = h->res_shape[3] == 2;
+        h->linear = false;     // not known without a read-back (only the cost_grad test hook asks)
         h->kp.reserved = 1;
     } else {
         if (h->capturing) return fail(h, -6, "stream capture needs mpcgpu_reserve_shape: the automatic LDS carve reads the batch's row counts back");
@@ -375,7 +375,7 @@ void mpcgpu_destroy(void* handle) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf* bufs[] = {&h->ws, &h->counts, &h->evals, &h->perm, &h->bins, &h->trace, &h->p, &h->u0, &h->y0, &h->c0, &h->u, &h->cost, &h->status, &h->inner,
+    DevBuf* bufs[] = {&h->ws, &h->counts, &h->evals, &h->perm, &h->bins, &h->nlist, &h->trace, &h->p, &h->u0, &h->y0, &h->c0, &h->u, &h->cost, &h->status, &h->inner,
                       &h->outer, &h->fpr, &h->f2, &h->y, &h->ms, &h->xi, &h->psi, &h->f, &h->grad, &h->F1, &h->F2};
     for (DevBuf* b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
@@ -457,8 +457,8 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
             KParams kt = h->kp;
             fill_team_layout(kt, TEAM_WAVES, h->cfg.Nstcobs, h->cfg.Nother, h->cfg.Ndynobs);
             const size_t lds_t = kt.l_total * sizeof(double);
-            // + 256: prep_problem's static __shared__ table travels on top of the dynamic carve
-            if (lds_t + 256 <= 160 * 1024) {   // else (long horizons with many obstacle slots): the throughput kernel below
+            // prep_problem's static __shared__ tables travel on top of the dynamic carve
+            if (lds_t + PREP_STATIC_LDS <= 160 * 1024) {   // else (long horizons with many obstacle slots): the throughput kernel below
                 if (!h->capturing) HIP_OK(h, hipEventRecord(h->ev[0], s));
                 if (trk) {   // the records come from the tracker's arrays: one more (tiny) launch in front of the solve
                     hipLaunchKernelGGL(tracker_assemble_kernel, dim3(B), dim3(WAVE), 0, s, h->kp, tracker_view(h, trk), refs, io.ws, (int*)nullptr);
@@ -487,7 +487,7 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
         kt.reserved = 1;                       // every problem is checked against the tables' size on the device
         const size_t lds_t = kt.l_total * sizeof(double);
         const int per_cu = tw == 2 ? 4 : 2;    // 256 VGPRs per wavefront: eight wavefronts per compute unit
-        if ((lds_t + 64) * per_cu <= 160 * 1024) {
+        if ((lds_t + PREP_STATIC_LDS) * per_cu <= 160 * 1024) {
             io.p = nullptr;                    // the records exist already
             if (!h->capturing) HIP_OK(h, hipEventRecord(h->ev[2], s));
             if (tw == 2) { LAUNCH_TEAM_N(2, kt, lds_t) } else { LAUNCH_TEAM_N(TEAM_WAVES, kt, lds_t) }
@@ -514,10 +514,11 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
     // of three.  Taken when the batch has more problems than the three-wavefront build keeps resident.
     bool lin40 = false;
     h->last_linear = false;
-    if (compiled_horizon(h) == 40 && h->opt_linear && h->shape_const && h->axis_aligned && h->linear && !h->last_pairing &&
+    KParams kp_stored = h->kp;    // the layout with the stored centres: what the pick-up launch of a linear-table launch runs with
+    if (MPC_LINEAR40 && compiled_horizon(h) == 40 && h->opt_linear && h->shape_const && h->axis_aligned && !h->last_pairing &&
         LBFGS_IN_WORKSPACE && MPC_TRY_FOUR_WAVES && B > 4 * MPC_MIN_WAVES * h->num_cus) {
         fill_lds_layout(h->kp, h->kp.mKs, h->kp.mKf, h->kp.mKd, true, false, true, 4);
-        if (h->kp.l_total * (int)sizeof(double) <= 10 * 1024) lin40 = true;
+        if (h->kp.l_total * (int)sizeof(double) <= (MPC_STW40_W4 == 6 ? 9 * 1280 : 10 * 1024)) lin40 = true;
         else fill_lds_layout(h->kp, h->kp.mKs, h->kp.mKf, h->kp.mKd, true, !LBFGS_IN_WORKSPACE);
         h->last_shape[3] = h->kp.l_total * (int)sizeof(double);
     }
@@ -587,12 +588,28 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
             else if (sc) LAUNCH_PAIR(20, true); else LAUNCH_PAIR(20, false);
             break;
         case 40:
+#if MPC_LINEAR40
             if (lin40) {
+                // Problems with a row that does not fit the linear tables (H_NLIN: curved predictions, a coordinate next to zero) are
+                // skipped by this launch and listed for a pick-up launch of the stored-centre kernel right behind it: its grid is
+                // the whole batch, workgroups beyond the (device-side) length of the list leave at once.  Nothing is read back.
+                if (int r_ = ensure(h, h->nlist, (size_t)B * sizeof(int32_t))) return r_;
+                hipLaunchKernelGGL(nl_list_kernel, dim3((B + 255) / 256), dim3(256), 0, s, (const double*)h->ws.ptr, h->kp.ws_stride, B, io.counts,
+                                   (int32_t*)h->nlist.ptr);
                 auto kern = solve_kernel_pair<40, true, LBFGS_IN_WORKSPACE, 4, true, true>;
                 if (int r_ = opt_in_lds(h, (const void*)kern, lds)) return r_;
                 hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE), lds, s, h->kp, io, B);
+                BatchPtrs io2 = io;
+                io2.perm = (const int32_t*)h->nlist.ptr;
+                io2.nsel = io.counts + CNT_NL_COUNT;
+                auto kern2 = solve_kernel_pair<40, true, LBFGS_IN_WORKSPACE, MPC_MIN_WAVES, true, false>;
+                const size_t lds2 = kp_stored.l_total * sizeof(double);
+                if (int r_ = opt_in_lds(h, (const void*)kern2, lds2)) return r_;
+                hipLaunchKernelGGL(kern2, dim3(B), dim3(WAVE), lds2, s, kp_stored, io2, B);
                 h->last_linear = true;
-            } else if (sc) LAUNCH_PAIR(40, true); else LAUNCH_PAIR(40, false);
+            } else
+#endif
+            if (sc) LAUNCH_PAIR(40, true); else LAUNCH_PAIR(40, false);
             break;
         default: if (sc) LAUNCH_PAIR(0, true); else LAUNCH_PAIR(0, false); break;
     }
@@ -798,7 +815,7 @@ int32_t mpcgpu_cost_grad_batch(void* handle, int32_t B, const double* u, const d
     h->capturing = false;
     if (int r = prepare(h, B, (const double*)h->p.ptr, s, io, false)) return r;
     // test hook of the linear centre tables: the same evaluation through the LIN instantiation (N_hor = 40)
-    const bool lin_cg = compiled_horizon(h) == 40 && h->opt_linear && h->shape_const && h->axis_aligned && h->linear && !h->last_pairing;
+    const bool lin_cg = MPC_LINEAR40 && compiled_horizon(h) == 40 && h->opt_linear && h->shape_const && h->axis_aligned && h->linear && !h->last_pairing;
     if (lin_cg) fill_lds_layout(h->kp, h->kp.mKs, h->kp.mKf, h->kp.mKd, true, !LBFGS_IN_WORKSPACE, true, 3);
     h->last_linear = lin_cg;
     const size_t lds_cg = h->kp.l_total * sizeof(double);
@@ -822,12 +839,15 @@ int32_t mpcgpu_cost_grad_batch(void* handle, int32_t B, const double* u, const d
         switch (compiled_horizon(h)) {
             case 20: LAUNCH_CG1(20, true); break;
             case 40:
+#if MPC_LINEAR40
                 if (lin_cg) {
                     auto kern = cost_grad_kernel<40, true, Solo<40>, true, true>;
                     if (int r_ = opt_in_lds(h, (const void*)kern, lds_cg)) return r_;
                     hipLaunchKernelGGL(kern, dim3(B), dim3(WAVE), lds_cg, s, h->kp, io, (const double*)h->u.ptr, (const double*)h->xi.ptr,
                                        (double*)h->psi.ptr, (double*)h->f.ptr, (double*)h->grad.ptr, (double*)h->F1.ptr, (double*)h->F2.ptr, B);
-                } else LAUNCH_CG1(40, true);
+                } else
+#endif
+                LAUNCH_CG1(40, true);
                 break;
             default: LAUNCH_CG1(0, true); break;
         }
@@ -908,7 +928,7 @@ int32_t mpcgpu_reserve_shape(void* handle, int32_t max_static, int32_t max_fleet
         return fail(h, -1, "reserved shape (%d, %d, %d) outside the configured maxima (%d, %d, %d)", max_static, max_fleet,
                     max_dyn, c.Nstcobs, c.Nother, c.Ndynobs);
     KParams probe = h->kp;
-    if (var_shape < 0 || var_shape > 3) return fail(h, -1, "var_shape must be 0 (shape-constant rows), 1 (rows may change shape), 2 (shape-constant, axis-aligned) or 3 (axis-aligned discs on straight lines), got %d", var_shape);
+    if (var_shape < 0 || var_shape > 2) return fail(h, -1, "var_shape must be 0 (shape-constant rows), 1 (rows may change shape) or 2 (shape-constant, axis-aligned), got %d", var_shape);
     fill_lds_layout(probe, max_static, max_fleet, max_dyn, var_shape != 1, !LBFGS_IN_WORKSPACE);
     if (probe.l_total * (int)sizeof(double) > 160 * 1024) return fail(h, -5, "reserved LDS carve of %d bytes exceeds 160 KiB", probe.l_total * 8);
     h->res_shape[0] = max_static; h->res_shape[1] = max_fleet; h->res_shape[2] = max_dyn; h->res_shape[3] = var_shape;
@@ -927,6 +947,7 @@ int32_t mpcgpu_reserve_batch(void* handle, int32_t B) {
     if (int r = ensure(h, h->evals, (size_t)B * 2 * sizeof(int32_t))) return r;
     if (int r = ensure(h, h->perm, (size_t)B * sizeof(int32_t))) return r;
     if (int r = ensure(h, h->bins, ORD_BINS * sizeof(int))) return r;
+    if (int r = ensure(h, h->nlist, (size_t)B * sizeof(int32_t))) return r;
     // A batch of the latency range is captured in its one-launch form (tables for the configured maxima: more than 64 KiB of
     // dynamic LDS for the yaml's slot counts), whatever form an eager call of the same size takes: opt that kernel in now.
     const int team_cap = h->team_max_batch >= 0 ? h->team_max_batch : 4 * h->num_cus;
@@ -934,7 +955,7 @@ int32_t mpcgpu_reserve_batch(void* handle, int32_t B) {
         KParams kt = h->kp;
         fill_team_layout(kt, TEAM_WAVES, h->cfg.Nstcobs, h->cfg.Nother, h->cfg.Ndynobs);
         const size_t lds_t = kt.l_total * sizeof(double);
-        if (lds_t + 256 <= 160 * 1024) {
+        if (lds_t + PREP_STATIC_LDS <= 160 * 1024) {
             const void* kern = compiled_horizon(h) == 20 ? (const void*)solve_kernel_team<20, TEAM_WAVES>
                              : compiled_horizon(h) == 40 ? (const void*)solve_kernel_team<40, TEAM_WAVES>
                                                          : (const void*)solve_kernel_team<0, TEAM_WAVES>;
@@ -962,8 +983,8 @@ int32_t mpcgpu_set_option(void* handle, int32_t option, double value) {
             h->pairing = (int)value;
             return 0;
         case MPCGPU_OPT_LINEAR_TABLES:
-            if (value != 0.0 && value != 1.0) return fail(h, -1, "linear tables must be 0 (off) or 1 (automatic), got %g", value);
-            h->opt_linear = (int)value;
+            if (value != 0.0 && value != 1.0) return fail(h, -1, "linear tables must be 0 (off) or 1 (on where compiled in), got %g", value);
+            h->opt_linear = (int)value;   // has an effect only in builds with -DMPC_LINEAR40=1 (the variant libmpcgpu_linear40.so)
             return 0;
         case MPCGPU_OPT_ORDER:
             if (value != 0.0 && value != 1.0) return fail(h, -1, "order must be 0 (as given) or 1 (longest first by the previous call), got %g", value);

@@ -91,7 +91,7 @@ _libs = {}
 
 
 def variant_path(name: str) -> str:
-    """Path of a test-only variant build (csrc/Makefile `variants`): 'trace' or 'lbfgs_lds'."""
+    """Path of a test-only variant build (csrc/Makefile `variants`): 'trace', 'lbfgs_lds', 'twoloop', 'onesite', 'linear40'."""
     return os.path.join(_PKG, "variants", f"libmpcgpu_{name}.so")
 
 
@@ -224,7 +224,7 @@ class BatchSolver:
         default: robot i of this tick is robot i of the last one), "as_given" = workgroup g solves problem g (env MPCGPU_ORDER
         overrides None).  Results do not depend on it (bitwise).
         ``linear_tables``: False = never use the linear centre tables (MPCGPU_OPT_LINEAR_TABLES = 0; env MPCGPU_LINEAR_TABLES=0
-        overrides None).  Results do not depend on it (bitwise)."""
+        overrides None; an experiment that only the variant build libmpcgpu_linear40.so carries).  Results do not depend on it."""
         self.config = config if config is not None else MpcConfig()
         self._L = load_library(library)
         self._h = C.c_void_p()
@@ -359,23 +359,20 @@ class BatchSolver:
         self._check(rc, "mpcgpu_solve_batch_dev")
 
     def reserve_shape(self, max_static: Optional[int] = None, max_fleet: Optional[int] = None,
-                      max_dyn: Optional[int] = None, var_shape: bool = True, axis_aligned: bool = False, linear: bool = False):
+                      max_dyn: Optional[int] = None, var_shape: bool = True, axis_aligned: bool = False):
         """Promise upper bounds on the active rows of the following ``solve_device`` batches (``None`` = the
         configured maximum): the launch then needs no count read-back -- it never blocks and can be captured into
         a hipGraph (after ``reserve_batch``).  ``var_shape=False``: every dynamic row keeps (rx, ry, angle, alpha) over
         the horizon (compact tables); with ``axis_aligned=True`` on top: every row has angle 0, what the reference's own
-        prediction feeder produces (src/main.py:77-85); ``linear=True`` on top of that: the centres of every row lie on a
-        straight line up to rounding (constant-velocity predictions; linear centre tables).  Problems that break a promise come
-        back with status 4 (``ShapeExceeded``)."""
+        prediction feeder produces (src/main.py:77-85).  Problems that break a promise come back with status 4
+        (``ShapeExceeded``)."""
         c = self.config
         if axis_aligned and var_shape:
             raise MpcGpuError("axis_aligned=True needs var_shape=False")
-        if linear and not axis_aligned:
-            raise MpcGpuError("linear=True needs axis_aligned=True")
         self._check(self._L.mpcgpu_reserve_shape(
             self._h, int(c.Nstcobs if max_static is None else max_static),
             int(c.Nother if max_fleet is None else max_fleet), int(c.Ndynobs if max_dyn is None else max_dyn),
-            1 if var_shape else ((3 if linear else 2) if axis_aligned else 0)), "mpcgpu_reserve_shape")
+            1 if var_shape else (2 if axis_aligned else 0)), "mpcgpu_reserve_shape")
 
     def reserve_batch(self, B: int):
         """Size the library-owned device buffers for batches of up to ``B`` problems now (needed before a
