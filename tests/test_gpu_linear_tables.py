@@ -14,7 +14,8 @@ from trajtrack_mpcndqn_rlboost_amd import BatchSolver, scenes
 from trajtrack_mpcndqn_rlboost_amd.feeders import constant_velocity_prediction
 from trajtrack_mpcndqn_rlboost_amd.solver import variant_path
 
-LIN = variant_path("linear40")
+LIN = variant_path("linear40")      # built on the row walk of the dynamic rows (as measured): compared with that build
+ROW = variant_path("rowwalk40")
 
 pytestmark = pytest.mark.gpu
 
@@ -31,7 +32,7 @@ def test_linear_tables_give_the_bits_of_the_stored_centres(family):
     B = 6144                                          # more than the 3072 problems the three-wavefront build keeps resident
     sc = scenes.make_family(cfg, B, family, seed=404)
     lin = BatchSolver(cfg, latency_batch=0, order="as_given", library=LIN)
-    ref = BatchSolver(cfg, latency_batch=0, order="as_given")
+    ref = BatchSolver(cfg, latency_batch=0, order="as_given", library=ROW)
     ra, rb = lin.solve(sc["p"]), ref.solve(sc["p"])
     sa, sb = lin.last_shape(), ref.last_shape()
     assert sa["linear"] and sa["waves_per_simd"] == 4 and sa["lds_bytes"] <= 10240
@@ -58,7 +59,7 @@ def test_the_reference_feeder_is_linear_and_a_curved_row_is_not():
     last = cur - rng.uniform(-0.3, 0.3, (B, 4, 2))
     p[:, off["od"]:off["od"] + 4 * 6 * N] = constant_velocity_prediction(last, cur, steps=N).reshape(B, -1)
     bs = BatchSolver(cfg, latency_batch=0, library=LIN)
-    ref = BatchSolver(cfg, latency_batch=0)
+    ref = BatchSolver(cfg, latency_batch=0, library=ROW)
     ra, rb = bs.solve(p), ref.solve(p)
     assert bs.last_shape()["linear"]
     _same(ra, rb)
@@ -95,7 +96,7 @@ def test_cost_and_gradient_through_the_linear_tables_are_bitwise_the_stored_ones
     u = rng.uniform(-0.4, 1.2, (B, 80))
     y = rng.normal(0, 1.0, (B, 80))
     a = BatchSolver(cfg, library=LIN)
-    b = BatchSolver(cfg)
+    b = BatchSolver(cfg, library=ROW)
     ga = a.cost_grad(u, sc["p"], c=np.full(B, 50.0), y=y)
     gb = b.cost_grad(u, sc["p"], c=np.full(B, 50.0), y=y)
     assert a.last_shape()["linear"] and not b.last_shape()["linear"]

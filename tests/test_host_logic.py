@@ -114,7 +114,7 @@ def test_variant_builds_export_the_abi_and_their_debug_hooks():
     its two debug entry points, the product library must not carry them."""
     prod = ctypes.CDLL(solver_mod.library_path())
     assert not hasattr(prod, "mpcgpu_debug_set_trace") and not hasattr(prod, "mpcgpu_debug_read_trace")
-    for name in ("trace", "lbfgs_lds", "twoloop", "onesite", "linear40"):
+    for name in ("trace", "lbfgs_lds", "twoloop", "onesite", "linear40", "rowwalk40"):
         path = solver_mod.variant_path(name)
         assert os.path.exists(path), f"{path} missing -- run __graft_entry__.build()"
         lib = ctypes.CDLL(path)

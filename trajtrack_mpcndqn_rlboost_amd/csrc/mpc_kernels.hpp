@@ -108,7 +108,7 @@ struct KParams {
     // LDS layout (doubles), strides use the batch maxima mKs/mKf/mKd
     int mKs, mKf, mKd;
     int reserved;  // 1: the carve comes from mpcgpu_reserve_shape, problems are checked against it on the device
-    int l_seg, l_stc, l_fxy, l_dyn, l_dync, l_dynl, l_qd, l_pos, l_H, l_W, l_part, l_stash, l_hd, l_S, l_Y, l_rho, l_alpha, l_old, l_gg, l_total;
+    int l_seg, l_stc, l_fxy, l_dyn, l_dync, l_dynl, l_qd, l_pos, l_H, l_W, l_part, l_bal, l_stash, l_hd, l_S, l_Y, l_rho, l_alpha, l_old, l_gg, l_total;
     int l_wstride, l_xch;  // team kernel (mpc_team.hpp): doubles per wavefront work block, offset of the exchange area
 };
 
@@ -127,7 +127,7 @@ struct KParams {
 // address arithmetic beyond the lane's own scaled index.  The host (mpcgpu.hip fill_lds_layout / fill_team_layout) fills
 // KParams::l_* from the SAME function, so the generic kernel and the latency kernel read the identical layout at run time.
 // ------------------------------------------------------------------------------------------------
-struct FixedLds { int hd, seg, pos, stash, part, W, rho, gg, S, Y, old, end; };
+struct FixedLds { int hd, seg, pos, stash, part, W, bal, rho, gg, S, Y, old, end; };
 __host__ __device__ constexpr int even_c(int x) { return (x + 1) & ~1; }
 // (N_hor = 40 as well since the stash-free 168-register kernel: see stash_stride_c)
 __host__ __device__ constexpr bool gram_shape(int N, int mem) { return MPC_LBFGS_GRAM && (N == 20 || N == 40) && mem == 10; }
@@ -152,6 +152,14 @@ __host__ __device__ constexpr int part_doubles_c(int N, int mem) {
 // `minw`: wavefronts per SIMD the kernel is compiled for.  The 128-register build of the long horizon (minw = 4, round 4) cannot
 // carry the four Simpson values through the item phase: it parks them (stride 4; (v, w) stay in registers -- with all six parked
 // the carve of the benchmark shape would be 10 704 B, over the 10 240 B that sixteen wavefronts per compute unit allow).
+// Balanced walk of the dynamic rows where the item lanes do not divide the steps evenly (N_hor = 40: steps 0-23 have two item
+// lanes, steps 24-39 one): see eval_point.  0 = the row walk of rounds 1-3 (`make variants`: libmpcgpu_rowwalk40.so).
+#ifndef MPC_BALANCED40
+#define MPC_BALANCED40 1
+#endif
+__host__ __device__ constexpr bool balanced_shape(int N, int mem) { return MPC_BALANCED40 && N == 40 && mem == 10; }
+// gradient accumulators of the single-lane steps (2 doubles each) that the helper lanes add their foreign items to
+__host__ __device__ constexpr int bal_doubles_c(int N, int mem) { return balanced_shape(N, mem) ? 2 * (N - (64 - N)) : 0; }
 #ifndef MPC_STW40_W4
 #define MPC_STW40_W4 4   // experiment knob of round 4 (6: all six values parked, 14 wavefronts per compute unit)
 #endif
@@ -185,6 +193,7 @@ __host__ __device__ constexpr FixedLds fixed_lds(int N, int mem, bool lbfgs_in_l
     // order): one region
     f.part = o; f.W = o + HW_ROWS;
     { const int ps = part_doubles_c(N, mem); o += ps > 2 * HW_ROWS ? ps : 2 * HW_ROWS; }
+    f.bal = o; o += bal_doubles_c(N, mem);
     f.rho = o; o += even_c(mem);
     f.gg = o;   // Gram matrices s_i.y_j (full) + y_i.y_j (packed symmetric), or the alpha scratch of the two-loop form
     o += gram_shape(N, mem) ? even_c(mem * mem + mem * (mem + 1) / 2) : even_c(mem);
@@ -751,6 +760,8 @@ struct Ctx {
     double vref;  // vector lane k: speed reference of step k
     // LDS tables
     double *seg, *stc, *fxy, *dyn, *dync, *pos, *H, *W, *part, *stash;
+    double* bal;               // balanced walk: (gx, gy) accumulators of the single-lane steps
+    int balT, balT2;           // ... its trip counts (from Kd): every lane makes balT trips, the two-lane steps balT2 of their own
     const double* dynl;        // linear centre tables: [Kd][DYNL]
     const unsigned* dynr;      // ... and the residuals of every (row, step): signed 16-bit multiples of the row's unit, x low, y high
 };
@@ -794,8 +805,17 @@ __device__ __forceinline__ void load_problem(const KParams& kp, const double* __
     cx.dynl = lds + kp.l_dynl; cx.dynr = reinterpret_cast<const unsigned*>(lds + kp.l_dyn);   // LIN: the residuals take the place of the centres
     if (FIXED) {
         cx.seg = lds + FL.seg; cx.pos = lds + FL.pos; cx.stash = lds + FL.stash; cx.H = lds + FL.part; cx.W = lds + FL.W; cx.part = lds + FL.part;
+        cx.bal = lds + FL.bal;
     } else {
         cx.seg = lds + kp.l_seg; cx.pos = lds + kp.l_pos; cx.stash = lds + kp.l_stash; cx.H = lds + kp.l_H; cx.W = lds + kp.l_W; cx.part = lds + kp.l_part;
+        cx.bal = lds + kp.l_bal;
+    }
+    {   // balanced walk of the dynamic rows (eval_point): the two-lane steps own ceil(Kd / 2) trips; T = the smallest trip count at
+        // which the rows T.. of the single-lane steps fit into the spare trips of the helper lanes
+        const int ns1 = N - (P::W - N), nh = 2 * (P::W - N);
+        int t2 = (cx.Kd + 1) / 2, T = t2;
+        while (ns1 > 0 && (cx.Kd - T) * ns1 > nh * (T - t2)) ++T;
+        cx.balT = T; cx.balT2 = t2;
     }
     // coalesced table copies HBM -> LDS (only the active entries of this problem)
     for (int i = lane; i < N * SEGW; i += P::W) cx.seg[i] = ws[kp.ws_seg + i];
@@ -933,6 +953,9 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     const double X = HD(H_X0) + pX;
     const double Y = HD(H_Y0) + pY;
     if (lane < cx.Kd) cx.H[lane] = zero_here();   // row sums of the hard-constraint hinges, accumulated by the item lanes below
+    if (bal_doubles_c(NT ? NT : 2, MemOf<NT>::value ? MemOf<NT>::value : 1) && !P::DUO && want_grad &&
+        lane < bal_doubles_c(NT ? NT : 2, MemOf<NT>::value ? MemOf<NT>::value : 1))
+        cx.bal[lane] = zero_here();                // balanced walk: gradient accumulators of the single-lane steps
     if (c_vl) {
         cx.pos[2 * lane] = X; cx.pos[2 * lane + 1] = Y;
         // rollout quantities needed again only after the item phase (per-step terms, adjoint): parked in LDS so
@@ -961,7 +984,29 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     constexpr bool HM = !UNIFORM;
     unsigned hmask = 0u;
     const int minLPS = UNIFORM ? PW / N : (PW - N) / N + 1;
-    const int ntrip = HM ? (cx.Kd + minLPS - 1) / minLPS : 0;
+    // BALANCED WALK (round 4, N_hor = 40).  Steps 0 .. NL2-1 have two item lanes, the NS1 steps behind them ONE: walking the rows
+    // step by step, those lanes make Kd trips while the others are done after Kd / 2 -- and the wavefront waits for them.  Here
+    // every lane makes balT trips: the lane of a single-lane step takes rows 0 .. balT-1 of its step, the NH lanes of the two-lane
+    // steps take their own ceil(Kd / 2) rows and then FOREIGN items -- rows balT.. of the single-lane steps (Kd = 8: five trips
+    // instead of eight).  A foreign item reads the position of its step from LDS and adds its gradient to that step's
+    // accumulator in LDS (cx.bal; ds_add_f64, rare: only inside an ellipse); cost terms are wave-summed anyway and the hinge
+    // row sums are LDS atomics already.  Another summation order than the row walk for the steps of the second part of the horizon.
+    constexpr bool BAL = NT != 0 && !UNIFORM && !P::DUO && balanced_shape(NT ? NT : 2, MemOf<NT>::value ? MemOf<NT>::value : 1);
+    constexpr int NL2 = NT ? PW - NT : 0, NS1 = NT ? NT - NL2 : 1, NH = 2 * NL2;
+    const bool owner1 = BAL && lane >= NL2 && lane < N;      // the only item lane of its step
+    const int hid = lane < NL2 ? lane : lane - N + NL2;      // helper index 0 .. NH-1 of the lanes of the two-lane steps
+    const int ntrip = BAL ? cx.balT : HM ? (cx.Kd + minLPS - 1) / minLPS : 0;
+    // (row, step, position, foreign?) of this lane's item in trip t
+    auto trip_item = [&](int t, int k_own, double px_own, double py_own, int& i, int& kk, double& qx, double& qy) -> bool {
+        i = c_isub + t * LPS; kk = k_own; qx = px_own; qy = py_own;
+        if (BAL && !owner1 && t >= cx.balT2) {
+            const int f = hid + NH * (t - cx.balT2);
+            i = cx.balT + f / NS1; kk = NL2 + f % NS1;
+            if (i < cx.Kd) { qx = cx.pos[2 * kk]; qy = cx.pos[2 * kk + 1]; }
+            return true;
+        }
+        return false;
+    };
     if (c_il) {
         const int k = c_ik;
         px = cx.pos[2 * k]; py = cx.pos[2 * k + 1];
@@ -1057,6 +1102,46 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         PROF_MARK(3);  // fleet + static
         // dynamic ellipses: hard indicator -> H, soft cost with social margin (mpc_generator.py:229-241,38-44,85-95)
         // one body for both walks: HM: t = 0 .. ntrip-1 for every lane, row c_isub + t LPS if it exists; else i = c_isub, c_isub + LPS ...
+        if (BAL) {
+            MPC_ITEM_LOOP
+            for (int t = 0; t < ntrip; ++t) {
+                bool inside = false;
+                int i, kk; double qx, qy;
+                const bool foreign = trip_item(t, k, px, py, i, kk, qx, qy);
+                if (i < cx.Kd) {
+                    const DynItem d = dyn_item<SC, AXIS, LIN>(cx, i, kk, N, qx, qy);
+                    const double a2 = d.a * d.a, b2 = d.b * d.b;
+                    const double Ih = 1.0 - a2 * d.ihx - b2 * d.ihy;
+                    inside = Ih > 0.0;
+                    anyh |= inside;
+                    if (Ih > 0.0) lds_add(cx.H + i, Ih);
+                    const double Is = 1.0 - a2 * d.isx - b2 * d.isy;
+                    if (Is > 0.0) {
+                        cost_l += d.wgt * Is * Is;
+                        const double wI = 2.0 * d.wgt * Is;
+                        if (!foreign) {   // the expressions of the row walk, term for term
+                            if (AXIS) {
+                                gx += wI * (-2.0 * d.a * d.isx);
+                                gy += wI * (2.0 * d.b * d.isy);
+                            } else {
+                                gx += wI * (-2.0 * d.a * d.ca * d.isx - 2.0 * d.b * d.sa * d.isy);
+                                gy += wI * (-2.0 * d.a * d.sa * d.isx + 2.0 * d.b * d.ca * d.isy);
+                            }
+                        } else if (want_grad) {
+                            double* acc = cx.bal + 2 * (kk - NL2);
+                            if (AXIS) {
+                                lds_add(acc, wI * (-2.0 * d.a * d.isx));
+                                lds_add(acc + 1, wI * (2.0 * d.b * d.isy));
+                            } else {
+                                lds_add(acc, wI * (-2.0 * d.a * d.ca * d.isx - 2.0 * d.b * d.sa * d.isy));
+                                lds_add(acc + 1, wI * (-2.0 * d.a * d.sa * d.isx + 2.0 * d.b * d.ca * d.isy));
+                            }
+                        }
+                    }
+                }
+                if (P::any(inside)) hmask |= 1u << t;
+            }
+        } else {
         MPC_ITEM_LOOP
         for (int t = 0, i = c_isub; HM ? t < ntrip : i < cx.Kd; ++t, i += LPS) {
             bool inside = false;
@@ -1081,6 +1166,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
                 }
             }
             if (HM && P::any(inside)) hmask |= 1u << t;
+        }
         }
     }
     if (HM) hmask = P::uni_u(hmask);
@@ -1131,7 +1217,38 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         wave_sync();
         if (c_il) {
             const int k = c_ik;
-            if (any_h) {
+            if (any_h && BAL) {
+                MPC_ITEM_LOOP
+                for (int t = 0; t < ntrip; ++t) {
+                    if (!((hmask >> t) & 1u)) continue;                        // no lane of this trip is inside a hard ellipse
+                    int i, kk; double qx, qy;
+                    const bool foreign = trip_item(t, k, px, py, i, kk, qx, qy);
+                    if (i >= cx.Kd) continue;
+                    const DynItem d = dyn_item<SC, AXIS, LIN>(cx, i, kk, N, qx, qy);
+                    const double Ih = 1.0 - d.a * d.a * d.ihx - d.b * d.b * d.ihy;
+                    if (Ih > 0.0) {
+                        const double wi = cx.W[i];
+                        if (!foreign) {
+                            if (AXIS) {
+                                gx += wi * (-2.0 * d.a * d.ihx);
+                                gy += wi * (2.0 * d.b * d.ihy);
+                            } else {
+                                gx += wi * (-2.0 * d.a * d.ca * d.ihx - 2.0 * d.b * d.sa * d.ihy);
+                                gy += wi * (-2.0 * d.a * d.sa * d.ihx + 2.0 * d.b * d.ca * d.ihy);
+                            }
+                        } else {
+                            double* acc = cx.bal + 2 * (kk - NL2);
+                            if (AXIS) {
+                                lds_add(acc, wi * (-2.0 * d.a * d.ihx));
+                                lds_add(acc + 1, wi * (2.0 * d.b * d.ihy));
+                            } else {
+                                lds_add(acc, wi * (-2.0 * d.a * d.ca * d.ihx - 2.0 * d.b * d.sa * d.ihy));
+                                lds_add(acc + 1, wi * (-2.0 * d.a * d.sa * d.ihx + 2.0 * d.b * d.ca * d.ihy));
+                            }
+                        }
+                    }
+                }
+            } else if (any_h) {
                 MPC_ITEM_LOOP
                 for (int t = 0, i = c_isub; HM ? t < ntrip : i < cx.Kd; ++t, i += LPS) {
                     if (HM && (!((hmask >> t) & 1u) || i >= cx.Kd)) continue;   // no lane of this trip is inside a hard ellipse
@@ -1180,6 +1297,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
             Gx += pp[0]; Gy += pp[1];
             if (pp[2] < bb) { bb = pp[2]; wbx = pp[3]; wby = pp[4]; }
         }
+        if (BAL && want_grad && lane >= NL2) { Gx += cx.bal[2 * (lane - NL2)]; Gy += cx.bal[2 * (lane - NL2) + 1]; }   // foreign items of this step
         Gx += HD(H_QRPD) * wbx; Gy += HD(H_QRPD) * wby;
         vcost = HD(H_QRPD) * bb;
         if (cx.pad_f && kp.W2 - r2o > 0.0) {

@@ -203,7 +203,7 @@ void fill_lds_layout(KParams& k, int mKs, int mKf, int mKd, bool shape_const, bo
     // fixed part first (compile-time offsets in the kernels with a compiled horizon), then the tables that follow the batch
     const FixedLds f = fixed_lds(N, k.mem, lbfgs_in_lds, minw);
     k.l_hd = f.hd; k.l_seg = f.seg; k.l_pos = f.pos; k.l_stash = f.stash;
-    k.l_H = f.part; k.l_W = f.W; k.l_part = f.part;
+    k.l_H = f.part; k.l_W = f.W; k.l_part = f.part; k.l_bal = f.bal;
     k.l_rho = f.rho; k.l_alpha = f.gg; k.l_gg = f.gg;
     k.l_S = f.S; k.l_Y = f.Y; k.l_old = f.old;
     int o = f.end;
@@ -249,6 +249,7 @@ void fill_team_layout(KParams& k, int tw, int mKs, int mKf, int mKd) {
     const int h_sz = h_rows + even(k.mKd), part_sz = part_doubles(k);
     k.l_H = o; k.l_W = o + h_rows; k.l_part = o;
     o += h_sz > part_sz ? h_sz : part_sz;
+    k.l_bal = o; o += bal_doubles_c(k.N, k.mem);   // balanced walk of the dynamic rows (eval_point): per wavefront
     k.l_S = o; o += k.mem * N * 2;
     k.l_Y = o; o += k.mem * N * 2 + N * 2;  // + the zero row
     k.l_rho = o; o += even(k.mem);
