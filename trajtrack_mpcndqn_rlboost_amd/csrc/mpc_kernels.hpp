@@ -998,8 +998,8 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     const int ntrip = BAL ? cx.balT : HM ? (cx.Kd + minLPS - 1) / minLPS : 0;
     // (row, step, position, foreign?) of this lane's item in trip t
     auto trip_item = [&](int t, int k_own, double px_own, double py_own, int& i, int& kk, double& qx, double& qy) -> bool {
-        i = c_isub + t * LPS; kk = k_own; qx = px_own; qy = py_own;
-        if (BAL && !owner1 && t >= cx.balT2) {
+        i = c_isub + t * LPS; kk = k_own; qx = px_own; qy = py_own;      // (a single-lane step: LPS = 1, row t)
+        if (BAL && !owner1) {                                            // called for the trips t >= balT2 only
             const int f = hid + NH * (t - cx.balT2);
             i = cx.balT + f / NS1; kk = NL2 + f % NS1;
             if (i < cx.Kd) { qx = cx.pos[2 * kk]; qy = cx.pos[2 * kk + 1]; }
@@ -1103,42 +1103,53 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         // dynamic ellipses: hard indicator -> H, soft cost with social margin (mpc_generator.py:229-241,38-44,85-95)
         // one body for both walks: HM: t = 0 .. ntrip-1 for every lane, row c_isub + t LPS if it exists; else i = c_isub, c_isub + LPS ...
         if (BAL) {
-            MPC_ITEM_LOOP
-            for (int t = 0; t < ntrip; ++t) {
-                bool inside = false;
-                int i, kk; double qx, qy;
-                const bool foreign = trip_item(t, k, px, py, i, kk, qx, qy);
-                if (i < cx.Kd) {
-                    const DynItem d = dyn_item<SC, AXIS, LIN>(cx, i, kk, N, qx, qy);
-                    const double a2 = d.a * d.a, b2 = d.b * d.b;
-                    const double Ih = 1.0 - a2 * d.ihx - b2 * d.ihy;
-                    inside = Ih > 0.0;
-                    anyh |= inside;
-                    if (Ih > 0.0) lds_add(cx.H + i, Ih);
-                    const double Is = 1.0 - a2 * d.isx - b2 * d.isy;
-                    if (Is > 0.0) {
-                        cost_l += d.wgt * Is * Is;
-                        const double wI = 2.0 * d.wgt * Is;
-                        if (!foreign) {   // the expressions of the row walk, term for term
-                            if (AXIS) {
-                                gx += wI * (-2.0 * d.a * d.isx);
-                                gy += wI * (2.0 * d.b * d.isy);
-                            } else {
-                                gx += wI * (-2.0 * d.a * d.ca * d.isx - 2.0 * d.b * d.sa * d.isy);
-                                gy += wI * (-2.0 * d.a * d.sa * d.isx + 2.0 * d.b * d.ca * d.isy);
-                            }
-                        } else if (want_grad) {
-                            double* acc = cx.bal + 2 * (kk - NL2);
-                            if (AXIS) {
-                                lds_add(acc, wI * (-2.0 * d.a * d.isx));
-                                lds_add(acc + 1, wI * (2.0 * d.b * d.isy));
-                            } else {
-                                lds_add(acc, wI * (-2.0 * d.a * d.ca * d.isx - 2.0 * d.b * d.sa * d.isy));
-                                lds_add(acc + 1, wI * (-2.0 * d.a * d.sa * d.isx + 2.0 * d.b * d.ca * d.isy));
-                            }
+            // one (row, step) item of phase A; `foreign`: the step is not this lane's own -- its gradient goes to the step's accumulator
+            auto dyn_a = [&](int i, int kk, double qx, double qy, bool foreign) -> bool {
+                const DynItem d = dyn_item<SC, AXIS, LIN>(cx, i, kk, N, qx, qy);
+                const double a2 = d.a * d.a, b2 = d.b * d.b;
+                const double Ih = 1.0 - a2 * d.ihx - b2 * d.ihy;
+                if (Ih > 0.0) lds_add(cx.H + i, Ih);
+                const double Is = 1.0 - a2 * d.isx - b2 * d.isy;
+                if (Is > 0.0) {
+                    cost_l += d.wgt * Is * Is;
+                    const double wI = 2.0 * d.wgt * Is;
+                    if (!foreign) {   // the expressions of the row walk, term for term
+                        if (AXIS) {
+                            gx += wI * (-2.0 * d.a * d.isx);
+                            gy += wI * (2.0 * d.b * d.isy);
+                        } else {
+                            gx += wI * (-2.0 * d.a * d.ca * d.isx - 2.0 * d.b * d.sa * d.isy);
+                            gy += wI * (-2.0 * d.a * d.sa * d.isx + 2.0 * d.b * d.ca * d.isy);
+                        }
+                    } else if (want_grad) {
+                        double* acc = cx.bal + 2 * (kk - NL2);
+                        if (AXIS) {
+                            lds_add(acc, wI * (-2.0 * d.a * d.isx));
+                            lds_add(acc + 1, wI * (2.0 * d.b * d.isy));
+                        } else {
+                            lds_add(acc, wI * (-2.0 * d.a * d.ca * d.isx - 2.0 * d.b * d.sa * d.isy));
+                            lds_add(acc + 1, wI * (-2.0 * d.a * d.sa * d.isx + 2.0 * d.b * d.ca * d.isy));
                         }
                     }
                 }
+                return Ih > 0.0;
+            };
+            // trips 0 .. balT2-1: every lane walks rows of its own step (the row walk, unchanged) ...
+            MPC_ITEM_LOOP
+            for (int t = 0, i = c_isub; t < cx.balT2; ++t, i += LPS) {
+                bool inside = false;
+                if (i < cx.Kd) inside = dyn_a(i, k, px, py, false);
+                anyh |= inside;
+                if (P::any(inside)) hmask |= 1u << t;
+            }
+            // ... trips balT2 .. balT-1: the single-lane steps go on with their rows, the other lanes take foreign items
+            MPC_ITEM_LOOP
+            for (int t = cx.balT2; t < ntrip; ++t) {
+                bool inside = false;
+                int i, kk; double qx, qy;
+                const bool foreign = trip_item(t, k, px, py, i, kk, qx, qy);
+                if (i < cx.Kd) inside = dyn_a(i, kk, qx, qy, foreign);
+                anyh |= inside;
                 if (P::any(inside)) hmask |= 1u << t;
             }
         } else {
@@ -1218,12 +1229,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         if (c_il) {
             const int k = c_ik;
             if (any_h && BAL) {
-                MPC_ITEM_LOOP
-                for (int t = 0; t < ntrip; ++t) {
-                    if (!((hmask >> t) & 1u)) continue;                        // no lane of this trip is inside a hard ellipse
-                    int i, kk; double qx, qy;
-                    const bool foreign = trip_item(t, k, px, py, i, kk, qx, qy);
-                    if (i >= cx.Kd) continue;
+                auto dyn_b = [&](int i, int kk, double qx, double qy, bool foreign) {
                     const DynItem d = dyn_item<SC, AXIS, LIN>(cx, i, kk, N, qx, qy);
                     const double Ih = 1.0 - d.a * d.a * d.ihx - d.b * d.b * d.ihy;
                     if (Ih > 0.0) {
@@ -1247,6 +1253,18 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
                             }
                         }
                     }
+                };
+                MPC_ITEM_LOOP
+                for (int t = 0, i = c_isub; t < cx.balT2; ++t, i += LPS) {
+                    if (!((hmask >> t) & 1u) || i >= cx.Kd) continue;          // no lane of this trip is inside a hard ellipse
+                    dyn_b(i, k, px, py, false);
+                }
+                MPC_ITEM_LOOP
+                for (int t = cx.balT2; t < ntrip; ++t) {
+                    if (!((hmask >> t) & 1u)) continue;
+                    int i, kk; double qx, qy;
+                    const bool foreign = trip_item(t, k, px, py, i, kk, qx, qy);
+                    if (i < cx.Kd) dyn_b(i, kk, qx, qy, foreign);
                 }
             } else if (any_h) {
                 MPC_ITEM_LOOP
