@@ -293,6 +293,13 @@ int32_t mpcgpu_workspace_record(void* handle);
  * workspace records and return when they are complete). */
 int32_t mpcgpu_debug_prep(void* handle, int32_t B, const double* p);
 int32_t mpcgpu_debug_tracker_assemble(void* handle, const mpcgpu_tracker* t, const double* refs);
+/* Test hook (ABI 6; compiled horizons N_hor = 20 / 40): the L-BFGS operator of PANOC alone.  U, R [B][m + 1][2N]: a recorded
+ * sequence of iterates u_j and residuals gamma*fpr_j; they are fed to the buffer the way the solver feeds it (pairs
+ * s = u_j - u_{j-1}, y = r_j - r_{j-1}, C-BFGS acceptance, memory 10) and d = H r_m comes back twice: evaluated in the Gram form the
+ * product kernels use (d_gram) and by the two-loop recursion of the `lbfgs` crate (d_twoloop), [B][2N] each; pairs [B][2] =
+ * accepted pairs in the buffer of either form (may be NULL).  HOST pointers. */
+int32_t mpcgpu_debug_lbfgs_direction(void* handle, int32_t B, int32_t m, const double* U, const double* R, double* d_gram,
+                                     double* d_twoloop, int32_t* pairs);
 
 #ifdef __cplusplus
 }

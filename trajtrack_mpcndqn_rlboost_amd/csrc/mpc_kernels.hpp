@@ -361,11 +361,21 @@ __device__ __forceinline__ double here_s(double x) { asm volatile("" : "+s"(x));
 __device__ __forceinline__ double zero_here() { double z = 0.0; asm volatile("" : "+v"(z)); return z; }
 
 // inclusive prefix PRODUCT of unit complex numbers (re, im) over lanes 0..16*ROWS-1 (lanes >= n carry 1+0i)
+// x moved by DPP, lanes without a source (or in rows that are masked off) receive 1.0.  The low word of 1.0 is zero: where every
+// row is written it travels in the zero-filling form and only the high word needs its fill value preloaded.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_one(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    if (ROW_MASK == 0xf) lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+    else lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0x3ff00000, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ void cmul_step(double& re, double& im) {
     // identity element 1 + 0i for lanes without a source: the real part needs its fill value preloaded, the imaginary part is the
     // zero-filling form (two v_mov less per step)
-    const double pr = dppf<CTRL, ROW_MASK>(re, 1.0), pi = dpp0<CTRL, ROW_MASK>(im);
+    const double pr = dpp_one<CTRL, ROW_MASK>(re), pi = dpp0<CTRL, ROW_MASK>(im);
     const double nr = re * pr - im * pi, ni = re * pi + im * pr;
     re = nr; im = ni;
 }
@@ -447,6 +457,24 @@ struct Solo {
     template <int ROWS> static __device__ __forceinline__ double prefix(double x) { return scan_prefix<ROWS>(x); }
     template <int ROWS> static __device__ __forceinline__ void cprod(double& re, double& im) { scan_cprod<ROWS>(re, im); }
     template <int ROWS> static __device__ __forceinline__ double suffix(double x, int lane) { return scan_suffix<ROWS>(x, lane); }
+    // two inclusive suffix sums over the vector lanes for the price of one when they fit half a wavefront (b travels in rows 2-3,
+    // like prefix2): the same additions in the same order per element, bitwise the two separate scans
+    template <int ROWS> static __device__ __forceinline__ void suffix2(double a, double b, int lane, double& sa, double& sb) {
+        if (ROWS <= 2) {
+            auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+            auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+            double x = __hiloint2double((int)hi[0], (int)lo[0]);   // lanes 0..31: a, lanes 32..63: b (its lanes 0..31)
+            x = row_suffix(x);
+            if (ROWS > 1) {   // rows 0 / 2 add the (completed) first lane of rows 1 / 3
+                const double t1 = readlane_d(x, 16), t3 = readlane_d(x, 48);
+                if ((lane & 31) < 16) x += (lane < 32 ? t1 : t3);
+            }
+            lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(x), false, false);
+            hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(x), false, false);
+            sa = x;
+            sb = __hiloint2double((int)hi[1], (int)lo[1]);
+        } else { sa = scan_suffix<ROWS>(a, lane); sb = scan_suffix<ROWS>(b, lane); }
+    }
     static __device__ __forceinline__ double from_lane(double x, int l) { return readlane_d(x, l); }
     // two inclusive prefix sums over the vector lanes for the price of one when they fit half a wavefront: b travels in rows 2-3
     // (v_permlane32_swap), one DPP sequence serves both halves, b comes back the same way.  Bitwise the two separate scans.
@@ -485,6 +513,7 @@ struct Duo {
     template <int ROWS> static __device__ __forceinline__ double prefix(double x) { return scan_prefix<2>(x); }
     template <int ROWS> static __device__ __forceinline__ void cprod(double& re, double& im) { scan_cprod<2>(re, im); }
     template <int ROWS> static __device__ __forceinline__ double suffix(double x, int) { return half_suffix(x); }
+    template <int ROWS> static __device__ __forceinline__ void suffix2(double a, double b, int, double& sa, double& sb) { sa = half_suffix(a); sb = half_suffix(b); }
     static __device__ __forceinline__ double from_lane(double x, int l) { return half_allsum(lane() == l ? x : 0.0); }
     template <int ROWS> static __device__ __forceinline__ void prefix2(double a, double b, double& pa, double& pb) {
         pa = scan_prefix<2>(a); pb = scan_prefix<2>(b);
@@ -1084,10 +1113,12 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         MPC_ITEM_LOOP
         for (int o = c_isub; o < cx.Ks; o += LPS) {
             const double* s = cx.stc + STCW * o;
-            const double m0 = fmax(0.0, s[0] - s[4] * px - s[8] * py);
-            const double m1 = fmax(0.0, s[1] - s[5] * px - s[9] * py);
-            const double m2 = fmax(0.0, s[2] - s[6] * px - s[10] * py);
-            const double m3 = fmax(0.0, s[3] - s[7] * px - s[11] * py);
+            const double h0 = s[0] - s[4] * px - s[8] * py, h1 = s[1] - s[5] * px - s[9] * py;
+            const double h2 = s[2] - s[6] * px - s[10] * py, h3 = s[3] - s[7] * px - s[11] * py;
+            // a point outside (some half-plane value <= 0) has the product exactly 0: the squares and products are formed only in
+            // the trips in which some lane is inside a polygon
+            if (!P::any(fmin(fmin(h0, h1), fmin(h2, h3)) > 0.0)) continue;
+            const double m0 = fmax(0.0, h0), m1 = fmax(0.0, h1), m2 = fmax(0.0, h2), m3 = fmax(0.0, h3);
             const double q0 = m0 * m0, q1 = m1 * m1, q2 = m2 * m2, q3 = m3 * m3;
             const double p01 = q0 * q1, p23 = q2 * q3;
             const double prod = p01 * p23;
@@ -1182,8 +1213,8 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     }
     if (HM) hmask = P::uni_u(hmask);
     PROF_MARK(4);  // dynamic
-    double X = 0.0, Y = 0.0;  // position of this vector lane's step, back from LDS
-    if (c_vl) { X = cx.pos[2 * lane]; Y = cx.pos[2 * lane + 1]; }
+    // position of this vector lane's step: lane k < N is item lane (k, sub 0), px / py hold it already
+    const double X = c_vl ? px : 0.0, Y = c_vl ? py : 0.0;
     // zero-padded rows, closed form on the vector lanes: npf discs of radius W and npd degenerate ellipses
     // (semi-axes 1e-6, alpha = 0: hard indicator only) at the origin
     double hp = 0.0, r2o = 0.0;
@@ -1378,7 +1409,8 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         // (kept in registers they are finite beyond the horizon, where v = 0 and the adjoint sums Ax, Ay are 0: same bits)
         double Cx = kCx, Sy = kSy, dCw = kdCw, dSw = kdSw;
         if (STW >= 4 && c_vl) { const double* st = cx.stash + lane * STW; Cx = st[0]; Sy = st[1]; dCw = st[2]; dSw = st[3]; }
-        const double Ax = P::template suffix<RV>(Gx, lane), Ay = P::template suffix<RV>(Gy, lane);
+        double Ax, Ay;
+        P::template suffix2<RV>(Gx, Gy, lane, Ax, Ay);
         const double T = ts * v * (-Sy * Ax + Cx * Ay);   // v = 0 and finite factors beyond the horizon: a (signed) zero there
         const double Bx = P::template suffix<RV>(T, lane) - T;
         gv += ts * (Cx * Ax + Sy * Ay);
@@ -1952,6 +1984,57 @@ template <int NT> struct GramFor { static constexpr bool value = MPC_LBFGS_GRAM 
 template <bool DUO, int NT> struct LbfgsOf { using type = PanocLbfgs; };
 template <> struct LbfgsOf<false, 40> { using type = std::conditional<gram_shape(40, 10), PanocLbfgsGram, PanocLbfgs>::type; };
 template <> struct LbfgsOf<false, 20> { using type = std::conditional<GramFor<20>::value, PanocLbfgsGram, PanocLbfgs>::type; };
+
+// ------------------------------------------------------------------------------------------------
+// test-hook kernel: the L-BFGS operator alone.  A recorded sequence of iterates and residuals (u_j, gamma fpr_j), j = 0 .. m, is
+// fed to the buffer exactly as solve_body feeds it (update, then the direction from the last residual) -- once through the
+// Gram form, once through the two-loop recursion -- and both directions come back (tests/test_gpu_baseline_parity.py compares
+// them with each other and with a host restatement of the `lbfgs` crate's recursion, oracle/mpc_oracle.c:406-449).
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(WAVE) void lbfgs_direction_kernel(KParams kp, double* __restrict__ wsb, const double* __restrict__ U,
+                                                               const double* __restrict__ R, int m, double* d_gram, double* d_two,
+                                                               int32_t* pairs, int B) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    using P = Solo<NT>;
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    const int lane = threadIdx.x, N = NT, mem = kp.mem;
+    constexpr int MEMT = MemOf<NT>::value;
+    constexpr FixedLds FL = fixed_lds(NT, MEMT, false);
+    Ctx cx{};
+    double* hd = lds + FL.hd;
+    if (lane < 27) hd[KC_BASE + lane] = KTAB[lane];
+    cx.hd = hd; cx.pos = lds + FL.pos; cx.lane = lane; cx.vl = lane < N;
+    LbMem lm;
+    lm.LM = wsb + (size_t)b * kp.ws_stride + kp.ws_lbs;
+    lm.LOLD = wsb + (size_t)b * kp.ws_stride + kp.ws_lold;
+    lm.LRHO = lds + FL.rho; lm.LALPHA = lds + FL.gg; lm.GG = lds + FL.gg; lm.XA = cx.pos;
+    const bool vl = lane < N;
+    auto run = [&](auto& lb, double* out, int which) {
+        for (int i = lane; i < (2 * mem + 1) * N; i += WAVE) reinterpret_cast<double2*>(lm.LM)[i] = make_double2(0.0, 0.0);
+        wave_sync();
+        double dv = 0.0, dw = 0.0;
+        for (int j = 0; j <= m; ++j) {
+            const double* uj = U + ((size_t)b * (m + 1) + j) * 2 * N;
+            const double* rj = R + ((size_t)b * (m + 1) + j) * 2 * N;
+            const double uv = vl ? uj[2 * lane] : 0.0, uw = vl ? uj[2 * lane + 1] : 0.0;
+            const double rv = vl ? rj[2 * lane] : 0.0, rw = vl ? rj[2 * lane + 1] : 0.0;
+            const double nfpr = P::uni(sqrt(dot2r<P, P::RV>(rv, rw, rv, rw)));
+            double pr = 0.0;
+            lb.template update<P, NT, MEMT>(cx, kp, vl, lane, uv, uw, rv, rw, nfpr, lm, pr);
+            wave_sync();
+            if (j == m) lb.template direction<P, NT, MEMT, true>(cx, kp, vl, lane, rv, rw, lm, pr, dv, dw);
+        }
+        if (vl) { out[(size_t)b * 2 * N + 2 * lane] = dv; out[(size_t)b * 2 * N + 2 * lane + 1] = dw; }
+        if (lane == 0 && pairs) pairs[2 * b + which] = lb.active;
+        wave_sync();
+    };
+    PanocLbfgsGram g;
+    run(g, d_gram, 0);
+    PanocLbfgs t;
+    run(t, d_two, 1);
+}
 
 // ALM / PM outer step: y+ <- y + c (F1(u) - Proj_C(F1(u) + y/c)); ||y+ - y||
 template <class P>

@@ -721,6 +721,43 @@ int32_t mpcgpu_debug_tracker_assemble(void* handle, const mpcgpu_tracker* t, con
     return 0;
 }
 
+// test hook: the L-BFGS operator alone, in both forms (lbfgs_direction_kernel)
+int32_t mpcgpu_debug_lbfgs_direction(void* handle, int32_t B, int32_t m, const double* U, const double* R, double* d_gram,
+                                     double* d_twoloop, int32_t* pairs) {
+    Handle* h = (Handle*)handle;
+    if (!h || B <= 0 || m < 1 || !U || !R || !d_gram || !d_twoloop) return -1;
+    const int NT = compiled_horizon(h);
+    if (!NT || !gram_layout(h->kp)) return fail(h, -1, "the Gram form exists for the compiled horizons (N_hor = 20, 40; L-BFGS memory 10)");
+    HIP_OK(h, hipSetDevice(h->device));
+    h->capturing = false;
+    const size_t n = 2 * (size_t)h->kp.N, seq = (size_t)B * (m + 1) * n * 8;
+    DevBuf dU, dR;   // one-off buffers of a test hook
+    if (int r = ensure(h, dU, seq)) return r;
+    if (int r = ensure(h, dR, seq)) { (void)hipFree(dU.ptr); return r; }
+    int rc = 0;
+    do {
+        if ((rc = ensure(h, h->ws, (size_t)B * h->kp.ws_stride * sizeof(double)))) break;
+        if ((rc = ensure(h, h->u, (size_t)B * n * 8))) break;
+        if ((rc = ensure(h, h->grad, (size_t)B * n * 8))) break;
+        if ((rc = ensure(h, h->evals, (size_t)B * 2 * sizeof(int32_t)))) break;
+        hipStream_t s = h->stream;
+        if (hipMemcpyAsync(dU.ptr, U, seq, hipMemcpyHostToDevice, s) != hipSuccess || hipMemcpyAsync(dR.ptr, R, seq, hipMemcpyHostToDevice, s) != hipSuccess) { rc = fail(h, -10, "hipMemcpyAsync failed"); break; }
+        const size_t lds = fixed_lds(NT, h->kp.mem, false).end * sizeof(double);
+        if (NT == 20) hipLaunchKernelGGL(lbfgs_direction_kernel<20>, dim3(B), dim3(WAVE), lds, s, h->kp, (double*)h->ws.ptr, (const double*)dU.ptr, (const double*)dR.ptr, m,
+                                         (double*)h->u.ptr, (double*)h->grad.ptr, (int32_t*)h->evals.ptr, B);
+        else hipLaunchKernelGGL(lbfgs_direction_kernel<40>, dim3(B), dim3(WAVE), lds, s, h->kp, (double*)h->ws.ptr, (const double*)dU.ptr, (const double*)dR.ptr, m,
+                                (double*)h->u.ptr, (double*)h->grad.ptr, (int32_t*)h->evals.ptr, B);
+        if (hipGetLastError() != hipSuccess) { rc = fail(h, -10, "launch failed"); break; }
+        if (hipMemcpyAsync(d_gram, h->u.ptr, (size_t)B * n * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipMemcpyAsync(d_twoloop, h->grad.ptr, (size_t)B * n * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            (pairs && hipMemcpyAsync(pairs, h->evals.ptr, (size_t)B * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess) ||
+            hipStreamSynchronize(s) != hipSuccess) { rc = fail(h, -10, "copy back failed"); break; }
+        h->evals_B = 0; h->last_B = 0;   // the counters buffer was borrowed
+    } while (0);
+    (void)hipFree(dU.ptr); (void)hipFree(dR.ptr);
+    return rc;
+}
+
 int32_t mpcgpu_workspace_stride(void* handle) { Handle* h = (Handle*)handle; return h ? h->kp.ws_stride : -1; }
 int32_t mpcgpu_workspace_record(void* handle) { Handle* h = (Handle*)handle; return h ? h->kp.ws_lbs : -1; }
 

@@ -61,7 +61,8 @@ EXPORTS = ("mpcgpu_abi_version", "mpcgpu_create", "mpcgpu_destroy", "mpcgpu_last
            "mpcgpu_last_eval_counts", "mpcgpu_last_shape", "mpcgpu_last_waves_per_simd", "mpcgpu_reserve_shape",
            "mpcgpu_set_option", "mpcgpu_last_problems_per_wavefront", "mpcgpu_last_ordered", "mpcgpu_last_latency_kernel", "mpcgpu_reserve_batch", "mpcgpu_last_table_kind", "mpcgpu_tracker_window_dev",
            "mpcgpu_tracker_step_dev", "mpcgpu_rl_reference_dev", "mpcgpu_hint_switch_dev", "mpcgpu_debug_read_workspace",
-           "mpcgpu_workspace_stride", "mpcgpu_workspace_record", "mpcgpu_debug_prep", "mpcgpu_debug_tracker_assemble")
+           "mpcgpu_workspace_stride", "mpcgpu_workspace_record", "mpcgpu_debug_prep", "mpcgpu_debug_tracker_assemble",
+           "mpcgpu_debug_lbfgs_direction")
 
 
 def library_path() -> str:
@@ -165,6 +166,8 @@ def load_library(path: Optional[str] = None):
     L.mpcgpu_debug_prep.restype = C.c_int32
     L.mpcgpu_debug_tracker_assemble.argtypes = [vp, tp, vp]
     L.mpcgpu_debug_tracker_assemble.restype = C.c_int32
+    L.mpcgpu_debug_lbfgs_direction.argtypes = [vp, C.c_int32, C.c_int32, dp, dp, dp, dp, ip]
+    L.mpcgpu_debug_lbfgs_direction.restype = C.c_int32
     L.mpcgpu_last_table_kind.argtypes = [vp]
     L.mpcgpu_last_table_kind.restype = C.c_int32
     L.mpcgpu_reserve_batch.argtypes = [vp, C.c_int32]
@@ -425,6 +428,17 @@ class BatchSolver:
     def debug_tracker_assemble(self, view: "CTracker", refs):
         self._check(self._L.mpcgpu_debug_tracker_assemble(self._h, C.byref(view), C.c_void_p(refs.data_ptr())),
                     "mpcgpu_debug_tracker_assemble")
+
+    def debug_lbfgs_direction(self, U, R):
+        """Test hook: U, R [B, m + 1, 2N] (iterates, gamma*fpr) -> (d_gram [B, 2N], d_twoloop [B, 2N], pairs [B, 2])."""
+        U = np.ascontiguousarray(U, dtype=np.float64); R = np.ascontiguousarray(R, dtype=np.float64)
+        B, m1 = U.shape[0], U.shape[1]
+        if U.shape != (B, m1, self.n) or R.shape != U.shape or m1 < 2:
+            raise MpcGpuError(f"bad shapes U{U.shape} R{R.shape}")
+        dg = np.empty((B, self.n)); dt = np.empty((B, self.n)); pairs = np.empty((B, 2), np.int32)
+        self._check(self._L.mpcgpu_debug_lbfgs_direction(self._h, B, m1 - 1, _dp(U), _dp(R), _dp(dg), _dp(dt), _ip(pairs)),
+                    "mpcgpu_debug_lbfgs_direction")
+        return dg, dt, pairs
 
     def release_shape(self):
         self._check(self._L.mpcgpu_reserve_shape(self._h, -1, -1, -1, 0), "mpcgpu_reserve_shape")
