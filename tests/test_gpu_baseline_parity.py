@@ -296,6 +296,54 @@ def test_gram_form_of_the_lbfgs_operator_against_the_two_loop_build_on_the_gpu(N
     a.close(); b.close()
 
 
+def _two_loop_host(S, Y, r):
+    """The `lbfgs` crate's recursion (oracle/mpc_oracle.c:406-449), newest pair first; S, Y lists oldest -> newest."""
+    q = r.copy()
+    al = []
+    for s, y in zip(reversed(S), reversed(Y)):
+        a = (s @ q) / (s @ y)
+        al.append(a)
+        q = q - a * y
+    q = q * ((S[-1] @ Y[-1]) / (Y[-1] @ Y[-1]))
+    for (s, y), a in zip(zip(S, Y), reversed(al)):
+        be = (y @ q) / (s @ y)
+        q = q + (a - be) * s
+    return q
+
+
+@pytest.mark.parametrize("N,m", [(20, 6), (20, 14), (40, 14)])
+def test_gram_direction_against_the_two_loop_direction_on_recorded_pairs(N, m):
+    """The L-BFGS operator alone (mpcgpu_debug_lbfgs_direction): the same recorded sequence of (u_j, gamma fpr_j) goes through the
+    Gram form the product kernels use and through the two-loop recursion ON THE GPU, and through a host restatement of the
+    recursion: d = H r agrees to 1e-11 relative -- with fewer pairs than the memory and with a wrapped ring."""
+    cfg = make_cfg(N)
+    B, n = 64, 2 * N
+    rng = np.random.default_rng(N + m)
+    U = np.zeros((B, m + 1, n)); R = np.zeros((B, m + 1, n))
+    U[:, 0] = rng.normal(0, 0.3, (B, n)); R[:, 0] = rng.normal(0, 1e-2, (B, n))
+    for b in range(B):
+        Q = rng.normal(size=(n, n))
+        M = np.diag(rng.uniform(0.5, 2.0, n)) + 0.05 * (Q @ Q.T) / n          # SPD: every pair has s'y > 0
+        for j in range(1, m + 1):
+            s = rng.normal(0, 1e-2, n)
+            U[b, j] = U[b, j - 1] + s
+            R[b, j] = R[b, j - 1] + 1e-2 * (M @ s)
+    bs = BatchSolver(cfg)
+    dg, dt, pairs = bs.debug_lbfgs_direction(U, R)
+    bs.close()
+    assert (pairs[:, 0] == min(m, 10)).all() and (pairs[:, 1] == min(m, 10)).all()      # every pair accepted by both forms
+    worst_gt = worst_h = 0.0
+    for b in range(B):
+        S = [U[b, j] - U[b, j - 1] for j in range(1, m + 1)][-10:]
+        Y = [R[b, j] - R[b, j - 1] for j in range(1, m + 1)][-10:]
+        dh = _two_loop_host(S, Y, R[b, m])
+        sc = np.max(np.abs(dh))
+        worst_gt = max(worst_gt, np.max(np.abs(dg[b] - dt[b])) / sc)
+        worst_h = max(worst_h, np.max(np.abs(dt[b] - dh)) / sc, np.max(np.abs(dg[b] - dh)) / sc)
+    print(f"\n[L-BFGS direction, N={N}, {m} updates] Gram vs two-loop on the GPU: {worst_gt:.2e} relative; both vs the host recursion: {worst_h:.2e}")
+    assert worst_gt <= 1e-11 and worst_h <= 1e-11
+
+
 def test_solve_device_is_ordered_with_torch_work_on_the_same_stream_without_host_sync():
     """`p` is produced by a torch kernel right before solve_device and `u` is consumed by one right after, on torch's
     current stream (raw handle 0 for the default stream), with no host synchronisation in between."""
