@@ -47,8 +47,11 @@ def test_captured_solve_replays_bitwise(B):
     bs.reserve_batch(B)
     if B > 4096:
         # more problems than are resident at once: after one eager call the handle holds evaluation counts, and the captured
-        # launch carries the three ordering kernels (MPCGPU_OPT_ORDER) -- every replay re-sorts by the counts of the one before
-        bs.solve_device(p, out, stream=torch.cuda.current_stream().cuda_stream)
+        # launch carries the three ordering kernels (MPCGPU_OPT_ORDER) -- every replay re-sorts by the counts of the one before.
+        # The hints are used only when they were written on the SAME stream (no ordering exists across streams): the eager call
+        # goes to the stream that is captured afterwards.
+        with torch.cuda.stream(side):
+            bs.solve_device(p, out, stream=torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g, stream=side):

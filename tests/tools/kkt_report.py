@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Solution-level report (GPU box): tests/support/kkt.py applied to samples of converged AND cap-limited answers of
-libmpcgpu.so on the BASELINE configurations.  usage: python tests/tools/kkt_report.py > profiles/r03_kkt_report.txt"""
+libmpcgpu.so on the BASELINE configurations.  usage: python tests/tools/kkt_report.py > profiles/r04_kkt_report.txt"""
 import os
 import sys
 
@@ -24,6 +24,9 @@ def block(title, cfg, ocfg, p, res, idx, scipy_on):
     print("    infeasibility max(U, C, F2) :", pct([max(r["infeas_U"], r["infeas_C"], r["infeas_F2"]) for r in rows]))
     print("    projected-gradient residual :", pct([r["pg_residual"] for r in rows]))
     print("    active hard constraints     :", np.bincount([r["n_active_hard"] for r in rows]).tolist() if rows else [])
+    mus = [r["mu_dyn_max"] for r in rows if r.get("n_active_dyn", 0) >= 1 and "mu_dyn_max" in r]
+    if mus:
+        print("    multipliers of active ellipses:", pct(mus), " (> 0: %d of %d)" % (sum(m > 0 for m in mus), len(mus)))
     if scipy_on:
         print("    |u_scipy - u*|_inf          :", pct([r["scipy_move"] for r in rows]))
         print("    relative f gain of scipy    :", pct([max(r["scipy_f_gain_rel"], 0.0) for r in rows]))
@@ -36,7 +39,10 @@ print("# cap-limited solves are REPORTED only: how far from a KKT point a NotCon
 for name, N, n_dyn, B, kw in (("config 2, passing family", 20, 4, 1024, dict(dyn_clearance=0.1, box_clearance=0.3)),
                               ("config 3, passing family", 40, 8, 4096, dict(dyn_clearance=0.1, box_clearance=0.3)),
                               ("metric configuration, passing family", 20, 8, 8192, dict(dyn_clearance=0.1, box_clearance=0.3)),
-                              ("metric configuration, benchmark family (bench.py headline)", 20, 8, 8192, dict())):
+                              ("metric configuration, benchmark family (bench.py headline)", 20, 8, 8192, dict()),
+                              ("metric configuration, AVOIDANCE family (discs cover the path; bench.py config.avoidance)", 20, 8, 8192, dict(scenes.FAMILIES["avoidance"])),
+                              ("metric configuration, GRAZING family (one disc covers the path by 5-50 mm, soft weights 10: plans rest ON the hard ellipse)", 20, 8, 8192, dict(scenes.FAMILIES["grazing"])),
+                              ("config 3, GRAZING family, on track", 40, 8, 8192, dict(scenes.FAMILIES["grazing"], on_track=True))):
     cfg = MpcConfig(N_hor=N)
     ocfg = oracle.OracleConfig.from_dict(cfg.solver_dict())
     sc = scenes.make_batch(cfg, B, n_dyn=n_dyn, seed=77, **kw)
@@ -47,4 +53,8 @@ for name, N, n_dyn, B, kw in (("config 2, passing family", 20, 4, 1024, dict(dyn
     conv, cap = np.where(res.status == 0)[0], np.where(res.status == 1)[0]
     print(f"\n{name}: N_hor={N}, {n_dyn} dynamic obstacles, B={B}: status histogram {np.bincount(res.status, minlength=3).tolist()}")
     block("converged (status 0), sample", cfg, ocfg, sc["p"], res, rng.choice(conv, min(32, len(conv)), replace=False) if len(conv) else [], True)
+    inside = np.where((res.status == 0) & (res.f2_norm > 0.0))[0]
+    if "GRAZING" in name or "AVOIDANCE" in name:
+        print(f"  converged with F2 > 0 (resting on a hard constraint from inside): {len(inside)} of {len(conv)} converged")
+        block("converged with F2 > 0, sample", cfg, ocfg, sc["p"], res, rng.choice(inside, min(32, len(inside)), replace=False) if len(inside) else [], True)
     block("cap-limited (status 1), sample", cfg, ocfg, sc["p"], res, rng.choice(cap, min(32, len(cap)), replace=False) if len(cap) else [], False)

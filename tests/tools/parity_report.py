@@ -62,6 +62,29 @@ def baseline_config(N, n_dyn, B, S=256):
     bs.close()
 
 
+def family_config(N, family, B, cfgkw=None, S=256):
+    """Round 4: a named scene family (scenes.FAMILIES) at full batch; GPU vs oracle on a sample, next to the oracle against itself
+    with every parameter moved by one ulp (tests/test_gpu_baseline_parity.py::test_avoidance_and_long_iteration_families_match_oracle)."""
+    cfg = MpcConfig(N_hor=N, **(cfgkw or {}))
+    ocfg = oracle.OracleConfig.from_dict(cfg.solver_dict())
+    bs = BatchSolver(cfg)
+    sc = scenes.make_family(cfg, B, family, seed=4321)
+    res = bs.solve(sc["p"])
+    pick = np.random.default_rng(N).choice(B, S, replace=False)
+    uo, _, ro, _ = oracle.solve_batch(ocfg, sc["p"][pick])
+    up, _, rp, _ = oracle.solve_batch(ocfg, np.nextafter(sc["p"][pick], np.inf))
+    both = (res.status[pick] == 0) & (ro["status"] == 0)
+    both_p = (rp["status"] == 0) & (ro["status"] == 0)
+    du = np.max(np.abs(res.solution[pick] - uo), axis=1)
+    dp = np.max(np.abs(up - uo), axis=1)
+    f = lambda m, d: f"max {d[m].max():.2e} median {np.median(d[m]):.2e}" if m.any() else "none"   # noqa: E731
+    print(f"N={N} '{family}' {cfgkw or ''} B={B}: status histogram {np.bincount(res.status, minlength=3).tolist()} (whole batch); sample of {S}: "
+          f"converged GPU {np.sum(res.status[pick] == 0)} / oracle {np.sum(ro['status'] == 0)} / both {both.sum()}: |du|inf {f(both, du)}, agreement on "
+          f"which converge {np.mean((res.status[pick] == 0) == (ro['status'] == 0)):.3f}  ||  oracle vs oracle with every parameter moved by one ulp: both "
+          f"{both_p.sum()}: |du|inf {f(both_p, dp)}, agreement {np.mean((rp['status'] == 0) == (ro['status'] == 0)):.3f}")
+    bs.close()
+
+
 def per_outer_match(tg, to):
     """{outer index: (steps of that inner problem in the oracle trace, leading steps whose discrete decisions coincide)} --
     every inner problem is compared from ITS first step, also when an earlier one has already diverged."""
@@ -127,6 +150,11 @@ def decision_trace(N, fallback, max_inner, max_outer, CAP=240, B=48, cold=False,
 if __name__ == "__main__":
     print("# BASELINE.json configurations at full batch, 'passing' scene family (tests/test_gpu_baseline_parity.py asserts these)")
     baseline_config(20, 8, 8192); baseline_config(40, 8, 4096); baseline_config(20, 4, 1024)
+    print("# round 4: the 'avoidance' family (1-3 discs cover the path, the box covers it in 30 % of the problems) at the metric batch; config 3 on the")
+    print("#          'on_track' family with the yaml's caps (WHICH problems converge within 500 inner iterations is rounding-decided at N_hor = 40)")
+    print("#          and with the inner cap at 5000 (a robust converged set)")
+    family_config(20, "avoidance", 8192); family_config(40, "avoidance", 4096)
+    family_config(40, "on_track", 4096); family_config(40, "on_track", 4096, dict(solver_max_inner_iterations=5000))
     print("# decision traces on benchmark-family scenes from a non-zero initial guess (48 problems each)")
     decision_trace(20, "last_trial", 40, 6); decision_trace(20, "half_step", 40, 6)
     decision_trace(40, "last_trial", 40, 6); decision_trace(20, "last_trial", 500, 10)

@@ -794,6 +794,15 @@ struct Ctx {
     const double* dynl;        // linear centre tables: [Kd][DYNL]
     const unsigned* dynr;      // ... and the residuals of every (row, step): signed 16-bit multiples of the row's unit, x low, y high
 };
+// balanced walk of the dynamic rows (eval_point): the two-lane steps own ceil(Kd / 2) trips; T = the smallest trip count at which
+// the rows T.. of the single-lane steps fit into the spare trips of the helper lanes.  (Every kernel that runs eval_point: load_problem,
+// and the latency kernel's own context set-up.)
+__device__ __forceinline__ void set_balanced_trips(Ctx& cx, int N, int lanes) {
+    const int ns1 = N - (lanes - N), nh = 2 * (lanes - N);
+    int t2 = (cx.Kd + 1) / 2, T = t2;
+    while (ns1 > 0 && (cx.Kd - T) * ns1 > nh * (T - t2)) ++T;
+    cx.balT = T; cx.balT2 = t2;
+}
 constexpr int KC_BASE = 32;
 #define KC(i) (cx.hd[KC_BASE + (i)])
 #define HD(i) (cx.hd[(i)])
@@ -839,13 +848,7 @@ __device__ __forceinline__ void load_problem(const KParams& kp, const double* __
         cx.seg = lds + kp.l_seg; cx.pos = lds + kp.l_pos; cx.stash = lds + kp.l_stash; cx.H = lds + kp.l_H; cx.W = lds + kp.l_W; cx.part = lds + kp.l_part;
         cx.bal = lds + kp.l_bal;
     }
-    {   // balanced walk of the dynamic rows (eval_point): the two-lane steps own ceil(Kd / 2) trips; T = the smallest trip count at
-        // which the rows T.. of the single-lane steps fit into the spare trips of the helper lanes
-        const int ns1 = N - (P::W - N), nh = 2 * (P::W - N);
-        int t2 = (cx.Kd + 1) / 2, T = t2;
-        while (ns1 > 0 && (cx.Kd - T) * ns1 > nh * (T - t2)) ++T;
-        cx.balT = T; cx.balT2 = t2;
-    }
+    set_balanced_trips(cx, N, P::W);
     // coalesced table copies HBM -> LDS (only the active entries of this problem)
     for (int i = lane; i < N * SEGW; i += P::W) cx.seg[i] = ws[kp.ws_seg + i];
     for (int i = lane; i < cx.Ks * STCW; i += P::W) cx.stc[i] = ws[kp.ws_stc + i];

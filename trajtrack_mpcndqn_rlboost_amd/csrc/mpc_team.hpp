@@ -84,6 +84,8 @@ __global__ __launch_bounds__(WAVE * TW) void solve_kernel_team(KParams kp, Batch
         cx.seg = lds + kp.l_seg; cx.stc = lds + kp.l_stc; cx.fxy = lds + kp.l_fxy;
         cx.dyn = lds + kp.l_dyn; cx.dync = cx.dyn;
         cx.pos = mine + kp.l_pos; cx.H = mine + kp.l_H; cx.W = mine + kp.l_W; cx.part = mine + kp.l_part; cx.stash = mine + kp.l_stash;
+        cx.bal = mine + kp.l_bal;
+        set_balanced_trips(cx, N, WAVE);
         const int T = WAVE * TW;
         for (int i = threadIdx.x; i < N * SEGW; i += T) cx.seg[i] = ws[kp.ws_seg + i];
         for (int i = threadIdx.x; i < cx.Ks * STCW; i += T) cx.stc[i] = ws[kp.ws_stc + i];
