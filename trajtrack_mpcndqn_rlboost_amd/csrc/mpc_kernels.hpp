@@ -1992,7 +1992,7 @@ template <> struct LbfgsOf<false, 20> { using type = std::conditional<GramFor<20
 // test-hook kernel: the L-BFGS operator alone.  A recorded sequence of iterates and residuals (u_j, gamma fpr_j), j = 0 .. m, is
 // fed to the buffer exactly as solve_body feeds it (update, then the direction from the last residual) -- once through the
 // Gram form, once through the two-loop recursion -- and both directions come back (tests/test_gpu_baseline_parity.py compares
-// them with each other and with a host restatement of the `lbfgs` crate's recursion, oracle/mpc_oracle.c:406-449).
+// them with each other and with a host restatement of the recursion of the `lbfgs` crate).
 // ------------------------------------------------------------------------------------------------
 template <int NT>
 __global__ __launch_bounds__(WAVE) void lbfgs_direction_kernel(KParams kp, double* __restrict__ wsb, const double* __restrict__ U,
