@@ -140,3 +140,26 @@ def check_solution(cfg, ocfg, p, u, y, run_scipy=True, active_tol=1e-3):
     out["scipy_feasible"] = bool((gs.max() if gs.size else -1.0) <= 1e-6)
     out["scipy_f_gain_rel"] = float((f0 - res.fun) / max(abs(f0), 1e-12))     # > 0: scipy found a lower f
     return out
+
+
+def scipy_from_cold_start(cfg, ocfg, p, maxiter=500):
+    """An INDEPENDENT solve of the reference's constrained problem: SLSQP on the reference-pinned f / grad f, the acceleration box as
+    a linear constraint and the hard constraints in their inequality form, started where the reference's call sites start the solver
+    (initial_guess=None -> u = 0, src/interface_mpc.py:82).  Nothing of the PANOC / ALM restatement is involved.  Returns
+    dict(x, ok, f, n_active_hard)."""
+    N = int(cfg.N_hor)
+    lo = np.tile([cfg.lin_vel_min, -cfg.ang_vel_max], N)
+    hi = np.tile([cfg.lin_vel_max, cfg.ang_vel_max], N)
+    clo = np.r_[np.full(N, cfg.lin_acc_min), np.full(N, -cfg.ang_acc_max)]
+    chi = np.r_[np.full(N, cfg.lin_acc_max), np.full(N, cfg.ang_acc_max)]
+    A, b0 = f1_matrix(ocfg, p)
+    cons = [LinearConstraint(A, clo - b0, chi - b0)]
+    if hard_constraints(cfg, p, np.zeros(2 * N)).size:
+        cons.append(NonlinearConstraint(lambda x: hard_constraints(cfg, p, x), -np.inf, 0.0))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        res = minimize(lambda x: oracle.cost_grad(ocfg, x, p)["f"], np.zeros(2 * N), jac=lambda x: oracle.cost_grad(ocfg, x, p)["grad"],
+                       bounds=list(zip(lo, hi)), constraints=cons, method="SLSQP", options=dict(maxiter=maxiter, ftol=1e-13))
+    g = hard_constraints(cfg, p, res.x)
+    return dict(x=res.x, ok=res.status == 0, f=float(res.fun), n_active_hard=int((g > -1e-3).sum()) if g.size else 0)

@@ -84,6 +84,57 @@ def test_oracle_solutions_on_an_active_hard_ellipse_are_kkt_points_with_positive
         assert_kkt(r, f"grazing problem {i}")
 
 
+def same_minimiser_as_scipy(cfg, ocfg, p, u, rows, tag=""):
+    """For every listed problem: scipy's own solve from the cold start (kkt.scipy_from_cold_start) against the solver's answer.
+    Returns (number of runs scipy completed, number of those within the north-star tolerance 1e-3, worst |du|inf among them)."""
+    done = same = 0
+    worst = 0.0
+    for i in rows:
+        r = kkt.scipy_from_cold_start(cfg, ocfg, p[i])
+        if not r["ok"]:
+            continue
+        done += 1
+        du = float(np.abs(r["x"] - u[i]).max())
+        if du <= MOVE_TOL:
+            same += 1
+            worst = max(worst, du)
+        else:
+            print(f"  {tag} problem {i}: scipy ended in another point (|du| {du:.2e}, f {r['f']:.6g})")
+    return done, same, worst
+
+
+@pytest.mark.parametrize("family", ["passing", "avoidance"])
+def test_scipy_from_the_cold_start_reaches_the_solver_s_control_sequence(family):
+    """Evidence that does not pass through ANY restatement of OpEn: a different algorithm (SQP) on the reference-pinned problem
+    functions, from the reference's own cold start, ends in the control sequence the PANOC / ALM iteration returns (north-star
+    tolerance 1e-3; measured 1e-7 .. 1e-5)."""
+    cfg = make_cfg(20)
+    ocfg = oracle_cfg(cfg)
+    sc = scenes.make_family(cfg, 48, family, seed=77)
+    u, y, res, _ = oracle.solve_batch(ocfg, sc["p"])
+    rows = np.where(res["status"] == 0)[0][:8]
+    assert len(rows) == 8
+    done, same, worst = same_minimiser_as_scipy(cfg, ocfg, sc["p"], u, rows, family)
+    print(f"\n[scipy from u = 0, {family}] {done} of 8 runs completed, {same} end in the solver's control sequence (worst |du|inf {worst:.2e})")
+    assert done >= 6 and same >= done - 1
+
+
+def test_scipy_from_the_cold_start_lands_on_the_same_active_constraint():
+    cfg = make_cfg(20)
+    ocfg = oracle_cfg(cfg)
+    sc = scenes.make_family(cfg, 1024, "grazing", seed=21)
+    u, y, res, _ = oracle.solve_batch(ocfg, sc["p"])
+    rows = active_hard_candidates(cfg, ocfg, sc["p"], u, y, res["status"], res["f2_norm"], want=5)
+    assert len(rows) >= 4
+    done = same = 0
+    for i in rows:
+        r = kkt.scipy_from_cold_start(cfg, ocfg, sc["p"][i])
+        if r["ok"]:
+            done += 1
+            same += int(np.abs(r["x"] - u[i]).max() <= MOVE_TOL and r["n_active_hard"] >= 1)
+    assert done >= 3 and same == done, (done, same)
+
+
 def test_a_capped_solve_is_visibly_not_a_kkt_point():
     """The check discriminates: answers that stopped at the iteration cap on the benchmark family fail it by orders of magnitude."""
     cfg = make_cfg(20)

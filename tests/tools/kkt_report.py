@@ -18,6 +18,21 @@ def pct(x):
     return "n=%d  median %.2e  p90 %.2e  max %.2e" % (len(x), np.median(x), np.percentile(x, 90), x.max()) if len(x) else "n=0"
 
 
+def cold(title, cfg, ocfg, p, res, idx):
+    """scipy's own solve from u = 0 against the GPU's answer (tests/support/kkt.py: scipy_from_cold_start)."""
+    du, act, failed = [], [], 0
+    for i in idx:
+        r = kkt.scipy_from_cold_start(cfg, ocfg, p[i])
+        if not r["ok"]:
+            failed += 1
+            continue
+        du.append(float(np.abs(r["x"] - res.solution[i]).max())); act.append(r["n_active_hard"])
+    du = np.array(du)
+    print(f"  {title}: scipy (SLSQP) from the cold start u = 0, {len(idx)} problems, {failed} where SLSQP gave up")
+    if len(du):
+        print(f"    |u_scipy - u_gpu|_inf        : {pct(du)};  within 1e-3: {int((du <= 1e-3).sum())} of {len(du)};  active hard constraints at scipy's point: {np.bincount(act).tolist()}")
+
+
 def block(title, cfg, ocfg, p, res, idx, scipy_on):
     rows = [kkt.check_solution(cfg, ocfg, p[i], res.solution[i], res.lagrange_multipliers[i], run_scipy=scipy_on) for i in idx]
     print(f"  {title}")
@@ -36,6 +51,8 @@ print("# tests/tools/kkt_report.py on one MI355X: answers of libmpcgpu.so examin
 print("# constrained problem by scipy (SLSQP on the reference-pinned f, F1, hard constraints; tests/support/kkt.py).")
 print("# Asserted for converged solves by tests/test_gpu_solution_kkt.py (feasible to 1e-4, move <= 1e-3, f gain <= 1e-6, residual <= 1e-3);")
 print("# cap-limited solves are REPORTED only: how far from a KKT point a NotConvergedIterations answer is.")
+print("# Round 4: next to it, scipy's OWN solve of the same problem from the reference's cold start u = 0 -- a different algorithm, nothing shared with the")
+print("# solver but the reference-pinned problem functions -- compared with the GPU's control sequence (asserted: tests/test_gpu_solution_kkt.py).")
 for name, N, n_dyn, B, kw in (("config 2, passing family", 20, 4, 1024, dict(dyn_clearance=0.1, box_clearance=0.3)),
                               ("config 3, passing family", 40, 8, 4096, dict(dyn_clearance=0.1, box_clearance=0.3)),
                               ("metric configuration, passing family", 20, 8, 8192, dict(dyn_clearance=0.1, box_clearance=0.3)),
@@ -53,8 +70,10 @@ for name, N, n_dyn, B, kw in (("config 2, passing family", 20, 4, 1024, dict(dyn
     conv, cap = np.where(res.status == 0)[0], np.where(res.status == 1)[0]
     print(f"\n{name}: N_hor={N}, {n_dyn} dynamic obstacles, B={B}: status histogram {np.bincount(res.status, minlength=3).tolist()}")
     block("converged (status 0), sample", cfg, ocfg, sc["p"], res, rng.choice(conv, min(32, len(conv)), replace=False) if len(conv) else [], True)
+    cold("converged (status 0), sample", cfg, ocfg, sc["p"], res, rng.choice(conv, min(16 if N == 20 else 8, len(conv)), replace=False) if len(conv) else [])
     inside = np.where((res.status == 0) & (res.f2_norm > 0.0))[0]
     if "GRAZING" in name or "AVOIDANCE" in name:
         print(f"  converged with F2 > 0 (resting on a hard constraint from inside): {len(inside)} of {len(conv)} converged")
         block("converged with F2 > 0, sample", cfg, ocfg, sc["p"], res, rng.choice(inside, min(32, len(inside)), replace=False) if len(inside) else [], True)
+        cold("converged with F2 > 0, sample", cfg, ocfg, sc["p"], res, rng.choice(inside, min(16 if N == 20 else 8, len(inside)), replace=False) if len(inside) else [])
     block("cap-limited (status 1), sample", cfg, ocfg, sc["p"], res, rng.choice(cap, min(32, len(cap)), replace=False) if len(cap) else [], False)
