@@ -77,3 +77,5 @@ for name, N, n_dyn, B, kw in (("config 2, passing family", 20, 4, 1024, dict(dyn
         block("converged with F2 > 0, sample", cfg, ocfg, sc["p"], res, rng.choice(inside, min(32, len(inside)), replace=False) if len(inside) else [], True)
         cold("converged with F2 > 0, sample", cfg, ocfg, sc["p"], res, rng.choice(inside, min(16 if N == 20 else 8, len(inside)), replace=False) if len(inside) else [])
     block("cap-limited (status 1), sample", cfg, ocfg, sc["p"], res, rng.choice(cap, min(32, len(cap)), replace=False) if len(cap) else [], False)
+    if "benchmark family" in name:      # is the headline workload hard for an independent optimiser as well?
+        cold("cap-limited (status 1), sample", cfg, ocfg, sc["p"], res, rng.choice(cap, min(16, len(cap)), replace=False) if len(cap) else [])
