@@ -47,3 +47,26 @@ def test_bench_line_contract_and_in_run_counters():
         # committed counter passes to fall back to, so the counter fields are null)
         print("counters not measured in this run:", ro.get("traffic_source"))
         assert ro["traffic"] is None and ro["secondary"] is None and not ro["measured_in_run"]["secondary"]
+
+
+def test_two_ranks_share_the_one_gpu_through_the_real_solver():
+    """The N > 1 path of bench.py with the REAL library: two rank processes (started by bench.py itself, gloo for the barrier and
+    the reductions) shard the batch and share the one GPU of this box -- what the driver's 8-GPU run does with one GPU per rank.
+    Each rank solves its own B robots (weak scaling); the line reports both ranks' rates and the whole-job value over the
+    max-over-ranks time; side legs stay on the one-rank run."""
+    B = 4096
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MPCGPU_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", str(B), "--steps", "2", "--warmup", "1",
+                        "--cpu-seconds", "0"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["backend"] == "gloo" and d["data"] == "synthetic"
+    assert len(d["per_rank_solves_per_s"]) == 2 and all(v > 0 for v in d["per_rank_solves_per_s"])
+    assert abs(d["value"] - 2 * B * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    assert sum(d["config"]["status_histogram"]) == B          # rank 0's shard
+    for k in ("convergent", "avoidance", "batch_sweep", "closed_loop"):
+        assert k not in d["config"], k
+    assert d["roofline"]["measured_in_run"]["traffic"] is False   # counter passes belong to the one-rank run
