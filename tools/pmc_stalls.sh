@@ -12,7 +12,7 @@ for SET in "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADD
            "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS" \
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --pmc $SET --output-format csv -d "$OUT/s$i" -o pmc -- python3 "$REPO/tools/valu_per_eval.py" "$B" 8 1 > "$OUT/s$i.log" 2>&1
+  rocprofv3 --pmc $SET --output-format csv -d "$OUT/s$i" -o pmc -- python3 "$REPO/tools/valu_per_eval.py" "$B" 8 1 ${PMC_N:-20} > "$OUT/s$i.log" 2>&1
   echo "set $i rc=$?"
 done
 python3 - "$OUT" <<'PY'
