@@ -351,7 +351,12 @@ def main():
     # more than generating its content, so the buffer is allocated once -- page-locked when there is a GPU, which also populates
     # it in bulk -- and every family is generated into (a slice of) it and uploaded.
     t_gen = time.perf_counter()
-    host_buf = None if args.p_file else torch.empty((B, cfg.num_params), dtype=torch.float64, pin_memory=not stub).numpy()
+    host_buf = None
+    if not args.p_file:
+        try:
+            host_buf = torch.empty((B, cfg.num_params), dtype=torch.float64, pin_memory=not stub).numpy()
+        except RuntimeError:     # no page-locked memory to be had (cgroup limit): pageable, page faults and all
+            host_buf = np.empty((B, cfg.num_params))
 
     def family_on_device(family, b, seed):
         scenes.make_family(cfg, b, family, n_dyn=args.n_dyn, seed=seed, out=host_buf[:b])
