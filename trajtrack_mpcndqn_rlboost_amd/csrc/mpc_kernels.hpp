@@ -18,6 +18,21 @@
 #include <stdint.h>
 #include <type_traits>
 
+// Wave priority (s_setprio; round 4): the phases of an evaluation that are chains of dependent cross-lane steps (rollout scans, adjoint,
+// and the solver logic between two evaluations) run at a raised priority, the item loops -- independent work per lane, the part that
+// fills the issue slots other wavefronts leave -- at the base priority: a wavefront in a chain issues as soon as its operand arrives
+// instead of waiting its turn.  No instruction but the two s_setprio per evaluation; same bits.  -1.0 % kernel time at N_hor = 20
+// and 40 (profiles/r04_setprio_ab.txt); with the raised priority ending at the end of the evaluation (logic at base) the gain is lost.
+#ifndef MPC_SETPRIO
+#define MPC_SETPRIO 1
+#endif
+#if MPC_SETPRIO
+#define MPC_PRIO_CHAIN() __builtin_amdgcn_s_setprio(2)
+#define MPC_PRIO_ITEMS() __builtin_amdgcn_s_setprio(0)
+#else
+#define MPC_PRIO_CHAIN()
+#define MPC_PRIO_ITEMS()
+#endif
 #define MPC_ITEM_LOOP _Pragma("unroll 1")  // item loops: keep the loads of one iteration in flight, not of all (other policies: +-1 %, round 2)
 
 namespace mpcgpu {
@@ -941,6 +956,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     const double fleetw = here_s(kp.fleetw);
     const double inf = __builtin_huge_val();
     if (!c_vl) { v = 0.0; w = 0.0; }
+    MPC_PRIO_CHAIN();
 
     // ---- rollout.  Heading phasors e^{i theta}: theta_{k+1} = theta_k + ts*w_k, so they are a prefix PRODUCT of
     //      unit complex numbers e^{i ts w_k} (DPP scan); positions are a prefix SUM of Simpson increments.
@@ -1001,6 +1017,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     }
     wave_sync();
     PROF_MARK(1);  // positions + publish
+    MPC_PRIO_ITEMS();
 
     // ---- item phase A: stage terms of step ik handled by this lane
     double cost_l = 0.0, S_l = 0.0, gx = 0.0, gy = 0.0, dsx = 0.0, dsy = 0.0;
@@ -1332,6 +1349,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     }
 
     PROF_MARK(6);  // phase B
+    MPC_PRIO_CHAIN();
     // ---- combine the LPS item lanes of each step on its vector lane.  Lane k < N is itself the first item lane of step k
     //      (sub 0): its partial stays in registers, only the lanes of sub >= 1 go through LDS.
     if (c_il && c_isub > 0) {
