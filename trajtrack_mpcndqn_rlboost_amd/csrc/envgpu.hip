@@ -73,13 +73,26 @@ __device__ __forceinline__ unsigned wave_xor(unsigned m) {
     for (int off = 32; off >= 1; off >>= 1) m ^= (unsigned)__shfl_xor((int)m, off, WAVE);
     return m;
 }
+// fmin / fmax as the single instruction they are: the library forms canonicalise every operand the compiler did not compute itself
+// (v_max_f64 x, x, x in front of each), three instructions for one in the clip chains of the edge loop.  v_min_f64 / v_max_f64 return
+// the other operand for a quiet NaN exactly as fmin / fmax do (IEEE mode): the same values.
+__device__ __forceinline__ double min_raw(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double max_raw(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 // 1 / x: hardware estimate + one Newton step (~1e-15 relative; the observations are rounded to float32 afterwards)
 __device__ __forceinline__ double fast_rcp(double x) {
     const double r = __builtin_amdgcn_rcp(x);
     return r * (2.0 - x * r);
 }
 __device__ __forceinline__ double normalize_distance(double d) {  // components/utils.py:10-15
-    return 2.0 / (1.0 + exp(-2.0 * d / 10.0)) - 1.0;
+    return 2.0 * fast_rcp(1.0 + exp(-0.2 * d)) - 1.0;   // (the observations are rounded to float32)
 }
 
 // cos / sin of j * pi / 8, j = 0..15
@@ -134,13 +147,17 @@ __global__ __launch_bounds__(WAVE, 4) void env_step_kernel(EnvK k, const double*
         if (w > P.angvel_max) w = P.angvel_max;
         if (w < P.angvel_min) w = P.angvel_min;
         th += ts * w;
-        x += ts * v * cos(th);
-        y += ts * v * sin(th);
+    }
+    // cos / sin of the heading once: the kinematic step and the observation pass use the same angle
+    double cth0, sth0;
+    sincos(th, &sth0, &cth0);
+    if (act) {
+        x += ts * v * cth0;
+        y += ts * v * sth0;
     }
     // Pass 0 is the step itself.  With in-kernel auto-reset (out.max_steps > 0) an environment whose episode ended is
     // put back to its start state and observed again in pass 1 -- no host round trip, no second launch.
-    auto run_pass = [&](const int pass) -> bool {   // returns true when the episode ended and pass 1 is wanted
-    const double cth = cos(th), sth = sin(th);
+    auto run_pass = [&](const int pass, const double cth, const double sth) -> bool {   // returns true when the episode ended and pass 1 is wanted
 
     // ---- key-frame pose of obstacle `lane` (obstacle.py:71-88): (x, y, cos rot, sin rot) -> LDS
     if (lane < n_obst) {
@@ -155,7 +172,7 @@ __global__ __launch_bounds__(WAVE, 4) void env_step_kernel(EnvK k, const double*
         for (int i = 0; i < nk; ++i) {
             t += tsv[i];
             if (!found && t <= tm && tm < t + tsv[i + 1]) {
-                const double xx = (tm - t) / tsv[i + 1];
+                const double xx = (tm - t) * fast_rcp(tsv[i + 1]);
                 const double alpha = kind == 1 ? (1.0 - cos(xx * M_PI)) / 2.0 : xx;
                 const double* k0 = kf + 3 * i;
                 const double* k1 = kf + 3 * ((i + 1) % nk);
@@ -165,7 +182,9 @@ __global__ __launch_bounds__(WAVE, 4) void env_step_kernel(EnvK k, const double*
                 found = true;
             }
         }
-        pose[lane][0] = px; pose[lane][1] = py; pose[lane][2] = cos(rot); pose[lane][3] = sin(rot);
+        double crot, srot;
+        sincos(rot, &srot, &crot);
+        pose[lane][0] = px; pose[lane][1] = py; pose[lane][2] = crot; pose[lane][3] = srot;
     }
     __syncthreads();
 
@@ -224,22 +243,22 @@ __global__ __launch_bounds__(WAVE, 4) void env_step_kernel(EnvK k, const double*
             // wedge = {cross(d_lower, X) >= 0} and {cross(d_upper, X) <= 0}: clip the edge's parameter range [0, 1]
             double t0 = 0.0, t1 = 1.0;
             bool empty = false;
-            if (lower.g1 > 0.0) t0 = fmax(t0, lower.tc);
-            else if (lower.g1 < 0.0) t1 = fmin(t1, lower.tc);
+            if (lower.g1 > 0.0) t0 = max_raw(t0, lower.tc);
+            else if (lower.g1 < 0.0) t1 = min_raw(t1, lower.tc);
             else if (lower.g0 < 0.0) empty = true;
-            if (upper.g1 < 0.0) t0 = fmax(t0, upper.tc);
-            else if (upper.g1 > 0.0) t1 = fmin(t1, upper.tc);
+            if (upper.g1 < 0.0) t0 = max_raw(t0, upper.tc);
+            else if (upper.g1 > 0.0) t1 = min_raw(t1, upper.tc);
             else if (upper.g0 > 0.0) empty = true;
             if (!empty && t0 <= t1) {
-                const double tt = fmin(fmax(t_free, t0), t1);
+                const double tt = min_raw(max_raw(t_free, t0), t1);
                 const double cx = Px + tt * Ex, cy = Py + tt * Ey;
-                sec[i] = fmin(sec[i], cx * cx + cy * cy);  // squared; the root is taken once, after the reduction
+                sec[i] = min_raw(sec[i], cx * cx + cy * cy);  // squared; the root is taken once, after the reduction
             }
             // ray i: P + t E = s d with t = tc of the centre line; s follows from the projection on d (|d| = 1)
             if (centre.g1 != 0.0) {
                 const double t = centre.tc;
                 const double sd = (Px + t * Ex) * centre.dx + (Py + t * Ey) * centre.dy;
-                if (sd >= 0.0 && t >= 0.0 && t <= 1.0 && sd <= L_SECTOR) ray[i] = fmin(ray[i], sd);
+                if (sd >= 0.0 && t >= 0.0 && t <= 1.0 && sd <= L_SECTOR) ray[i] = min_raw(ray[i], sd);
             }
             lower = upper;
         }
@@ -256,22 +275,22 @@ __global__ __launch_bounds__(WAVE, 4) void env_step_kernel(EnvK k, const double*
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const double keep = h5 ? ray[i] : sec[i], send = h5 ? sec[i] : ray[i];
-            v8[i] = fmin(keep, __shfl_xor(send, 32, WAVE));
+            v8[i] = min_raw(keep, __shfl_xor(send, 32, WAVE));
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const double keep = h4 ? v8[4 + i] : v8[i], send = h4 ? v8[i] : v8[4 + i];
-            v4[i] = fmin(keep, __shfl_xor(send, 16, WAVE));
+            v4[i] = min_raw(keep, __shfl_xor(send, 16, WAVE));
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const double keep = h3 ? v4[2 + i] : v4[i], send = h3 ? v4[i] : v4[2 + i];
-            v2[i] = fmin(keep, __shfl_xor(send, 8, WAVE));
+            v2[i] = min_raw(keep, __shfl_xor(send, 8, WAVE));
         }
         const double keep = h2 ? v2[1] : v2[0], send = h2 ? v2[0] : v2[1];
-        red = fmin(keep, __shfl_xor(send, 4, WAVE));
-        red = fmin(red, __shfl_xor(red, 2, WAVE));
-        red = fmin(red, __shfl_xor(red, 1, WAVE));
+        red = min_raw(keep, __shfl_xor(send, 4, WAVE));
+        red = min_raw(red, __shfl_xor(red, 2, WAVE));
+        red = min_raw(red, __shfl_xor(red, 1, WAVE));
     }
     // ---- external observation with one-step memory (ext_obsv_sector_and_ray.py:66-74): 16 lanes, one entry each
     if ((lane & 3) == 0) {
@@ -294,7 +313,7 @@ __global__ __launch_bounds__(WAVE, 4) void env_step_kernel(EnvK k, const double*
         const double ax = pxy[2 * lane], ay = pxy[2 * lane + 1];
         const double ex = pxy[2 * lane + 2] - ax, ey = pxy[2 * lane + 3] - ay;
         const double den = ex * ex + ey * ey;
-        double t = den == 0.0 ? 0.0 : ((x - ax) * ex + (y - ay) * ey) / den;
+        double t = den == 0.0 ? 0.0 : ((x - ax) * ex + (y - ay) * ey) * fast_rcp(den);
         t = fmin(1.0, fmax(0.0, t));
         cpx = ax + t * ex; cpy = ay + t * ey;
         tproj = t;
@@ -314,7 +333,7 @@ __global__ __launch_bounds__(WAVE, 4) void env_step_kernel(EnvK k, const double*
         else {
             const unsigned long long bal = __ballot(lane < n_path - 1 && s < cum[lane < n_path - 1 ? lane + 1 : 0]);
             const int i = bal ? __ffsll((long long)bal) - 1 : n_path - 2;
-            const double t = (s - cum[i]) / len[i];
+            const double t = (s - cum[i]) * fast_rcp(len[i]);
             spx = pxy[2 * i] + t * (pxy[2 * i + 2] - pxy[2 * i]);
             spy = pxy[2 * i + 1] + t * (pxy[2 * i + 3] - pxy[2 * i + 1]);
         }
@@ -336,7 +355,7 @@ __global__ __launch_bounds__(WAVE, 4) void env_step_kernel(EnvK k, const double*
         const double ddx = qx - x, ddy = qy - y;
         const double d = sqrt(ddx * ddx + ddy * ddy);
         double cr = cth, sr = -sth;
-        if (d > 0.0) { cr = (ddx * cth + ddy * sth) / d; sr = (ddy * cth - ddx * sth) / d; }
+        if (d > 0.0) { const double id = fast_rcp(d); cr = (ddx * cth + ddy * sth) * id; sr = (ddy * cth - ddx * sth) * id; }
         float* o = oi + 2 + 3 * lane;
         o[0] = (float)cr; o[1] = (float)sr; o[2] = (float)normalize_distance(d);
     }
@@ -350,9 +369,9 @@ __global__ __launch_bounds__(WAVE, 4) void env_step_kernel(EnvK k, const double*
 
     if (lane == 0) {
         // ---- speed and angular velocity (components/int_obsv_speed.py, int_obsv_angular_velocity.py)
-        oi[0] = (float)(2.0 * (v - P.speed_min) / (P.speed_max - P.speed_min) - 1.0);
+        oi[0] = (float)(2.0 * (v - P.speed_min) * fast_rcp(P.speed_max - P.speed_min) - 1.0);
         // the reference normalises the angular velocity with the angular ACCELERATION limits (int_obsv_angular_velocity.py:13-19)
-        oi[1] = (float)(2.0 * (w - P.angacc_min) / (P.angacc_max - P.angacc_min) - 1.0);
+        oi[1] = (float)(2.0 * (w - P.angacc_min) * fast_rcp(P.angacc_max - P.angacc_min) - 1.0);
         if (pass == 0) {
             // ---- reward R1 (rays_reward1.py:26-39; summed in component order)
             if (act) {
@@ -379,7 +398,7 @@ __global__ __launch_bounds__(WAVE, 4) void env_step_kernel(EnvK k, const double*
     return pass == 0 && out.max_steps > 0 && act && (collided || reached || timeout);
     };  // run_pass
 
-    if (!run_pass(0)) return;
+    if (!run_pass(0, cth0, sth0)) return;
 
     // ---- the episode ended: keep its last observation, go back to the start state (environment.py:166-186) and
     //      observe once more.  The observation memory (st[8..23]) is not cleared -- the reference's component keeps it.
@@ -392,7 +411,8 @@ __global__ __launch_bounds__(WAVE, 4) void env_step_kernel(EnvK k, const double*
     __syncthreads();
     x = rec[5]; y = rec[6]; th = rec[7]; v = rec[8]; w = rec[9];
     clock = 0.0; flags = 0; steps = 0.0; last_prog = 0.0; act = false;
-    run_pass(1);
+    sincos(th, &sth0, &cth0);
+    run_pass(1, cth0, sth0);
 }
 
 thread_local std::string g_err;
