@@ -222,7 +222,7 @@ __global__ __launch_bounds__(WAVE, 4) void env_step_kernel(EnvK k, const double*
         const double t_free = ee > 0.0 ? -pe * fast_rcp(ee) : 0.0;
         // Line j through the robot with direction d_j meets the edge's carrier at parameter tc; g0 / g1 are the signed
         // distances (x |d| = 1) of P and of the edge direction from that line.  Odd lines are sector borders (each
-        // shared by two neighbouring sectors), even lines carry the rays -- 16 reciprocals per edge in all.  The lines
+        // shared by two neighbouring sectors), even lines carry the rays.  The lines
         // are walked in order and only the previous border is kept (registers: residency, see __launch_bounds__).
         struct Line { double g0, g1, tc, dx, dy; };
         asm volatile("" ::: "memory");  // keep the direction reads inside the loop (hoisted, they pin 64 VGPRs again)
@@ -234,32 +234,48 @@ __global__ __launch_bounds__(WAVE, 4) void env_step_kernel(EnvK k, const double*
             l.tc = -l.g0 * fast_rcp(l.g1);   // inf / nan when the edge is parallel to the line: handled below
             return l;
         };
-        const Line first = line(15);
-        Line lower = first;
-#pragma unroll
-        for (int i = 0; i < NSEG; ++i) {
-            const Line centre = line(2 * i);
-            const Line upper = i == NSEG - 1 ? first : line(2 * i + 1);
+        // Line j + 8 is line j walked the other way: g0 and g1 change sign, tc stays.  Sector i and the sector opposite to it (i + 4)
+        // share their two border carriers, ray i and ray i + 4 their carrier: nine line evaluations per edge instead of sixteen.
+        auto sector = [&](int i, const Line& lo, const Line& up, double sgn) {
             // wedge = {cross(d_lower, X) >= 0} and {cross(d_upper, X) <= 0}: clip the edge's parameter range [0, 1]
+            const double lg1 = sgn * lo.g1, lg0 = sgn * lo.g0, ug1 = sgn * up.g1, ug0 = sgn * up.g0;
             double t0 = 0.0, t1 = 1.0;
             bool empty = false;
-            if (lower.g1 > 0.0) t0 = max_raw(t0, lower.tc);
-            else if (lower.g1 < 0.0) t1 = min_raw(t1, lower.tc);
-            else if (lower.g0 < 0.0) empty = true;
-            if (upper.g1 < 0.0) t0 = max_raw(t0, upper.tc);
-            else if (upper.g1 > 0.0) t1 = min_raw(t1, upper.tc);
-            else if (upper.g0 > 0.0) empty = true;
+            if (lg1 > 0.0) t0 = max_raw(t0, lo.tc);
+            else if (lg1 < 0.0) t1 = min_raw(t1, lo.tc);
+            else if (lg0 < 0.0) empty = true;
+            if (ug1 < 0.0) t0 = max_raw(t0, up.tc);
+            else if (ug1 > 0.0) t1 = min_raw(t1, up.tc);
+            else if (ug0 > 0.0) empty = true;
             if (!empty && t0 <= t1) {
                 const double tt = min_raw(max_raw(t_free, t0), t1);
                 const double cx = Px + tt * Ex, cy = Py + tt * Ey;
                 sec[i] = min_raw(sec[i], cx * cx + cy * cy);  // squared; the root is taken once, after the reduction
             }
+        };
+        auto rayhit = [&](int i, const Line& ce, double sgn) {
             // ray i: P + t E = s d with t = tc of the centre line; s follows from the projection on d (|d| = 1)
-            if (centre.g1 != 0.0) {
-                const double t = centre.tc;
-                const double sd = (Px + t * Ex) * centre.dx + (Py + t * Ey) * centre.dy;
+            if (ce.g1 != 0.0) {
+                const double t = ce.tc;
+                const double sd = sgn * ((Px + t * Ex) * ce.dx + (Py + t * Ey) * ce.dy);
                 if (sd >= 0.0 && t >= 0.0 && t <= 1.0 && sd <= L_SECTOR) ray[i] = min_raw(ray[i], sd);
             }
+        };
+        Line lower = line(7);   // line 15 = line 7 reversed: the lower border of sector 0
+#pragma unroll
+        for (int i = 0; i < NSEG / 2; ++i) {
+            const Line centre = line(2 * i);
+            const Line upper = line(2 * i + 1);
+            // sector i lies between lines 2i - 1 and 2i + 1; for i = 0 the lower border is line 15 = -line 7
+            {   // sector i
+                Line lo = lower;
+                if (i == 0) { lo.g0 = -lo.g0; lo.g1 = -lo.g1; }
+                sector(i, lo, upper, 1.0);
+                // the opposite sector i + 4: borders 2i + 7 = -(2i - 1) ... and 2i + 9 = -(2i + 1)
+                sector(i + NSEG / 2, lo, upper, -1.0);
+            }
+            rayhit(i, centre, 1.0);
+            rayhit(i + NSEG / 2, centre, -1.0);
             lower = upper;
         }
     }
