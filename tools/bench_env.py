@@ -24,10 +24,10 @@ HBM_PEAK_GBS = 8000.0
 
 
 def measured_traffic(B):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_env_hbm_traffic.json), when they were
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r04_env_hbm_traffic.json), when they were
     collected on this batch size."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_env_hbm_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r04_env_hbm_traffic.json")) as fh:
             d = json.load(fh)
         return d["env_step_kernel_bytes_per_launch"] if d["workload"]["batch_per_gpu"] == B else None
     except (OSError, KeyError, ValueError):
