@@ -21,8 +21,10 @@
 // Wave priority (s_setprio; round 4): the phases of an evaluation that are chains of dependent cross-lane steps (rollout scans, adjoint,
 // and the solver logic between two evaluations) run at a raised priority, the item loops -- independent work per lane, the part that
 // fills the issue slots other wavefronts leave -- at the base priority: a wavefront in a chain issues as soon as its operand arrives
-// instead of waiting its turn.  No instruction but the two s_setprio per evaluation; same bits.  -1.0 % kernel time at N_hor = 20
-// and 40 (profiles/r04_setprio_ab.txt); with the raised priority ending at the end of the evaluation (logic at base) the gain is lost.
+// instead of waiting its turn.  No instruction but the two s_setprio per evaluation; same bits.  N_hor = 20 only: -1 % kernel time at
+// B = 32768, -2.5 % at B = 8192; with the raised priority ending at the end of the evaluation (logic at base) the gain is lost.  At
+// N_hor = 40 (three wavefronts per SIMD) it is -1 % at B = 16384 and +1.5 % at B = 4096, config 3's batch: not used there
+// (profiles/r04_setprio_ab.txt).
 #ifndef MPC_SETPRIO
 #define MPC_SETPRIO 1
 #endif
@@ -956,7 +958,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     const double fleetw = here_s(kp.fleetw);
     const double inf = __builtin_huge_val();
     if (!c_vl) { v = 0.0; w = 0.0; }
-    MPC_PRIO_CHAIN();
+    if (NT == 20) MPC_PRIO_CHAIN();
 
     // ---- rollout.  Heading phasors e^{i theta}: theta_{k+1} = theta_k + ts*w_k, so they are a prefix PRODUCT of
     //      unit complex numbers e^{i ts w_k} (DPP scan); positions are a prefix SUM of Simpson increments.
@@ -1017,7 +1019,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     }
     wave_sync();
     PROF_MARK(1);  // positions + publish
-    MPC_PRIO_ITEMS();
+    if (NT == 20) MPC_PRIO_ITEMS();
 
     // ---- item phase A: stage terms of step ik handled by this lane
     double cost_l = 0.0, S_l = 0.0, gx = 0.0, gy = 0.0, dsx = 0.0, dsy = 0.0;
@@ -1349,7 +1351,7 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     }
 
     PROF_MARK(6);  // phase B
-    MPC_PRIO_CHAIN();
+    if (NT == 20) MPC_PRIO_CHAIN();
     // ---- combine the LPS item lanes of each step on its vector lane.  Lane k < N is itself the first item lane of step k
     //      (sub 0): its partial stays in registers, only the lanes of sub >= 1 go through LDS.
     if (c_il && c_isub > 0) {
