@@ -26,4 +26,4 @@ def test_plain_c_program_solves_through_the_c_abi(tmp_path):
     print("\n" + one.stdout)
     assert "latency kernel 4" in one.stdout
     call_ms = float(one.stdout.split("best of 10:")[1].split("ms")[0])
-    assert call_ms < 0.8, call_ms
+    assert call_ms < 5.0, call_ms      # a sanity bound, not a benchmark (typically 0.3 ms; tools/latency.py measures it)
