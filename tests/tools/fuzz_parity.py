@@ -2,7 +2,7 @@
 """Fuzz run (GPU box; test tooling -- it imports the oracle): random horizons, obstacle / robot counts MIXED inside one batch, scene
 families, penalties and multipliers; the HIP path against the CPU oracle on psi / f / grad psi / F1 / F2 (1e-9 relative) and on short
 tracked solves (same iteration counts, |du| small).  Also perturbs the tables the scenes never produce: rotated and time-varying
-ellipses, rotated static polygons, terminal weights.  usage: python tests/tools/fuzz_parity.py [trials = 40] [seed = 0]"""
+ellipses, rotated static polygons, terminal weights.  usage: python tests/tools/fuzz_parity.py [trials = 40] [seed = 0] [full-solve trials = 0]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -86,5 +86,42 @@ for trial in range(trials):
     print(f"trial {trial:3d} N {N:2d} mode {mode} latency {shape['latency_kernel']} max_dyn {shape['max_dyn']} max_static {shape['max_static']} "
           f"max_fleet {shape['max_fleet']}: cost/grad ok so far {not [b for b in bad if b[0] == 'cost_grad']}, solve du median {np.median(du):.1e} max {du.max():.1e} "
           f"same iteration counts {same_it}", flush=True)
+
+# ---- optional: FULL solves (reference caps) of mixed batches against the oracle: converged-on-both pairs within the north-star tolerance
+n_full = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+both = agree = total = far = self_both = self_far = 0
+worst_du = 0.0
+for trial in range(n_full):
+    rng = np.random.default_rng(seed0 * 1000 + 500 + trial)
+    N = int(rng.choice([20, 20, 40]))
+    cfg = MpcConfig(N_hor=N)
+    parts = []
+    for sub in range(3):
+        n_dyn = int(rng.integers(1, cfg.Ndynobs + 1)); n_other = int(rng.integers(0, 4))
+        fam = str(rng.choice(["passing", "avoidance", "on_track"]))
+        kw = dict(scenes.FAMILIES[fam])
+        if "n_block" in kw and kw["n_block"][1] > n_dyn: kw["n_block"] = (1, max(1, n_dyn))
+        parts.append(scenes.make_batch(cfg, 8, n_dyn=n_dyn, n_other=n_other, seed=int(rng.integers(1 << 30)), **kw)["p"])
+    p = np.concatenate(parts); B = p.shape[0]
+    bs = BatchSolver(cfg, latency_batch=int(rng.choice([0, 1 << 20])))
+    res = bs.solve(p)
+    uo, _, ro, _ = oracle.solve_batch(ocfg_of(cfg), p, np.zeros((B, 2 * N)))
+    bs.close()
+    # the oracle against itself with every parameter moved by one ulp: what two float64 implementations may differ by
+    u1, _, r1, _ = oracle.solve_batch(ocfg_of(cfg), np.nextafter(p, np.inf), np.zeros((B, 2 * N)))
+    ok1 = (np.asarray(ro["status"]) == 0) & (np.asarray(r1["status"]) == 0)
+    du1 = np.max(np.abs(u1 - uo), axis=1)
+    self_both += int(ok1.sum()); self_far += int((ok1 & (du1 > 1e-3)).sum())
+    so = np.asarray(ro["status"]); sg = res.status
+    ok = (so == 0) & (sg == 0)
+    du = np.max(np.abs(res.solution - uo), axis=1)
+    both += int(ok.sum()); agree += int(((so == 0) == (sg == 0)).sum()); total += B
+    if ok.any(): worst_du = max(worst_du, float(du[ok].max()))
+    far += int((ok & (du > 1e-3)).sum())
+    if ok.any() and du[ok].max() > 1e-3: bad.append(("full", trial, N, int(np.argmax(np.where(ok, du, 0))), float(du[ok].max())))
+    print(f"full {trial:3d} N {N}: converged on both {int(ok.sum())}/{B}, max |du| on them {du[ok].max() if ok.any() else 0:.1e}, same converged/not {int(((so == 0) == (sg == 0)).sum())}/{B}", flush=True)
+if n_full:
+    print(f"full solves: {both} of {total} converged on both sides, {far} of them farther apart than 1e-3 (worst {worst_du:.2e}), agreement on which converge {agree / total:.3f}")
+    print(f"oracle vs 1-ulp oracle on the same problems: {self_both} converged on both, {self_far} of them farther apart than 1e-3")
 print("worst relative errors:", {k: f"{v:.2e}" for k, v in worst.items()})
 print("failures:", bad if bad else "none", f"({time.time() - t_start:.0f} s)")
