@@ -25,16 +25,8 @@
 // B = 32768, -2.5 % at B = 8192; with the raised priority ending at the end of the evaluation (logic at base) the gain is lost.  At
 // N_hor = 40 (three wavefronts per SIMD) it is -1 % at B = 16384 and +1.5 % at B = 4096, config 3's batch: not used there
 // (profiles/r04_setprio_ab.txt).
-#ifndef MPC_SETPRIO
-#define MPC_SETPRIO 1
-#endif
-#if MPC_SETPRIO
 #define MPC_PRIO_CHAIN() __builtin_amdgcn_s_setprio(2)
 #define MPC_PRIO_ITEMS() __builtin_amdgcn_s_setprio(0)
-#else
-#define MPC_PRIO_CHAIN()
-#define MPC_PRIO_ITEMS()
-#endif
 #define MPC_ITEM_LOOP _Pragma("unroll 1")  // item loops: keep the loads of one iteration in flight, not of all (other policies: +-1 %, round 2)
 
 namespace mpcgpu {
