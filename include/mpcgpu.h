@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MPCGPU_ABI_VERSION 6
+#define MPCGPU_ABI_VERSION 7
 
 /* replaces: the yaml config consumed by MpcModule.build (mpc_generator.py:151-158, config/mpc_default.yaml:7-55)
  * plus the SolverConfiguration of mpc_generator.py:285-293 (opengen defaults quoted there). */
@@ -197,9 +197,20 @@ int32_t mpcgpu_reserve_batch(void* handle, int32_t B);
  *       resident per compute unit; a problem with a row that does not fit is solved from the stored centres by a pick-up launch
  *       right behind.  Bitwise the same results -- and measured SLOWER (the 128-register build spills: profiles/
  *       r04_linear_tables_ab.txt), which is why the product does not carry it.  0: always the stored centres.
+ *   MPCGPU_OPT_TAIL_PROMOTION  (ABI 7) the tail of a throughput launch.  A solve is one long dependency chain, so the last problems
+ *       of a large batch finish on a draining GPU (0.07-0.08 s per launch whatever the batch).  -1 (default): once all but
+ *       K = 2 x #CUs problems of the launch have finished, every wavefront that is still running leaves at its next PANOC step
+ *       boundary -- the state of its iteration goes into the problem's workspace record -- and a continuation launch of the
+ *       LATENCY kernel on the same stream (four wavefronts per problem: the evaluations of a step side by side, 2.3 x faster per
+ *       problem on an empty GPU) finishes those problems from exactly that boundary.  > 0: that K (up to 2 x #CUs: four wavefronts per
+ *       problem, beyond: two); 0: off.  Same step functions on the same state: every output is BITWISE what the throughput kernel
+ *       alone writes (tests/test_gpu_yield.py); nothing is read back, the call stays capturable.  The reference has no counterpart.
+ *   MPCGPU_OPT_TAIL_POLL  (ABI 7) PANOC steps between two looks at the launch's finished-counter (a power of two, default 16;
+ *       only the A/B build -DMPC_YIELD_STEP=1 looks inside an inner problem at all).
+ *   MPCGPU_OPT_TAIL_WAVES  (ABI 7) wavefronts per promoted problem: 0 (default) by K as above, 2 or 4.
  */
 enum { MPCGPU_OPT_LINESEARCH_FALLBACK = 1, MPCGPU_OPT_PAIRING = 2, MPCGPU_OPT_TEAM_BATCH = 3, MPCGPU_OPT_ORDER = 4,
-       MPCGPU_OPT_LINEAR_TABLES = 5 };
+       MPCGPU_OPT_LINEAR_TABLES = 5, MPCGPU_OPT_TAIL_PROMOTION = 6, MPCGPU_OPT_TAIL_POLL = 7, MPCGPU_OPT_TAIL_WAVES = 8 };
 int32_t mpcgpu_set_option(void* handle, int32_t option, double value);
 
 /* Register-allocation variant the last solve call was launched with: 3 (148 / 168 VGPRs) or 4 wavefronts per SIMD
@@ -222,6 +233,11 @@ int32_t mpcgpu_last_problems_per_wavefront(void* handle);
 
 /* 1 when the last solve call started its problems longest first (MPCGPU_OPT_ORDER), 0 when in the order given. */
 int32_t mpcgpu_last_ordered(void* handle);
+
+/* (ABI 7) Tail promotion of the last solve call (MPCGPU_OPT_TAIL_PROMOTION): returns the capacity K of its continuation launch
+ * (0: none was enqueued -- latency-kernel batch, option off, two problems per wavefront).  `promoted` (may be NULL): how many
+ * problems actually moved to the latency kernel; reading it waits for `stream` (the stream the call was enqueued on). */
+int32_t mpcgpu_last_tail_promotion(void* handle, int32_t* promoted, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------------
  * Batched tracker harness on the device.  Replaces, for B robots per call and without a

@@ -65,6 +65,38 @@ def test_latency_kernel_with_short_caps_warm_start_and_multipliers():
     fast.close(); seq.close()
 
 
+@pytest.mark.parametrize("waves", [4, 2])
+def test_inner_problems_without_a_step(waves):
+    """Round 5.  With an inner cap near the length of the first inner problem, many second inner problems meet their tolerance at
+    the first residual and take NO PANOC step.  A build of the latency kernel whose loop-carried scalars had been packed by the
+    SLP vectoriser lost the iteration total and moved the L-BFGS ring position exactly there (and parted from the throughput
+    kernel by an ulp in the next inner problem): csrc/Makefile, -fno-slp-vectorize.  Also: the avoidance family at full caps."""
+    n = 1000
+    base = make_cfg(20)
+    p = scenes.make_family(base, n, "avoidance", n_dyn=8, seed=320)["p"]
+    zero_step = 0
+    for caps in ((3, 139), (3, 140), (4, 60), (10, 500)):
+        cfg = make_cfg(20, solver_max_outer_iterations=caps[0], solver_max_inner_iterations=caps[1])
+        seq = BatchSolver(cfg, latency_batch=0, tail_promotion=0)
+        fast = BatchSolver(cfg, latency_batch=n, tail_promotion=0)
+        fast.set_tail_promotion(0, waves=waves)
+        for bs in (seq, fast):
+            bs.reserve_shape(max_static=5, max_fleet=0, max_dyn=8, var_shape=True)
+        a, b = seq.solve(p), fast.solve(p)
+        assert int(fast._L.mpcgpu_last_latency_kernel(fast._h)) == waves and not seq.last_shape()["latency_kernel"]
+        _same(a, b)
+        ea, eb = seq.last_eval_counts(n), fast.last_eval_counts(n)
+        assert np.array_equal(ea[0], eb[0]) and np.array_equal(ea[1], eb[1])
+        if caps[0] == 3:   # problems whose second inner problem took no step: 3 evaluations (initial point, Lipschitz estimate, outer step)
+            two = BatchSolver(make_cfg(20, solver_max_outer_iterations=2, solver_max_inner_iterations=caps[1]), latency_batch=0, tail_promotion=0)
+            one = BatchSolver(make_cfg(20, solver_max_outer_iterations=1, solver_max_inner_iterations=caps[1]), latency_batch=0, tail_promotion=0)
+            r2, r1 = two.solve(p), one.solve(p)
+            zero_step += int(np.sum((r2.num_outer_iterations == 2) & (r2.num_inner_iterations == r1.num_inner_iterations)))
+            two.close(); one.close()
+        seq.close(); fast.close()
+    assert zero_step >= 5, zero_step
+
+
 def test_selection_rule_and_single_problem_call():
     cfg = make_cfg(20)
     sc = scenes.make_batch(cfg, 2048, n_dyn=4, seed=3, dyn_clearance=0.1, box_clearance=0.3)

@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/../trajtrack_mpcndqn_rlboost_amd/csrc" || exit 1
 mkdir -p /tmp/asm/k
 K=${KERNEL:-solve_kernel_pairILi20ELb1ELb1ELi4ELb1E}
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-variable -ffp-contract=on -mllvm -amdgpu-sched-strategy=iterative-ilp \
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-variable -ffp-contract=on -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-ilp \
   --cuda-device-only -S -o /tmp/asm/k/all.s "$@" mpcgpu.hip || exit 1
 awk -v k="$K" '$0 ~ "^_ZN6mpcgpu.*"k".*:" {p=1} p {print} p && /^\.Lfunc_end/ {exit}' /tmp/asm/k/all.s > /tmp/asm/k.s
 grep -E "^; (NumVgprs|ScratchSize|Occupancy|codeLenInByte|NumSgprs)|sgpr_spill_count|vgpr_spill_count" /tmp/asm/k/all.s | head -0

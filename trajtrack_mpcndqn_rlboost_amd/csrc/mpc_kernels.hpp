@@ -99,7 +99,9 @@ enum { H_KS = 18, H_KF = 19, H_KD = 20, H_CTH0 = 21, H_STH0 = 22, H_NPF = 23, H_
 // batch-wide reductions written by the compaction kernel
 enum { CNT_KS = 0, CNT_KF = 1, CNT_KD = 2, CNT_VARSHAPE = 3, CNT_ROTATED = 4 /* some active dynamic row is not an axis-aligned ellipse (angle != 0) */,
        CNT_NONLINEAR = 5 /* some active dynamic row is not a straight-line prediction */,
-       CNT_NL_COUNT = 6 /* length of the list of such problems (nl_list_kernel) */, CNT_WORDS = 8 };
+       CNT_NL_COUNT = 6 /* length of the list of such problems (nl_list_kernel) */,
+       CNT_FINISHED = 8 /* problems of the running throughput launch that have written their results (tail promotion, see YIELD) */,
+       CNT_YIELDED = 9 /* length of the list of problems that left the throughput launch at a step boundary */, CNT_WORDS = 12 };
 
 struct KParams {
     int N, Nother, Nstcobs, Ndynobs, np, mem;
@@ -119,7 +121,42 @@ struct KParams {
     int reserved;  // 1: the carve comes from mpcgpu_reserve_shape, problems are checked against it on the device
     int l_seg, l_stc, l_fxy, l_dyn, l_dync, l_dynl, l_qd, l_pos, l_H, l_W, l_part, l_bal, l_stash, l_hd, l_S, l_Y, l_rho, l_alpha, l_old, l_gg, l_total;
     int l_wstride, l_xch;  // team kernel (mpc_team.hpp): doubles per wavefront work block, offset of the exchange area
+    // tail promotion (YIELD below): a problem of the throughput launch leaves at a PANOC step boundary once `yield_from` problems
+    // of the launch have finished; 0 = off.  yield_cap: capacity of the list, yield_mask: the counter is polled when
+    // (step & yield_mask) == 0, ws_yield: offset of the saved iteration state in the workspace record.
+    int yield_from, yield_cap, yield_mask, ws_yield;
 };
+
+// ------------------------------------------------------------------------------------------------
+// TAIL PROMOTION (round 5).  A solve is one long dependency chain, so the last problems of a throughput launch finish on a
+// draining GPU: 0.07-0.08 s per launch whatever the batch (a quarter of a launch of 8192 problems).  The latency kernel
+// (mpc_team.hpp) runs the SAME iteration 2.3 x faster per problem -- when the GPU is empty.  So: every problem of the throughput
+// launch counts itself as finished (CNT_FINISHED); once all but `yield_cap` problems of the launch have finished, a wavefront that
+// reaches a PANOC step boundary writes the state of its iteration into its workspace record (the L-BFGS ring, the previous
+// iterate and the multipliers live there already), appends its problem to a list and leaves; a continuation launch of the latency
+// kernel on the same stream (solve_kernel_team with io.ylist set, grid = yield_cap, workgroups beyond the device-side list length leave
+// at once) picks the iteration up at that boundary.  Both kernels run the same step functions on the same state: every output is
+// BITWISE what the throughput kernel alone would have written (tests/test_gpu_yield.py).  Nothing is read back; capturable.
+// Record at ws_yield (doubles): YS_* scalars, then [N][8] = (u, grad, half step, multipliers) of every step, then the L-BFGS
+// scalars that live in LDS (rho, Gram matrices).
+// ------------------------------------------------------------------------------------------------
+// Where a problem may leave.  0 (product): at the start of an inner problem only -- the state machine of solve_body, ten times per
+// solve; the loop of the PANOC steps is untouched (a running problem takes up to one inner problem, <= max_inner steps, to get
+// there).  1 (A/B build): also at every yield_mask + 1-th PANOC step, with the whole PANOC cache and the L-BFGS buffer in the
+// record -- measured: the extra exit of the step loop costs registers in the 128-VGPR build (64 -> 92 spilled VGPRs, +59 lane
+// reads per step), more than the 2-5 ms the finer grain saves per launch.
+#ifndef MPC_YIELD_STEP
+#define MPC_YIELD_STEP 0
+#endif
+enum { YS_C = 0, YS_GAMMA, YS_IG, YS_LIP, YS_SIGMA, YS_COST, YS_GG, YS_D2H, YS_AKKT, YS_NFPR, YS_IP, YS_DYN, YS_F2N, YS_LASTFPR, YS_FFINAL,
+       YS_HGAMMA, YS_ELAPSED, YS_ITER, YS_NUMITER, YS_FLAGS /* 1 cont_iters, 2 cont_time, 4 a step has completed, 8 L-BFGS buffer empty, 16 left at the start of an inner problem */,
+       YS_ALMIT, YS_NOUTER, YS_INNERTOT, YS_STATUS, YS_NEVAL, YS_NEVALG, YS_LBACTIVE, YS_LBHEAD, YS_TRN, YS_TRPSI, YS_SCALARS = 32 };
+constexpr int YS_VECW = 8;
+__host__ __device__ constexpr int yield_even_c(int x) { return (x + 1) & ~1; }
+// doubles of the LDS region `gg` (Gram matrices, or the alpha scratch of the two-loop form): see fixed_lds
+__host__ __device__ constexpr int gg_doubles_c(int N, int mem, bool gram) {
+    return gram ? yield_even_c(mem * mem + mem * (mem + 1) / 2) : yield_even_c(mem);
+}
 
 // How H * (gamma fpr) is evaluated: 1 = Gram form (PanocLbfgsGram, round 3), 0 = two-loop recursion (PanocLbfgs; the build
 // `make variants` keeps as libmpcgpu_twoloop.so for A/B runs).  Two problems per wavefront (Duo) always take the two-loop form.
@@ -234,6 +271,7 @@ struct BatchPtrs {
     const int32_t* perm;  // throughput kernel: workgroup g solves problem perm[g] (NULL: problem g) -- MPCGPU_OPT_ORDER, mpc_order.hpp
     const int* nsel;      // != NULL: only the first *nsel entries of `perm` are problems of this launch (device-side count: the
                           // launch that picks up the problems a linear-table launch left out)
+    int32_t* ylist;       // tail promotion: problems that left the throughput launch at a step boundary (length: counts[CNT_YIELDED])
     double* trace;   // -DMPC_TRACE builds only: [B][trace_cap][TRACE_W] decision trace, one record per PANOC step
     int trace_cap;
 };
@@ -2111,6 +2149,7 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
                 if (io.fpr) io.fpr[b] = nan;         // every optional output is written: no stale value of an earlier call survives
                 if (io.f2norm) io.f2norm[b] = nan;
                 if (io.ms) io.ms[b] = 0.0;
+                if (kp.yield_from > 0) __hip_atomic_fetch_add(io.counts + CNT_FINISHED, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             return;
         }
@@ -2183,8 +2222,22 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
 #ifdef MPC_PROFILE
     Prof prof; prof.start();
 #endif
+    // tail promotion (see YIELD at KParams): this problem leaves at a step boundary once the launch is draining
+    constexpr bool CAN_YIELD = MPC_STEP_LOOP && !P::DUO && !LIN;
+    bool yielded = false, count_step = false;
+    int yslot = 0;
 
     for (;;) {
+        if (CAN_YIELD && state == ST_INIT0 && kp.yield_from > 0) {
+            // Start of an inner problem: the launch is draining when all but yield_cap of its problems have finished -- hand this one
+            // to the latency kernel.  Here the state of the iteration is small (point, multipliers, penalty, tolerance, counters: the
+            // PANOC cache and the L-BFGS buffer are empty) and nothing is added to the loop of the PANOC steps.
+            if (__hip_atomic_load(io.counts + CNT_FINISHED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= kp.yield_from) {
+                if (lane == 0) yslot = __hip_atomic_fetch_add(io.counts + CNT_YIELDED, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                yslot = __builtin_amdgcn_readfirstlane(yslot);
+                if (yslot < kp.yield_cap) { yielded = true; break; }   // (the list cannot overflow: at most yield_cap problems are unfinished)
+            }
+        }
         PROF_MARK(10 + state);  // solver logic that led to this evaluation (by the state it was issued for)
         PROF_COUNT(16 + state);
         ++n_eval; n_eval_grad += want_grad ? 1 : 0;
@@ -2315,9 +2368,17 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
         if (step_begin) {
             // ---- the PANOC steps of an inner problem: a loop of its own with its own call sites of eval_point (Lipschitz test,
             //      line search); the state machine above is left with the evaluations that happen ten times per solve.
-            bool count_step = state != ST_INIT1;   // a full step has completed: the solver loop's bookkeeping
+            count_step = state != ST_INIT1;   // a full step has completed: the solver loop's bookkeeping
             bool to_nols = false;
             for (;;) {
+                if (CAN_YIELD && MPC_YIELD_STEP && kp.yield_from > 0 && (num_iter & kp.yield_mask) == 0) {
+                    // the launch is draining when all but yield_cap of its problems have finished: hand this one to the latency kernel
+                    if (__hip_atomic_load(io.counts + CNT_FINISHED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= kp.yield_from) {
+                        if (lane == 0) yslot = __hip_atomic_fetch_add(io.counts + CNT_YIELDED, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        yslot = __builtin_amdgcn_readfirstlane(yslot);
+                        if (yslot < kp.yield_cap) { yielded = true; break; }   // (the list cannot overflow: at most yield_cap problems are unfinished)
+                    }
+                }
                 bool inner_done = false;
                 if (count_step) {
                     if (cont_iters && cont_time) {
@@ -2385,6 +2446,7 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
 #endif
                 ++iter;
             }
+            if (CAN_YIELD && MPC_YIELD_STEP && yielded) break;
             if (to_nols) {
                 uv = hv; uw = hw;
                 ev = uv; ew = uw; want_grad = true; state = ST_NOLS;
@@ -2395,6 +2457,68 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
             uv = hv; uw = hw;
             ev = uv; ew = uw; want_grad = false; state = ST_OUTER;
         }
+    }
+    if (CAN_YIELD && yielded) {
+        // ---- the state of the iteration at this step boundary -> the problem's workspace record; the continuation launch
+        //      (solve_kernel_team with io.ylist set) reads it back and goes on with the bookkeeping of the step loop above
+        double* yr = io.ws + (size_t)b * kp.ws_stride + kp.ws_yield;
+        if (state == ST_INIT0) {   // start of an inner problem: point, multipliers and the scalars of the outer loop
+            if (vl) {
+                double2* v = reinterpret_cast<double2*>(yr + YS_SCALARS + lane * YS_VECW);
+                v[0] = make_double2(uv, uw); v[3] = make_double2(ya, yb);
+            }
+            if (lane == 0) {
+                yr[YS_C] = c; yr[YS_AKKT] = akkt_tol; yr[YS_DYN] = dy_norm; yr[YS_F2N] = f2_norm;
+                yr[YS_ELAPSED] = (double)(wall_clock64() - t_start);
+                yr[YS_FLAGS] = 16;
+                yr[YS_ALMIT] = alm_iteration; yr[YS_NOUTER] = num_outer; yr[YS_INNERTOT] = inner_total;
+                yr[YS_NEVAL] = n_eval; yr[YS_NEVALG] = n_eval_grad;
+                yr[YS_LBHEAD] = lb.head;   // the ring keeps its position across a flush, and the Gram form sums the rows in slot order
+#ifdef MPC_TRACE
+                yr[YS_TRN] = tr_n;
+#endif
+                io.ylist[yslot] = b;
+            }
+#ifdef MPC_PROFILE
+            prof.mark(22); prof.flush();
+#endif
+            return;
+        }
+#if MPC_YIELD_STEP
+        if (vl) {
+            double2* v = reinterpret_cast<double2*>(yr + YS_SCALARS + lane * YS_VECW);
+            v[0] = make_double2(uv, uw); v[1] = make_double2(gv, gw); v[2] = make_double2(hv, hw); v[3] = make_double2(ya, yb);
+        }
+        if (lane == 0) {
+            yr[YS_C] = c; yr[YS_GAMMA] = gamma; yr[YS_IG] = ig; yr[YS_LIP] = Lip; yr[YS_COST] = cost;
+            yr[YS_GG] = gg; yr[YS_D2H] = d2h; yr[YS_AKKT] = akkt_tol; yr[YS_NFPR] = nfpr;
+            yr[YS_DYN] = dy_norm; yr[YS_F2N] = f2_norm;
+            yr[YS_HGAMMA] = lb.hgamma; yr[YS_ELAPSED] = (double)(wall_clock64() - t_start);
+            yr[YS_ITER] = iter; yr[YS_NUMITER] = num_iter;
+            yr[YS_FLAGS] = (cont_iters ? 1 : 0) | (cont_time ? 2 : 0) | (count_step ? 4 : 0) | (lb.first ? 8 : 0);
+            yr[YS_ALMIT] = alm_iteration; yr[YS_NOUTER] = num_outer; yr[YS_INNERTOT] = inner_total;
+            yr[YS_NEVAL] = n_eval; yr[YS_NEVALG] = n_eval_grad; yr[YS_LBACTIVE] = lb.active; yr[YS_LBHEAD] = lb.head;
+#ifdef MPC_TRACE
+            yr[YS_TRN] = tr_n; yr[YS_TRPSI] = tr_psi_u;
+#endif
+            io.ylist[yslot] = b;
+        }
+        {   // the L-BFGS scalars that live in LDS: rho and the Gram matrices (or nothing worth keeping, two-loop form)
+            double* yl = yr + YS_SCALARS + N * YS_VECW;
+            const int nrho = yield_even_c(mem), ngg = gg_doubles_c(N, mem, gram_shape(N, mem));
+            for (int i = lane; i < nrho; i += P::W) yl[i] = lm.LRHO[i];
+            for (int i = lane; i < ngg; i += P::W) yl[nrho + i] = lm.GG[i];
+        }
+        if (!LBG) {   // L-BFGS-in-LDS build: the ring and the previous (u, gamma fpr) travel through the record as well
+            double* wr = io.ws + (size_t)b * kp.ws_stride;
+            for (int i = lane; i < (2 * mem + 1) * N * 2; i += P::W) wr[kp.ws_lbs + i] = lm.LM[i];
+            for (int i = lane; i < N * 4; i += P::W) wr[kp.ws_lold + i] = lm.LOLD[i];
+        }
+#ifdef MPC_PROFILE
+        prof.mark(22); prof.flush();
+#endif
+#endif
+        return;
     }
 #else
         if (step_begin) {
@@ -2445,6 +2569,7 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
         if (io.fpr) io.fpr[b] = last_fpr;
         if (io.f2norm) io.f2norm[b] = f2_norm_plus;
         if (io.ms) io.ms[b] = (double)(wall_clock64() - t_start) * 1e-5;  // 100 MHz ticks -> ms
+        if (kp.yield_from > 0) __hip_atomic_fetch_add(io.counts + CNT_FINISHED, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

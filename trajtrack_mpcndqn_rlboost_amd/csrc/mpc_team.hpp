@@ -26,22 +26,43 @@ namespace mpcgpu {
 constexpr int TEAM_WAVES = 4;   // wavefronts per problem of the latency kernel proper; the mid-batch form runs 2 (template parameter TW)
 constexpr int TEAM_XCH = 8;  // doubles per wavefront in the exchange area
 
+// 2^-k, k = 0 .. 1022, built from its bit pattern: the line-search step lengths tau = 1, 1/2, 1/4, ... of the throughput kernel are
+// exact halvings; a library exp2 is not REQUIRED to return the exact power (and need not be the same code in every kernel)
+__device__ __forceinline__ double pow2_neg(int k) { return __hiloint2double((1023 - k) << 20, 0); }
+
 enum { TS_INIT0 = 0, TS_INIT1, TS_FIRST, TS_SPEC, TS_LIPSEQ, TS_BATCH, TS_FALLBACK, TS_OUTER };
 
 // TW = 4: wavefront 0 takes the Lipschitz test, wavefronts 1-3 the trials tau = 1, 1/2, 1/4 (1.38 passes per PANOC step on the
 // benchmark scenes).  TW = 2 (round 3, batches between 2 and 4 problems per compute unit): Lipschitz test + tau = 1 side by side
 // -- 67 % of the steps end there -- then two trials per pass; a workgroup is half as big, so twice as many problems are resident
 // and such a batch runs in ONE round instead of two.  Same device functions, same bits.
+// RESUME (round 5, tail promotion -- see YIELD in mpc_kernels.hpp): the same kernel is the continuation of a throughput launch
+// when it is handed the list of promoted problems (io.ylist != NULL; a RUN-TIME switch on purpose: the loop below is then the very
+// machine code every latency-kernel test exercises, not a second instantiation of it).  Workgroup g takes problem ylist[g]
+// (workgroups beyond the device-side list length leave at once), reads the state its wavefront of the throughput kernel left in
+// the workspace record at the start of an inner problem -- point, multipliers, penalty, tolerance, the outer loop's scalars and
+// counters, the ring position -- into every replica and starts that inner problem.  Same step functions, same state: bitwise
+// what the throughput kernel would have gone on to write.
 template <int NT, int TW>
 __global__ __launch_bounds__(WAVE * TW) void solve_kernel_team(KParams kp, BatchPtrs io, int B) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     using P = Solo<NT>;
     constexpr bool SC = false;  // general tables: no batch-wide shape information is needed before the launch
     const int N = NT ? NT : kp.N;  // compile-time horizon (0 = runtime horizon from KParams)
-    const int b = blockIdx.x;
+    const bool resume = io.ylist != nullptr;
+    int b = blockIdx.x;
+    if (resume) {
+        int n = io.counts[CNT_YIELDED];
+        n = n < kp.yield_cap ? n : kp.yield_cap;
+        if (b >= n) return;
+        b = __builtin_amdgcn_readfirstlane(io.ylist[b]);
+    }
     if (b >= B) return;
-    const long long t_start = wall_clock64();
-    const int wid = threadIdx.x >> 6, lane = threadIdx.x & (WAVE - 1), mem = kp.mem;
+    long long t_start = wall_clock64();
+    // The wavefront's index is wave-uniform, and the compiler is told so (v_readfirstlane): every `wid` branch below -- whose
+    // evaluation point, who publishes, who hands over -- is then a scalar branch instead of a divergent region that a wavefront
+    // walks through with an empty EXEC mask.
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & (WAVE - 1), mem = kp.mem;
     double* ws = io.ws + (size_t)b * kp.ws_stride;
     if (kp.reserved) {   // tables sized from promised / measured maxima: a problem beyond them is reported, not solved (solve_body)
         const bool over = (int)uniform(ws[H_KS]) > kp.mKs || (int)uniform(ws[H_KF]) > kp.mKf || (int)uniform(ws[H_KD]) > kp.mKd;
@@ -146,6 +167,58 @@ __global__ __launch_bounds__(WAVE * TW) void solve_kernel_team(KParams kp, Batch
 #define TEAM_TRACE_PSI()
 #endif
     int state = TS_INIT0;
+    bool resume_pending = false;
+    if (resume) {
+        // the boundary the throughput kernel left at (solve_body, `yielded`): every replica reads the same record
+        const double* yr = ws + kp.ws_yield;
+        auto YU = [&](int i) { return uniform(yr[i]); };
+        c = YU(YS_C); icm = uniform(1.0 / fmax(c, 1.0));
+        const int fl = (int)YU(YS_FLAGS);
+        akkt_tol = YU(YS_AKKT); dy_norm = YU(YS_DYN); f2_norm = YU(YS_F2N);
+        t_start -= (long long)YU(YS_ELAPSED);
+        alm_iteration = (int)YU(YS_ALMIT); num_outer = (int)YU(YS_NOUTER); inner_total = (int)YU(YS_INNERTOT);
+        n_eval = (int)YU(YS_NEVAL); n_eval_grad = (int)YU(YS_NEVALG);
+        lb.head = (int)YU(YS_LBHEAD);   // the ring keeps its position across a flush, and the Gram form sums the rows in slot order
+#ifdef MPC_TRACE
+        tr_n = (int)YU(YS_TRN);
+#endif
+        if (fl & 16) {
+            // left at the start of an inner problem: point and multipliers; the PANOC cache and the L-BFGS buffer start empty
+            if (vl) {
+                const double2* v = reinterpret_cast<const double2*>(yr + YS_SCALARS + lane * YS_VECW);
+                const double2 a = v[0], y = v[3];
+                uv = a.x; uw = a.y; ya = y.x; yb = y.y;
+            }
+        }
+#if MPC_YIELD_STEP
+        else {
+        gamma = YU(YS_GAMMA); ig = YU(YS_IG); Lip = YU(YS_LIP); cost = YU(YS_COST); gg = YU(YS_GG); d2h = YU(YS_D2H);
+        nfpr = YU(YS_NFPR); lb.hgamma = YU(YS_HGAMMA);
+        iter = (int)YU(YS_ITER); num_iter = (int)YU(YS_NUMITER);
+        cont_iters = (fl & 1) != 0; cont_time = (fl & 2) != 0; lb.first = (fl & 8) != 0;
+        state = (fl & 4) ? TS_BATCH : TS_INIT1;   // TS_INIT1 = no step has completed yet in this inner problem (the bookkeeping is skipped)
+        lb.active = (int)YU(YS_LBACTIVE);
+#ifdef MPC_TRACE
+        tr_psi_u = YU(YS_TRPSI);
+#endif
+        if (vl) {
+            const double2* v = reinterpret_cast<const double2*>(yr + YS_SCALARS + lane * YS_VECW);
+            const double2 a = v[0], g = v[1], hh = v[2], y = v[3];
+            uv = a.x; uw = a.y; gv = g.x; gw = g.y; hv = hh.x; hw = hh.y; ya = y.x; yb = y.y;
+        }
+        // the L-BFGS memory of this replica: ring + zero row, previous (u, gamma fpr), rho, Gram matrices
+        for (int i = lane; i < (2 * mem + 1) * N; i += WAVE)
+            reinterpret_cast<double2*>(lm.LM)[i] = reinterpret_cast<const double2*>(ws + kp.ws_lbs)[i];
+        for (int i = lane; i < N * 4; i += WAVE) lm.LOLD[i] = ws[kp.ws_lold + i];
+        const double* yl = yr + YS_SCALARS + N * YS_VECW;
+        const int nrho = yield_even_c(mem), ngg = gg_doubles_c(N, mem, gram_shape(N, mem));
+        for (int i = lane; i < nrho; i += WAVE) lm.LRHO[i] = yl[i];
+        for (int i = lane; i < ngg; i += WAVE) lm.GG[i] = yl[nrho + i];
+        resume_pending = true;
+        }
+#endif
+        wave_sync();
+    }
     double ev = uv, ew = uw;
     bool want_grad = true;
     EvalOut o;
@@ -194,8 +267,12 @@ __global__ __launch_bounds__(WAVE * TW) void solve_kernel_team(KParams kp, Batch
     auto trial_point = [&](double t) { ev = panoc_trial(uv, rv_, dv, t); ew = panoc_trial(uw, rw_, dw, t); };
 
     for (;;) {
-        eval_point<NT, SC, P>(kp, cx, ev, ew, c, icm, ya, yb, want_grad, state == TS_OUTER, o PROF_PASS);
         bool step_begin = false;
+        if (MPC_YIELD_STEP && resume_pending) {
+            resume_pending = false;
+            step_begin = true;
+        } else {
+        eval_point<NT, SC, P>(kp, cx, ev, ew, c, icm, ya, yb, want_grad, state == TS_OUTER, o PROF_PASS);
 
         if (state == TS_INIT0) {
             ++n_eval; ++n_eval_grad;
@@ -239,7 +316,7 @@ __global__ __launch_bounds__(WAVE * TW) void solve_kernel_team(KParams kp, Batch
                 lb.template direction<P, NT, MEMT, true>(cx, kp, vl, lane, rv_, rw_, lm, lb_pr, dv, dw);
                 rhs = panoc_fbe_rhs(cost, gamma, ig, gg, d2h, sigma, nfpr);
                 t0 = 0;
-                trial_point(exp2(-(double)(t0 + wid)));
+                trial_point(pow2_neg(t0 + wid));
                 want_grad = true; state = TS_BATCH;
                 continue;
             }
@@ -273,14 +350,14 @@ __global__ __launch_bounds__(WAVE * TW) void solve_kernel_team(KParams kp, Batch
                 n_eval += nls + 1; n_eval_grad += nls + 1;
                 TEAM_TRACE_PSI();
                 adopt(winner, uniform(o.psi), tgg, td2h, thv, thw);
-                TEAM_TRACE(nls, exp2(-(double)nls));
+                TEAM_TRACE(nls, pow2_neg(nls));
                 ++iter;
                 step_begin = true;
             } else {
                 n_eval += TW - 1; n_eval_grad += TW - 1;
                 TEAM_TRACE_PSI();
                 t0 = TW - 1;
-                trial_point(exp2(-(double)(t0 + wid)));
+                trial_point(pow2_neg(t0 + wid));
                 want_grad = true; state = TS_BATCH;
                 continue;
             }
@@ -307,13 +384,13 @@ __global__ __launch_bounds__(WAVE * TW) void solve_kernel_team(KParams kp, Batch
                 }
                 TEAM_TRACE_PSI();
                 adopt(winner, uniform(o.psi), tgg, td2h, thv, thw);
-                TEAM_TRACE(nls, exp2(-(double)nls));
+                TEAM_TRACE(nls, pow2_neg(nls));
                 ++iter;
                 step_begin = true;
             } else {
                 n_eval += TW; n_eval_grad += TW;
                 t0 += TW;
-                trial_point(exp2(-(double)(t0 + wid)));
+                trial_point(pow2_neg(t0 + wid));
                 continue;
             }
         } else if (state == TS_FALLBACK) {
@@ -359,6 +436,7 @@ __global__ __launch_bounds__(WAVE * TW) void solve_kernel_team(KParams kp, Batch
             ev = uv; ew = uw; want_grad = true; state = TS_INIT0;
             continue;
         }
+        }   // (evaluation + its state; skipped once when the kernel resumes at a step boundary)
 
         if (step_begin) {
             bool inner_done = false;
@@ -388,7 +466,7 @@ __global__ __launch_bounds__(WAVE * TW) void solve_kernel_team(KParams kp, Batch
                         lb.template direction<P, NT, MEMT, true>(cx, kp, vl, lane, rv_, rw_, lm, lb_pr, dv, dw);
                         rhs = panoc_fbe_rhs(cost, gamma, ig, gg, d2h, sigma, nfpr);
                         if (wid == 0) { ev = hv; ew = hw; want_grad = false; }
-                        else { trial_point(exp2(-(double)(wid - 1))); want_grad = true; }
+                        else { trial_point(pow2_neg(wid - 1)); want_grad = true; }
                         state = TS_SPEC;
                     }
                     continue;

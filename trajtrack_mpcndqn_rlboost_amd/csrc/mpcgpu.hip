@@ -37,7 +37,7 @@ struct Handle {
     bool timing_valid = false;
     std::string err;
     // grow-only device buffers
-    DevBuf ws, counts, evals, perm, bins, nlist, trace, p, u0, y0, c0, u, cost, status, inner, outer, fpr, f2, y, ms, xi, psi, f, grad, F1, F2;
+    DevBuf ws, counts, evals, perm, bins, nlist, ylist, trace, p, u0, y0, c0, u, cost, status, inner, outer, fpr, f2, y, ms, xi, psi, f, grad, F1, F2;
     int order = 1;      // MPCGPU_OPT_ORDER: 0 problems are dispatched as given, 1 longest first by the previous call's evaluation counts
     int evals_B = 0;    // batch size of the call whose evaluation counts `evals` holds (0: none)
     int last_ordered = 0;  // the last throughput launch used a permutation
@@ -55,6 +55,10 @@ struct Handle {
     int last_team = 0;        // wavefronts per problem of the latency kernel the last solve ran (4 or 2); 0: throughput kernel
     int pairing = -1;   // MPCGPU_OPT_PAIRING: -1 automatic, 0 one problem per wavefront, 1 two per wavefront (N_hor = 20)
     int last_pairing = 0;  // layout of the last solve / cost_grad launch
+    int yield_opt = -1;  // MPCGPU_OPT_TAIL_PROMOTION: -1 automatic (the last 2 x #CUs problems of a throughput launch), 0 off, > 0 that many
+    int yield_poll = 16; // ... the finished-counter is polled every this many PANOC steps (power of two)
+    int yield_waves = 0; // MPCGPU_OPT_TAIL_WAVES: wavefronts per promoted problem (0: four up to 2 problems per compute unit, else two)
+    int last_yield_cap = 0;  // capacity of the continuation launch of the last solve (0: none was enqueued)
     int trace_cap = 0;  // -DMPC_TRACE builds: PANOC steps recorded per problem (0 = tracing off)
     // mpcgpu_reserve_shape: upper bounds of active rows promised by the caller -> no count read-back before the launch
     bool capturing = false;  // the launch stream of the current call is being captured into a hipGraph: no event records
@@ -184,7 +188,10 @@ void fill_static_params(Handle* h) {
     k.ws_lby = o; o += c.lbfgs_mem * N * 2;
     o += N * 2;                               // one row of zeros behind [S; Y] (Gram form: padded row of pass 2)
     k.ws_lold = o; o += N * 4;
+    // tail promotion (mpc_kernels.hpp YIELD): the iteration state a problem leaves behind when it moves to the latency kernel
+    k.ws_yield = o; o += YS_SCALARS + N * YS_VECW + even(c.lbfgs_mem) + gg_doubles_c(N, c.lbfgs_mem, gram_shape(N, c.lbfgs_mem));
     k.ws_stride = (o + 15) & ~15;
+    k.yield_from = 0; k.yield_cap = 0; k.yield_mask = 15;
 }
 
 // sizes of the fixed regions: mpc_kernels.hpp (part_doubles_c, stash_doubles_c, fixed_lds) -- shared with the kernels
@@ -376,7 +383,7 @@ void mpcgpu_destroy(void* handle) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    DevBuf* bufs[] = {&h->ws, &h->counts, &h->evals, &h->perm, &h->bins, &h->nlist, &h->trace, &h->p, &h->u0, &h->y0, &h->c0, &h->u, &h->cost, &h->status, &h->inner,
+    DevBuf* bufs[] = {&h->ws, &h->counts, &h->evals, &h->perm, &h->bins, &h->nlist, &h->ylist, &h->trace, &h->p, &h->u0, &h->y0, &h->c0, &h->u, &h->cost, &h->status, &h->inner,
                       &h->outer, &h->fpr, &h->f2, &h->y, &h->ms, &h->xi, &h->psi, &h->f, &h->grad, &h->F1, &h->F2};
     for (DevBuf* b : bufs)
         if (b->ptr) (void)hipFree(b->ptr);
@@ -416,6 +423,8 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
     // configured maxima -- one launch, nothing read back.  Results are bitwise those of the throughput kernel.
     const int team_cap = h->team_max_batch >= 0 ? h->team_max_batch : 4 * h->num_cus;  // measured break-even: 1000-1500 problems (tools/team_sweep.py)
     h->last_team = 0;
+    h->last_yield_cap = 0;
+    h->kp.yield_from = 0;
     bool prepared = false;
 #ifdef MPC_TRACE
     if (h->trace_cap > 0) {     // trace builds (tests): one record per PANOC step, from whichever kernel runs
@@ -482,7 +491,7 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
         io.u0 = u0; io.y0 = y0; io.c0 = c0; io.u = u; io.cost = cost; io.status = status; io.inner_it = inner_it;
         io.outer_it = outer_it; io.fpr = fpr; io.f2norm = f2norm; io.y_out = y_out; io.ms = ms;
         io.evals = (int32_t*)h->evals.ptr;
-        const int tw = B <= 2 * h->num_cus ? TEAM_WAVES : 2;
+        const int tw = h->yield_waves ? h->yield_waves : (B <= 2 * h->num_cus ? TEAM_WAVES : 2);   // (MPCGPU_OPT_TAIL_WAVES: a test knob here)
         KParams kt = h->kp;
         fill_team_layout(kt, tw, h->kp.mKs, h->kp.mKf, h->kp.mKd);
         kt.reserved = 1;                       // every problem is checked against the tables' size on the device
@@ -573,6 +582,39 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
         h->last_ordered = 1;
     }
     h->evals_B = B;
+    // Tail promotion (mpc_kernels.hpp YIELD): once all but K problems of this launch have finished, the wavefronts that are still
+    // running leave at their next PANOC step boundary and a continuation launch of the latency kernel (four wavefronts per problem,
+    // K <= 2 per compute unit; two wavefronts up to 4 per compute unit) finishes them -- bitwise the same results.
+    int yield_K = 0, yield_tw = 0;
+    KParams kt_y{};
+    size_t lds_y = 0;
+    if (MPC_STEP_LOOP && h->yield_opt != 0 && !h->last_pairing && !lin40) {
+        // How many problems of the latency kernel a compute unit holds: 8 wavefronts of that kernel by registers, and the LDS carve
+        // (tables for this batch's maxima).  Automatic rule: four wavefronts per problem, K = what is resident at once.
+        auto team_shape = [&](int tw, KParams& kt, size_t& lds_t) -> int {
+            kt = h->kp;
+            fill_team_layout(kt, tw, h->kp.mKs, h->kp.mKf, h->kp.mKd);
+            kt.reserved = 1;
+            lds_t = kt.l_total * sizeof(double);
+            const int by_lds = (int)((160 * 1024) / (lds_t + PREP_STATIC_LDS)), by_regs = 8 / tw;
+            return by_lds < by_regs ? by_lds : by_regs;
+        };
+        int tw = h->yield_waves ? h->yield_waves : TEAM_WAVES;
+        int per_cu = team_shape(tw, kt_y, lds_y);
+        int K = h->yield_opt > 0 ? h->yield_opt : per_cu * h->num_cus;
+        if (!h->yield_waves && h->yield_opt > per_cu * h->num_cus) { tw = 2; per_cu = team_shape(tw, kt_y, lds_y); }   // more than four-wavefront teams hold at once: two each
+        if (K > B) K = B;
+        if (per_cu >= 1 && K > 0) {
+            if (int r = ensure(h, h->ylist, (size_t)K * sizeof(int32_t))) return r;
+            yield_K = K; yield_tw = tw;
+            h->kp.yield_from = B - K > 0 ? B - K : 1;
+            h->kp.yield_cap = K;
+            h->kp.yield_mask = h->yield_poll - 1;
+            io.ylist = (int32_t*)h->ylist.ptr;
+            kt_y.yield_cap = K;
+            kt_y.yield_mask = h->yield_poll - 1;
+        }
+    }
 #define LAUNCH_DUO(NT, SC)                                                                                          \
     do {                                                                                                             \
         auto kern = solve_kernel_duo<NT, SC, LBFGS_IN_WORKSPACE>;                                                    \
@@ -619,6 +661,24 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
 #undef LAUNCH_PAIR_WA
 #undef LAUNCH_PAIR_W
     HIP_OK(h, hipGetLastError());
+    if (yield_K > 0) {
+        // the continuation: grid = capacity of the list, workgroups beyond its device-side length leave at once
+#define LAUNCH_RESUME(NT, TW)                                                                                        \
+    do {                                                                                                             \
+        auto kern = solve_kernel_team<NT, TW>;                                                                       \
+        if (int r_ = opt_in_lds(h, (const void*)kern, lds_y)) return r_;                                             \
+        hipLaunchKernelGGL(kern, dim3(yield_K), dim3(WAVE * TW), lds_y, s, kt_y, io, B);                             \
+    } while (0)
+        io.p = nullptr; io.perm = nullptr;
+        switch (compiled_horizon(h)) {
+            case 20: if (yield_tw == 2) LAUNCH_RESUME(20, 2); else LAUNCH_RESUME(20, TEAM_WAVES); break;
+            case 40: if (yield_tw == 2) LAUNCH_RESUME(40, 2); else LAUNCH_RESUME(40, TEAM_WAVES); break;
+            default: if (yield_tw == 2) LAUNCH_RESUME(0, 2); else LAUNCH_RESUME(0, TEAM_WAVES); break;
+        }
+#undef LAUNCH_RESUME
+        HIP_OK(h, hipGetLastError());
+        h->last_yield_cap = yield_K;
+    }
     if (!h->capturing) HIP_OK(h, hipEventRecord(h->ev[3], s));
     h->timing_valid = !h->capturing;
     return 0;
@@ -1028,6 +1088,20 @@ int32_t mpcgpu_set_option(void* handle, int32_t option, double value) {
             if (value != 0.0 && value != 1.0) return fail(h, -1, "order must be 0 (as given) or 1 (longest first by the previous call), got %g", value);
             h->order = (int)value;
             return 0;
+        case MPCGPU_OPT_TAIL_PROMOTION:
+            if (value < -1.0 || value != (double)(int)value) return fail(h, -1, "tail promotion must be -1 (automatic), 0 (off) or a number of problems, got %g", value);
+            h->yield_opt = (int)value;
+            return 0;
+        case MPCGPU_OPT_TAIL_WAVES:
+            if (value != 0.0 && value != 2.0 && value != 4.0) return fail(h, -1, "tail waves must be 0 (automatic), 2 or 4, got %g", value);
+            h->yield_waves = (int)value;
+            return 0;
+        case MPCGPU_OPT_TAIL_POLL: {
+            const int v = (int)value;
+            if (value != (double)v || v < 1 || v > 4096 || (v & (v - 1)) != 0) return fail(h, -1, "tail poll interval must be a power of two in 1..4096, got %g", value);
+            h->yield_poll = v;
+            return 0;
+        }
         default:
             return fail(h, -1, "unknown option %d", option);
     }
@@ -1076,6 +1150,23 @@ int32_t mpcgpu_last_problems_per_wavefront(void* handle) {
     return h ? 1 + h->last_pairing : -1;
 }
 int32_t mpcgpu_last_ordered(void* handle) { Handle* h = (Handle*)handle; return h ? h->last_ordered : -1; }
+
+int32_t mpcgpu_last_tail_promotion(void* handle, int32_t* promoted, void* stream) {
+    Handle* h = (Handle*)handle;
+    if (!h) return -1;
+    if (promoted) {
+        *promoted = 0;
+        if (h->last_yield_cap > 0 && h->counts.ptr) {
+            HIP_OK(h, hipSetDevice(h->device));
+            hipStream_t s = pick_stream(h, stream);
+            HIP_OK(h, hipStreamSynchronize(s));
+            int n = 0;
+            HIP_OK(h, hipMemcpy(&n, (const int*)h->counts.ptr + CNT_YIELDED, sizeof(int), hipMemcpyDeviceToHost));
+            *promoted = n < h->last_yield_cap ? n : h->last_yield_cap;
+        }
+    }
+    return h->last_yield_cap;
+}
 
 #ifdef MPC_PROFILE
 // profiling builds only: read and clear the phase-cycle table (24 counters)

@@ -22,13 +22,16 @@ _LIB = os.environ.get("MPCGPU_LIB", os.path.join(_PKG, "libmpcgpu.so"))  # overr
 
 STATUS_NAMES = ("Converged", "NotConvergedIterations", "NotConvergedOutOfTime", "NotFiniteComputation",
                 "ShapeExceeded")
-ABI_VERSION = 6
+ABI_VERSION = 7
 _STREAM_OWN = C.c_void_p(-1)      # MPCGPU_STREAM_OWN: the handle's own non-blocking stream
 OPT_LINESEARCH_FALLBACK = 1       # MPCGPU_OPT_LINESEARCH_FALLBACK
 OPT_PAIRING = 2                   # MPCGPU_OPT_PAIRING
 OPT_TEAM_BATCH = 3                # MPCGPU_OPT_TEAM_BATCH
 OPT_ORDER = 4                     # MPCGPU_OPT_ORDER
 OPT_LINEAR_TABLES = 5             # MPCGPU_OPT_LINEAR_TABLES
+OPT_TAIL_PROMOTION = 6            # MPCGPU_OPT_TAIL_PROMOTION
+OPT_TAIL_POLL = 7                 # MPCGPU_OPT_TAIL_POLL
+OPT_TAIL_WAVES = 8                # MPCGPU_OPT_TAIL_WAVES
 
 
 def _stream_arg(stream):
@@ -59,7 +62,7 @@ class _CConfig(C.Structure):
 EXPORTS = ("mpcgpu_abi_version", "mpcgpu_create", "mpcgpu_destroy", "mpcgpu_last_error", "mpcgpu_num_params",
            "mpcgpu_solve_batch", "mpcgpu_solve_batch_dev", "mpcgpu_cost_grad_batch", "mpcgpu_last_timing",
            "mpcgpu_last_eval_counts", "mpcgpu_last_shape", "mpcgpu_last_waves_per_simd", "mpcgpu_reserve_shape",
-           "mpcgpu_set_option", "mpcgpu_last_problems_per_wavefront", "mpcgpu_last_ordered", "mpcgpu_last_latency_kernel", "mpcgpu_reserve_batch", "mpcgpu_last_table_kind", "mpcgpu_tracker_window_dev",
+           "mpcgpu_set_option", "mpcgpu_last_problems_per_wavefront", "mpcgpu_last_ordered", "mpcgpu_last_tail_promotion", "mpcgpu_last_latency_kernel", "mpcgpu_reserve_batch", "mpcgpu_last_table_kind", "mpcgpu_tracker_window_dev",
            "mpcgpu_tracker_step_dev", "mpcgpu_rl_reference_dev", "mpcgpu_hint_switch_dev", "mpcgpu_debug_read_workspace",
            "mpcgpu_workspace_stride", "mpcgpu_workspace_record", "mpcgpu_debug_prep", "mpcgpu_debug_tracker_assemble",
            "mpcgpu_debug_lbfgs_direction")
@@ -144,6 +147,9 @@ def load_library(path: Optional[str] = None):
     L.mpcgpu_last_problems_per_wavefront.restype = C.c_int32
     L.mpcgpu_last_ordered.argtypes = [vp]
     L.mpcgpu_last_ordered.restype = C.c_int32
+    if hasattr(L, "mpcgpu_last_tail_promotion"):   # (absent only in an old build loaded for an A/B run, see MPCGPU_ALLOW_ABI)
+        L.mpcgpu_last_tail_promotion.argtypes = [vp, ip, vp]
+        L.mpcgpu_last_tail_promotion.restype = C.c_int32
     L.mpcgpu_reserve_shape.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.mpcgpu_reserve_shape.restype = C.c_int32
     tp = C.POINTER(CTracker)
@@ -174,7 +180,7 @@ def load_library(path: Optional[str] = None):
     L.mpcgpu_reserve_batch.restype = C.c_int32
     L.mpcgpu_set_option.argtypes = [vp, C.c_int32, C.c_double]
     L.mpcgpu_set_option.restype = C.c_int32
-    if L.mpcgpu_abi_version() != ABI_VERSION:
+    if L.mpcgpu_abi_version() != ABI_VERSION and not os.environ.get("MPCGPU_ALLOW_ABI"):   # (A/B runs against an older build)
         raise MpcGpuError(f"{_LIB} has ABI version {L.mpcgpu_abi_version()}, this binding needs {ABI_VERSION}: rebuild it")
     if hasattr(L, "mpcgpu_debug_set_trace"):     # -DMPC_TRACE builds (tests)
         L.mpcgpu_debug_set_trace.argtypes = [vp, C.c_int32]
@@ -217,7 +223,7 @@ class BatchSolver:
 
     def __init__(self, config: Optional[MpcConfig] = None, device: int = 0, library: Optional[str] = None,
                  pairing: Optional[int] = None, latency_batch: Optional[int] = None, order: Optional[str] = None,
-                 linear_tables: Optional[bool] = None):
+                 linear_tables: Optional[bool] = None, tail_promotion: Optional[int] = None):
         """``pairing``: problems per wavefront of the solve kernel -- None = the library's rule (the faster layout: one),
         1 or 2 to force a layout (MPCGPU_OPT_PAIRING; 2 exists for N_hor = 20; env MPCGPU_PAIRING overrides None).
         ``latency_batch``: largest batch solved by the latency kernel (MPCGPU_OPT_TEAM_BATCH; None = the library's rule,
@@ -227,7 +233,10 @@ class BatchSolver:
         default: robot i of this tick is robot i of the last one), "as_given" = workgroup g solves problem g (env MPCGPU_ORDER
         overrides None).  Results do not depend on it (bitwise).
         ``linear_tables``: False = never use the linear centre tables (MPCGPU_OPT_LINEAR_TABLES = 0; env MPCGPU_LINEAR_TABLES=0
-        overrides None; an experiment that only the variant build libmpcgpu_linear40.so carries).  Results do not depend on it."""
+        overrides None; an experiment that only the variant build libmpcgpu_linear40.so carries).  Results do not depend on it.
+        ``tail_promotion``: how many problems at the end of a throughput launch move to the latency kernel at the start of their
+        next inner problem (MPCGPU_OPT_TAIL_PROMOTION): None / -1 = the library's rule (2 per compute unit), 0 = off (env
+        MPCGPU_TAIL_PROMOTION overrides None).  Results do not depend on it (bitwise)."""
         self.config = config if config is not None else MpcConfig()
         self._L = load_library(library)
         self._h = C.c_void_p()
@@ -266,6 +275,26 @@ class BatchSolver:
             linear_tables = os.environ["MPCGPU_LINEAR_TABLES"] != "0"
         if linear_tables is not None:
             self._check(self._L.mpcgpu_set_option(self._h, OPT_LINEAR_TABLES, 1.0 if linear_tables else 0.0), "mpcgpu_set_option")
+
+        if tail_promotion is None and os.environ.get("MPCGPU_TAIL_PROMOTION"):
+            tail_promotion = int(os.environ["MPCGPU_TAIL_PROMOTION"])
+        if tail_promotion is not None:
+            self.set_tail_promotion(tail_promotion)
+
+    def set_tail_promotion(self, problems: int, poll_steps: Optional[int] = None, waves: Optional[int] = None):
+        """MPCGPU_OPT_TAIL_PROMOTION (-1 automatic, 0 off, K problems) and, for the A/B build that can leave inside an inner
+        problem, MPCGPU_OPT_TAIL_POLL."""
+        self._check(self._L.mpcgpu_set_option(self._h, OPT_TAIL_PROMOTION, float(problems)), "mpcgpu_set_option")
+        if poll_steps is not None:
+            self._check(self._L.mpcgpu_set_option(self._h, OPT_TAIL_POLL, float(poll_steps)), "mpcgpu_set_option")
+        if waves is not None:
+            self._check(self._L.mpcgpu_set_option(self._h, OPT_TAIL_WAVES, float(waves)), "mpcgpu_set_option")
+
+    def last_tail_promotion(self, stream: Optional[int] = None):
+        """(capacity of the continuation launch of the last solve call, problems that actually moved to the latency kernel)."""
+        n = C.c_int32()
+        cap = int(self._L.mpcgpu_last_tail_promotion(self._h, C.byref(n), _stream_arg(stream)))
+        return cap, int(n.value)
 
     def set_order(self, order: str):
         if order not in ("as_given", "longest_first"):
