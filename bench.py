@@ -46,8 +46,13 @@ Rank 0 prints ONE JSON line (contract in the task description) with extra object
                    first by the evaluation counts of the previous call).  A bench step repeats the SAME batch, which makes those
                    hints perfect: an UPPER BOUND for a receding-horizon loop (config.closed_loop shows what real hints give).
                    The headline `value` itself starts the problems as given.
-  The side legs (convergent, avoidance, batch_sweep, closed_loop, counter passes, cpu_baseline) run on one rank only unless
-  --full is given: an N-rank run is bounded by the headline leg (plus the ordered leg), not by 8 x every side leg.
+  config.closed_loop.realtime_robots_per_gpu -- the largest fleet (multiple of 512 robots) whose WORST tick of that run stays within
+                   the sampling time ts = 0.2 s of the yaml, cold and warm start (`realtime`: the sizes tried, the per-tick times).
+  config.metric_batch -- the 8192-robot batch SURVEY.md 8(d) words the metric at, plain launches as given (copied from batch_sweep).
+  psi_evals_per_s -- psi evaluations per second of the headline leg: the workload-independent rate (families with other iteration
+                   counts compare on it).
+  The side legs (convergent, avoidance, ordered, batch_sweep, closed_loop, counter passes, cpu_baseline) run with ONE rank only
+  (world == 1) unless --full is given: an N-rank run is the headline leg and nothing else.
   cpu_baseline  -- the oracle (plain-C restatement, "port") on the host cores this process may use, on a bounded
                    sample.
 """
@@ -93,6 +98,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-sweep", action="store_true", help="skip the reference-batch legs (profiling runs)")
     ap.add_argument("--no-pmc", action="store_true", help="do not re-measure the counter-based roofline fields in this run")
     ap.add_argument("--no-closed-loop", action="store_true", help="skip the closed-loop leg")
+    ap.add_argument("--no-capacity", action="store_true", help="skip the real-time capacity search of the closed-loop leg")
     ap.add_argument("--side-batch", type=int, default=32768, help="problems per GPU of the convergent / avoidance legs")
     ap.add_argument("--full", action="store_true", help="run the side legs on every rank of a multi-GPU run as well")
     ap.add_argument("--p-file", default=None, help=argparse.SUPPRESS)   # counter passes: the parent's parameter vectors (.npy)
@@ -300,7 +306,8 @@ def main():
         barrier()
         mine = time.perf_counter() - t0
         n_psi, n_grad = sv.last_eval_counts(b, stream)
-        return dict(elapsed=mine, kernel_ms=float(np.mean(k_ms)), prep_ms=float(np.mean(p_ms)),
+        promo = sv.last_tail_promotion(stream) if hasattr(sv, "last_tail_promotion") else (0, 0)
+        return dict(elapsed=mine, kernel_ms=float(np.mean(k_ms)), prep_ms=float(np.mean(p_ms)), tail_promotion=promo,
                     status=o["status"].cpu().numpy().copy(), inner=o["inner_it"].cpu().numpy().copy(),
                     n_psi=n_psi, n_grad=n_grad)
 
@@ -426,7 +433,9 @@ def main():
             s_el, _ = over_ranks(sl["elapsed"])
             item = {"batch_per_gpu": b, "steps": side_steps,
                     "plain": {"value": world * b * side_steps / s_el, "unit": "solves/s", "ms_per_step": 1e3 * s_el / side_steps,
-                              "kernel_ms": sl["kernel_ms"], "status_histogram": np.bincount(sl["status"], minlength=3).tolist()}}
+                              "kernel_ms": sl["kernel_ms"], "status_histogram": np.bincount(sl["status"], minlength=3).tolist(),
+                              "psi_evals_per_s": world * float(sl["n_psi"].sum()) * side_steps / s_el,
+                              "tail_promotion": {"capacity": sl["tail_promotion"][0], "promoted_last_step": sl["tail_promotion"][1]}}}
             if hasattr(sv, "close"):
                 sv.close()
             item["ordered_perfect_hints"] = ordered_leg(pb, side_steps)
@@ -455,6 +464,13 @@ def main():
                 per_tick = r.pop("status_histogram_per_tick")
                 r["status_histogram_first_tick"], r["status_histogram_last_tick"] = per_tick[0], per_tick[-1]
                 closed["runs"].append(r)
+        if not args.no_capacity:
+            # the reference prints its solve time per control step (src/main.py:230-238); for a fleet the question is how many robots
+            # ONE GPU serves with every tick inside the sampling time ts of the yaml (0.2 s)
+            from tools.closed_loop import realtime_capacity
+            cap = {("warm" if warm else "cold"): realtime_capacity(cfg, warm=warm, device=dev_index) for warm in (False, True)}
+            closed["realtime_robots_per_gpu"] = {k: v["robots"] for k, v in cap.items()}
+            closed["realtime"] = cap
         barrier()
 
     if rank == 0:
@@ -480,6 +496,9 @@ def main():
             "rccl_ranks": dist.get_world_size() if world > 1 else 1,
             "backend": backend if world > 1 else None,
             "per_rank_solves_per_s": [B * args.steps / t for t in per_rank_s],
+            # workload-independent rate: psi (+ grad psi) evaluations per second of this rank's shard x ranks (families with other
+            # iteration counts compare on this, not on solves/s)
+            "psi_evals_per_s": world * float(n_psi.sum()) * args.steps / elapsed,
             "config": {"workload": f"mpc_default.yaml N_hor={N}, {args.n_dyn} dynamic obstacles (r=1.6 m discs crossing "
                                    "the path, SURVEY.md 8(d)), 5 static boxes, cold start u0=0, "
                                    f"batch={B} robots per GPU; K plain launches on one stream, problems started in the order given "
@@ -492,7 +511,10 @@ def main():
                        "converged_fraction": n_conv / B,
                        "converged_solves_per_s": world * n_conv * args.steps / elapsed,
                        "lds_bytes_per_wavefront": solver.last_shape()["lds_bytes"],
-                       "wavefronts_per_simd": solver.last_shape()["waves_per_simd"]},
+                       "wavefronts_per_simd": solver.last_shape()["waves_per_simd"],
+                       "tail_promotion": {"what": "MPCGPU_OPT_TAIL_PROMOTION (library default): the last problems of a plain launch "
+                                                  "move to the latency kernel at the start of their next inner problem; bitwise the same results",
+                                          "capacity": leg["tail_promotion"][0], "promoted_last_step": leg["tail_promotion"][1]}},
         }
         if conv is not None:
             cl = conv["leg"]
@@ -526,6 +548,10 @@ def main():
             line["config"]["closed_loop"] = closed
         if sweep:
             line["config"]["batch_sweep"] = sweep
+            mb = [it for it in sweep if it["batch_per_gpu"] == 8192]
+            if mb:      # SURVEY.md 8(d) words the metric at 8192 robots per GPU: that figure, plain launches as given, at the top level of config
+                line["config"]["metric_batch"] = {"batch_per_gpu": 8192, "what": "plain launches, problems started as given (batch_sweep has the other forms)",
+                                                  **mb[0]["plain"]}
         if ordered_head is not None:
             line["config"]["ordered_perfect_hints"] = ordered_head
         line["config"]["scene_generation_s"] = gen_s

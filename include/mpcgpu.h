@@ -128,8 +128,9 @@ int32_t mpcgpu_last_timing(void* handle, double* prep_ms, double* solve_ms);
 /* Work counters of the last solve call, per problem: psi evaluations executed and how many of them also produced
  * grad psi (the counts OpEn's generated `cost` / `grad_cost` functions would see, minus the redundant re-evaluation of
  * psi(u) in the Lipschitz update; the latency kernel reports the counts of the SEQUENTIAL algorithm, not its speculative
- * evaluations).  Synchronises the stream the last solve was enqueued on (and `stream`, if it is another one).  HOST output
- * pointers. */
+ * evaluations).  Waits for the last solve (the event recorded behind it; and for `stream`, if it is another one).  When the last
+ * solve was CAPTURED into a hipGraph there is no such event: pass the stream the graph is launched on -- that stream, and no
+ * other, is synchronised (never the whole device); calling this inside a capture fails with -6.  HOST output pointers. */
 int32_t mpcgpu_last_eval_counts(void* handle, int32_t B, int32_t* n_psi, int32_t* n_grad, void* stream);
 
 /* Batch-wide maxima of active entries seen by the last solve / cost_grad call: static obstacles, fleet

@@ -65,3 +65,32 @@ def test_bench_exits_non_zero_when_fewer_devices_than_gpus():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(have + 2), "--batch", "8"],
                        env=_env(), capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "GPU(s) visible" in r.stderr
+
+
+def test_the_drivers_eight_rank_launch_is_rehearsed_with_stubbed_ranks():
+    """The driver's command for the scaling run, word for word (`python -m torch.distributed.run --nnodes=1 --nproc-per-node 8
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 --steps K --warmup W`), with the solver stubbed and gloo in place of
+    RCCL: exit code 0, ONE JSON line, eight per-rank rates, no rank left behind in destroy_process_group, inside a minute."""
+    import socket
+    import time
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1",
+                        "--batch", "64"],
+                       env=_env(MPCGPU_BENCH_BACKEND="gloo", MPCGPU_BENCH_STUB="1", OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=280)
+    wall = time.time() - t0
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["rccl_ranks"] == 8 and len(line["per_rank_solves_per_s"]) == 8
+    assert line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak" and line["higher_is_better"] is True
+    assert abs(line["value"] - 8 * 64 * 3 / (line["ms_per_step"] * 3e-3)) < 1e-6 * line["value"]
+    assert line["config"]["parallelism"] == "shard8" and line["psi_evals_per_s"] > 0
+    for k in ("convergent", "avoidance", "batch_sweep", "closed_loop", "ordered_perfect_hints", "metric_batch"):
+        assert k not in line["config"], k             # an N-rank run is the headline leg and nothing else
+    assert "roofline" not in line and "cpu_baseline" not in line
+    assert wall < 120, wall

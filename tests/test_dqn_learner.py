@@ -331,3 +331,53 @@ def test_resumed_run_equals_the_uninterrupted_run_on_the_hip_environment(tmp_pat
         for k in ("exp_avg", "exp_avg_sq", "step"):
             assert torch.equal(torch.as_tensor(sa[i][k]).cpu(), torch.as_tensor(sc[i][k]).cpu()), (i, k)
         assert float(torch.as_tensor(sc[i]["step"])) > 0
+
+
+def test_graph_bound_optimizer_state_is_validated_before_anything_is_copied():
+    """DqnTrainer.load_optimizer_state on the graph path (the captured update is bound to the optimiser's state TENSORS): a
+    checkpoint whose hyper-parameters, parameter count or moment shapes differ from what the graph holds must raise BEFORE the
+    live state is touched; a fitting one lands in place.  (CPU: the graph itself is a marker here, the in-place path is host code.)"""
+    import copy
+
+    def batch(seed, n=32):
+        g = torch.Generator().manual_seed(seed)
+        return dict(obs=torch.rand(n, 46, generator=g) * 2 - 1, actions=torch.randint(0, 9, (n,), generator=g), rewards=torch.randn(n, generator=g),
+                    next_obs=torch.rand(n, 46, generator=g) * 2 - 1, dones=(torch.rand(n, generator=g) < 0.1).float())
+    torch.manual_seed(0)
+    src = dqn_train.DqnTrainer()
+    for i in range(3):
+        src.update(batch(i))
+    good = copy.deepcopy(src.optimizer.state_dict())
+    torch.manual_seed(1)
+    tr = dqn_train.DqnTrainer()
+    for i in range(2):
+        tr.update(batch(100 + i))
+    tr._graph = object()                           # what enable_graph leaves behind: from now on the state tensors must keep their identity
+    tensors = {id(p): {k: v for k, v in tr.optimizer.state[p].items()} for g in tr.optimizer.param_groups for p in g["params"]}
+    before = {pid: {k: torch.as_tensor(v).clone() for k, v in st.items()} for pid, st in tensors.items()}
+
+    def untouched():
+        return all(torch.equal(torch.as_tensor(tensors[pid][k]), before[pid][k]) for pid in tensors for k in before[pid])
+    for key, value in (("lr", 3e-3), ("betas", (0.8, 0.99)), ("eps", 1e-4), ("weight_decay", 0.01)):
+        bad = copy.deepcopy(good)
+        bad["param_groups"][0][key] = value
+        with pytest.raises(ValueError, match=key):
+            tr.load_optimizer_state(bad)
+        assert untouched(), key
+    bad = copy.deepcopy(good)
+    bad["param_groups"][0]["params"] = bad["param_groups"][0]["params"][:-1]
+    with pytest.raises(ValueError, match="parameters"):
+        tr.load_optimizer_state(bad)
+    assert untouched()
+    bad = copy.deepcopy(good)
+    first = next(iter(bad["state"]))
+    bad["state"][first]["exp_avg"] = bad["state"][first]["exp_avg"][:1]
+    with pytest.raises(ValueError, match="shape"):
+        tr.load_optimizer_state(bad)
+    assert untouched()
+    tr.load_optimizer_state(good)                  # fits: copied IN PLACE (same tensor objects, the source's values)
+    for g_t, g_s in zip(tr.optimizer.param_groups, src.optimizer.param_groups):
+        for p_t, p_s in zip(g_t["params"], g_s["params"]):
+            for k in ("exp_avg", "exp_avg_sq", "step"):
+                assert tr.optimizer.state[p_t][k] is tensors[id(p_t)][k]
+                assert torch.equal(torch.as_tensor(tr.optimizer.state[p_t][k]), torch.as_tensor(src.optimizer.state[p_s][k]))

@@ -8,7 +8,8 @@ stream, the constant-velocity predictions of src/main.py:77-85 formed by torch k
 ticks); bench.py reports it as `config.closed_loop`.  The hints of MPCGPU_OPT_ORDER are REAL here: the evaluation counts of tick
 k order tick k + 1.
 
-usage: closed_loop.py [B] [ticks] [n_dyn] [warm] [host]      ("host": the host-assembly loop of rounds 1-3, BatchedTracker)"""
+usage: closed_loop.py [B] [ticks] [n_dyn] [warm] [host | capacity]   ("host": the host-assembly loop of rounds 1-3, BatchedTracker;
+"capacity": the largest fleet per GPU whose worst tick stays within the sampling time, realtime_capacity)"""
 import os
 import sys
 import time
@@ -46,7 +47,8 @@ def setup(tracker, B, y0, static):
         tracker.update_static_constraints(i, static)
 
 
-def device_closed_loop(cfg, B=8192, ticks=30, warmup_ticks=5, n_dyn=4, warm=False, order="longest_first", device=0, seed=5):
+def device_closed_loop(cfg, B=8192, ticks=30, warmup_ticks=5, n_dyn=4, warm=False, order="longest_first", device=0, seed=5,
+                       tail_promotion=None):
     """Returns a dict: per-tick wall time (HIP events around the whole tick), solves/s, status histogram of every timed tick,
     mean inner iterations, progress and safety figures.  `warm`: previous plan shifted by one step as initial guess
     (the reference passes initial_guess=None, i.e. cold: src/interface_mpc.py:82)."""
@@ -56,7 +58,7 @@ def device_closed_loop(cfg, B=8192, ticks=30, warmup_ticks=5, n_dyn=4, warm=Fals
     from trajtrack_mpcndqn_rlboost_amd.feeders import DYN_OBS_SIZE
     N = int(cfg.N_hor)
     dev = torch.device("cuda", device)
-    solver = BatchSolver(cfg, device=device, order=order)
+    solver = BatchSolver(cfg, device=device, order=order, tail_promotion=tail_promotion)
     dt = DeviceTracker(cfg, B, device=device, solver=solver)
     y0, pos_h, vel_h, static = scene_one(B, n_dyn, seed)
     setup(dt, B, y0, static)
@@ -72,7 +74,7 @@ def device_closed_loop(cfg, B=8192, ticks=30, warmup_ticks=5, n_dyn=4, warm=Fals
         pred[..., 1] = pos[..., None, 1] + delta[..., None, 1] * k
         return pred
     total = warmup_ticks + ticks
-    hist = torch.zeros(total, 4, dtype=torch.int64, device=dev)
+    statuses = torch.zeros(total, B, dtype=torch.int32, device=dev)     # histogram after the loop: torch.bincount reads its bounds back
     inner = torch.zeros(total, dtype=torch.float64, device=dev)
     inside_box = torch.zeros(B, dtype=torch.bool, device=dev)
     hit_disc = torch.zeros(B, dtype=torch.bool, device=dev)
@@ -90,7 +92,7 @@ def device_closed_loop(cfg, B=8192, ticks=30, warmup_ticks=5, n_dyn=4, warm=Fals
                                  var_shape=not sh["shape_const"], axis_aligned=sh["axis_aligned"])
             solver.reserve_batch(B)
         ordered.append(bool(solver.last_shape()["ordered"]))
-        hist[t] = torch.bincount(out["status"].to(torch.int64), minlength=4)[:4]
+        statuses[t].copy_(out["status"])
         inner[t] = out["inner_it"].to(torch.float64).mean()
         if warm:
             u = out["u"].view(B, N, 2)
@@ -103,12 +105,15 @@ def device_closed_loop(cfg, B=8192, ticks=30, warmup_ticks=5, n_dyn=4, warm=Fals
     torch.cuda.synchronize()
     tick_ms = [ev[t].elapsed_time(ev[t + 1]) for t in range(total)]
     timed = tick_ms[warmup_ticks:]
-    hist_h = hist.cpu().numpy()
+    hist_h = np.stack([np.bincount(row, minlength=5)[:5] for row in statuses.cpu().numpy()])   # all five codes (3 not finite, 4 shape exceeded)
+    if hist_h[:, 3:].sum():
+        raise RuntimeError(f"closed loop: {hist_h[:, 3].sum()} non-finite and {hist_h[:, 4].sum()} shape-exceeded solves (reservation of tick 0 broken?)")
     res = {"batch": B, "ticks": ticks, "warmup_ticks": warmup_ticks, "n_dyn": n_dyn, "start": "warm" if warm else "cold",
            "order": order, "ordered_ticks": int(sum(ordered[warmup_ticks:])),
            "ms_per_tick": float(np.mean(timed)), "ms_per_tick_min_max": [float(min(timed)), float(max(timed))],
+           "ms_of_every_tick": [round(float(x), 2) for x in timed],
            "value": B * ticks / (sum(timed) * 1e-3), "unit": "solves/s",
-           "status_histogram_per_tick": hist_h[warmup_ticks:, :3].tolist(),
+           "status_histogram_per_tick": hist_h[warmup_ticks:, :3].tolist(),   # (codes 3 and 4 are zero: checked above)
            "status_histogram_total": hist_h[warmup_ticks:, :3].sum(axis=0).tolist(),
            "converged_fraction": float(hist_h[warmup_ticks:, 0].sum() / (B * ticks)),
            "mean_inner_iterations": float(inner[warmup_ticks:].mean()),
@@ -118,6 +123,39 @@ def device_closed_loop(cfg, B=8192, ticks=30, warmup_ticks=5, n_dyn=4, warm=Fals
     res["_final_states"] = dt.states.cpu().numpy()
     solver.close()
     return res
+
+
+def realtime_capacity(cfg, warm=False, order="longest_first", lo=2048, hi=8192, step=512, ticks=30, warmup_ticks=5, n_dyn=4, device=0,
+                      limit_ms=None):
+    """The largest fleet per GPU (a multiple of `step`) whose WORST control tick of the scene-1 run stays within the sampling
+    time `ts` of the yaml (config/mpc_default.yaml: 0.2 s) -- what the reference prints per step as its solve time
+    (src/main.py:230-238), asked of a fleet.  Bisection over device_closed_loop runs; returns the sizes tried with their worst /
+    mean tick and the per-tick times of the run at the answer."""
+    limit_ms = 1e3 * float(cfg.ts) if limit_ms is None else limit_ms
+    tried = {}
+
+    def worst(B):
+        if B not in tried:
+            r = device_closed_loop(cfg, B, ticks, warmup_ticks, n_dyn, warm, order, device=device)
+            tried[B] = r
+        return tried[B]["ms_per_tick_min_max"][1]
+    a, b = lo // step, hi // step
+    if worst(a * step) > limit_ms:
+        best = 0
+    elif worst(b * step) <= limit_ms:
+        best = b * step
+    else:
+        while b - a > 1:
+            m = (a + b) // 2
+            if worst(m * step) <= limit_ms: a = m
+            else: b = m
+        best = a * step
+    out = {"limit_ms": limit_ms, "start": "warm" if warm else "cold", "order": order, "robots": best, "step": step,
+           "tried": {str(B): {"worst_ms": round(r["ms_per_tick_min_max"][1], 2), "mean_ms": round(r["ms_per_tick"], 2)} for B, r in sorted(tried.items())}}
+    if best:
+        out["ms_of_every_tick"] = tried[best]["ms_of_every_tick"]
+        out["converged_fraction"] = tried[best]["converged_fraction"]
+    return out
 
 
 def host_loop(B, T, K, warm):
@@ -153,7 +191,13 @@ if __name__ == "__main__":
     T = int(sys.argv[2]) if len(sys.argv) > 2 else 80
     K = int(sys.argv[3]) if len(sys.argv) > 3 else 2
     WARM = "warm" in sys.argv[4:]
-    if "host" in sys.argv[4:]:
+    if "capacity" in sys.argv[4:]:
+        import json
+        from trajtrack_mpcndqn_rlboost_amd import MpcConfig
+        for warm in (False, True):
+            r = realtime_capacity(MpcConfig(), warm=warm, n_dyn=K)
+            print(json.dumps(r))
+    elif "host" in sys.argv[4:]:
         host_loop(B, T, K, WARM)
     else:
         from trajtrack_mpcndqn_rlboost_amd import MpcConfig

@@ -588,7 +588,9 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
     int yield_K = 0, yield_tw = 0;
     KParams kt_y{};
     size_t lds_y = 0;
-    if (MPC_STEP_LOOP && h->yield_opt != 0 && !h->last_pairing && !lin40) {
+    // Not with a launch that starts its problems longest first: its tail is short already and the continuation only adds its own
+    // launch and the wait for the inner-problem boundaries (measured: 210 -> 213 ms at B = 8192, profiles/r05_tail_promotion_ab.txt).
+    if (MPC_STEP_LOOP && h->yield_opt != 0 && !h->last_pairing && !lin40 && !(h->last_ordered && h->yield_opt < 0)) {
         // How many problems of the latency kernel a compute unit holds: 8 wavefronts of that kernel by registers, and the LDS carve
         // (tables for this batch's maxima).  Automatic rule: four wavefronts per problem, K = what is resident at once.
         auto team_shape = [&](int tw, KParams& kt, size_t& lds_t) -> int {
@@ -991,11 +993,17 @@ int32_t mpcgpu_last_eval_counts(void* handle, int32_t B, int32_t* n_psi, int32_t
     HIP_OK(h, hipSetDevice(h->device));
     // The counters are written by the solve kernel: wait for the EVENT recorded behind it (the launch stream is the caller's and may
     // have been destroyed since; a stream handle is never touched here unless the caller passes it now).  A solve that was captured
-    // into a hipGraph has no such event: its replays are ordered by the stream the caller names, plus a device-wide wait.
-    if (!h->last_captured && h->timing_valid) HIP_OK(h, hipEventSynchronize(h->ev[3]));
-    else HIP_OK(h, hipDeviceSynchronize());
+    // into a hipGraph has no such event: its replays are ordered by the stream the caller NAMES (the one the graph is launched on),
+    // and that stream alone is waited for -- no device-wide wait, which would stall every other stream of the device and fail
+    // outright while any of them is being captured.
     hipStream_t s = pick_stream(h, stream);
-    if (s != h->last_stream || h->last_captured) HIP_OK(h, hipStreamSynchronize(s));
+    if (!h->last_captured && h->timing_valid) {
+        HIP_OK(h, hipEventSynchronize(h->ev[3]));
+        if (s != h->last_stream) HIP_OK(h, hipStreamSynchronize(s));
+    } else {
+        if (stream_is_capturing(s)) return fail(h, -6, "mpcgpu_last_eval_counts inside a stream capture: the counters are read on the host");
+        HIP_OK(h, hipStreamSynchronize(s));
+    }
     int32_t* tmp = new (std::nothrow) int32_t[(size_t)B * 2];
     if (!tmp) return fail(h, -3, "out of host memory");
     hipError_t e = hipMemcpy(tmp, h->evals.ptr, (size_t)B * 2 * sizeof(int32_t), hipMemcpyDeviceToHost);

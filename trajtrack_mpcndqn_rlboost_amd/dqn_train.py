@@ -186,6 +186,23 @@ class DqnTrainer:
         ids = [i for g in sd["param_groups"] for i in g["params"]]
         if len(ids) != len(params):
             raise ValueError(f"optimizer checkpoint holds {len(ids)} parameters, this optimizer {len(params)}")
+        # everything the captured graph has baked in is compared BEFORE anything is copied: a checkpoint that does not fit must
+        # leave the live optimiser state as it was
+        if len(sd["param_groups"]) != len(self.optimizer.param_groups):
+            raise ValueError(f"optimizer checkpoint holds {len(sd['param_groups'])} parameter groups, this optimizer {len(self.optimizer.param_groups)}")
+        for g, gs in zip(self.optimizer.param_groups, sd["param_groups"]):
+            for key in ("lr", "betas", "eps", "weight_decay", "amsgrad", "maximize"):
+                as_tuple = lambda v: tuple(v) if isinstance(v, (tuple, list)) else (v,)
+                if key in g and key in gs and as_tuple(g[key]) != as_tuple(gs[key]):
+                    raise ValueError(f"the captured graph holds the optimiser's {key} = {g[key]!r} it was captured with; the checkpoint has "
+                                     f"{gs[key]!r} (load it before enable_graph, or capture again)")
+        for p, i in zip(params, ids):
+            src = sd["state"].get(i)
+            if src is not None:
+                for k in ("exp_avg", "exp_avg_sq"):
+                    if tuple(torch.as_tensor(src[k]).shape) != tuple(self.optimizer.state[p][k].shape):
+                        raise ValueError(f"optimizer checkpoint: {k} of parameter {i} has shape {tuple(torch.as_tensor(src[k]).shape)}, "
+                                         f"expected {tuple(self.optimizer.state[p][k].shape)}")
         with torch.no_grad():
             for p, i in zip(params, ids):
                 st, src = self.optimizer.state[p], sd["state"].get(i)
@@ -194,9 +211,6 @@ class DqnTrainer:
                         st[k].zero_()
                     else:
                         st[k].copy_(torch.as_tensor(src[k]).to(device=st[k].device, dtype=st[k].dtype))
-        for g, gs in zip(self.optimizer.param_groups, sd["param_groups"]):
-            if g["lr"] != gs["lr"]:
-                raise ValueError("the captured graph holds the learning rate it was captured with; checkpoint differs")
 
     def sync_target(self) -> None:
         """Hard target update (SB3 ``polyak_update`` with tau = 1)."""
