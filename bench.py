@@ -297,17 +297,17 @@ def main():
         for _ in range(max(warmup - 1, 0)):
             sv.solve_device(p, o, stream=stream)
         barrier()
-        k_ms, p_ms = [], []
+        k_ms, p_ms, t_ms = [], [], []
         t0 = time.perf_counter()
         for _ in range(steps):
             sv.solve_device(p, o, stream=stream)
             t = sv.last_timing()          # HIP events recorded on `stream` around the two kernels
-            k_ms.append(t["solve_ms"]); p_ms.append(t["prep_ms"])
+            k_ms.append(t.get("main_ms", t["solve_ms"])); p_ms.append(t["prep_ms"]); t_ms.append(t.get("tail_ms", 0.0))
         barrier()
         mine = time.perf_counter() - t0
         n_psi, n_grad = sv.last_eval_counts(b, stream)
         promo = sv.last_tail_promotion(stream) if hasattr(sv, "last_tail_promotion") else (0, 0)
-        return dict(elapsed=mine, kernel_ms=float(np.mean(k_ms)), prep_ms=float(np.mean(p_ms)), tail_promotion=promo,
+        return dict(elapsed=mine, kernel_ms=float(np.mean(k_ms)), prep_ms=float(np.mean(p_ms)), tail_ms=float(np.mean(t_ms)), tail_promotion=promo,
                     status=o["status"].cpu().numpy().copy(), inner=o["inner_it"].cpu().numpy().copy(),
                     n_psi=n_psi, n_grad=n_grad)
 
@@ -390,7 +390,7 @@ def main():
         o_el, _ = over_ranks(ol["elapsed"])
         b = int(pb.shape[0])
         item = {"value": world * b * steps / o_el, "unit": "solves/s", "steps": steps, "ms_per_step": 1e3 * o_el / steps,
-                "kernel_ms": ol["kernel_ms"], "status_histogram": np.bincount(ol["status"], minlength=3).tolist(),
+                "kernel_ms": ol["kernel_ms"] + ol["tail_ms"], "status_histogram": np.bincount(ol["status"], minlength=3).tolist(),
                 "how": "MPCGPU_OPT_ORDER = 1 (the library's default): problems started longest first by the evaluation counts of the "
                        "previous step; the step repeats the same batch, so the hints are PERFECT: an upper bound (config.closed_loop "
                        "has the figure with the real hints of a receding-horizon loop)"}
@@ -433,7 +433,7 @@ def main():
             s_el, _ = over_ranks(sl["elapsed"])
             item = {"batch_per_gpu": b, "steps": side_steps,
                     "plain": {"value": world * b * side_steps / s_el, "unit": "solves/s", "ms_per_step": 1e3 * s_el / side_steps,
-                              "kernel_ms": sl["kernel_ms"], "status_histogram": np.bincount(sl["status"], minlength=3).tolist(),
+                              "kernel_ms": sl["kernel_ms"] + sl["tail_ms"], "status_histogram": np.bincount(sl["status"], minlength=3).tolist(),
                               "psi_evals_per_s": world * float(sl["n_psi"].sum()) * side_steps / s_el,
                               "tail_promotion": {"capacity": sl["tail_promotion"][0], "promoted_last_step": sl["tail_promotion"][1]}}}
             if hasattr(sv, "close"):
@@ -514,7 +514,8 @@ def main():
                        "wavefronts_per_simd": solver.last_shape()["waves_per_simd"],
                        "tail_promotion": {"what": "MPCGPU_OPT_TAIL_PROMOTION (library default): the last problems of a plain launch "
                                                   "move to the latency kernel at the start of their next inner problem; bitwise the same results",
-                                          "capacity": leg["tail_promotion"][0], "promoted_last_step": leg["tail_promotion"][1]}},
+                                          "capacity": leg["tail_promotion"][0], "promoted_last_step": leg["tail_promotion"][1],
+                                          "continuation_kernel_ms": leg["tail_ms"]}},
         }
         if conv is not None:
             cl = conv["leg"]
@@ -523,7 +524,7 @@ def main():
                             "box_clearance=0.3): discs and box beside the path, a collision-free plan exists",
                 "batch_per_gpu": Bs,
                 "value": world * Bs * conv["steps"] / conv["elapsed"], "unit": "solves/s", "steps": conv["steps"],
-                "ms_per_step": 1e3 * conv["elapsed"] / conv["steps"], "kernel_ms": cl["kernel_ms"],
+                "ms_per_step": 1e3 * conv["elapsed"] / conv["steps"], "kernel_ms": cl["kernel_ms"] + cl["tail_ms"],
                 "status_histogram": np.bincount(cl["status"], minlength=3).tolist(),
                 "converged_fraction": float((cl["status"] == 0).mean()),
                 "mean_inner_iterations": float(cl["inner"].mean()),
@@ -538,7 +539,7 @@ def main():
                             "the problems, the detour leads to the free side of the corridor; previous speed 0.8-1.2 m/s",
                 "batch_per_gpu": Bs,
                 "value": world * Bs * av["steps"] / av["elapsed"], "unit": "solves/s", "steps": av["steps"],
-                "ms_per_step": 1e3 * av["elapsed"] / av["steps"], "kernel_ms": al["kernel_ms"],
+                "ms_per_step": 1e3 * av["elapsed"] / av["steps"], "kernel_ms": al["kernel_ms"] + al["tail_ms"],
                 "status_histogram": np.bincount(al["status"], minlength=3).tolist(),
                 "converged_fraction": float((al["status"] == 0).mean()),
                 "mean_inner_iterations": float(al["inner"].mean()),
@@ -568,7 +569,9 @@ def main():
             tf = flops / (k_ms * 1e-3) / 1e12
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
-                    "kernel": "solve_kernel", "kernel_ms": k_ms, "prep_kernel_ms": leg["prep_ms"],
+                    "kernel": "solve_kernel_pair", "kernel_ms": k_ms, "prep_kernel_ms": leg["prep_ms"],
+                    "tail_kernel": "solve_kernel_team (continuation launch of the tail promotion: the last problems of the launch)",
+                    "tail_kernel_ms": leg["tail_ms"],
                     "algorithmic_bytes_per_solve": algo_bytes // B,
                     "measured_in_run": {"achieved": True, "kernel_ms": True, "frac": True, "flops": True,
                                         "traffic": in_run, "wasted_traffic_ratio": in_run, "traffic_GBps": in_run,

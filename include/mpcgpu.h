@@ -125,6 +125,11 @@ int32_t mpcgpu_cost_grad_batch(void* handle, int32_t B, const double* u, const d
  * solve kernel.  Valid after the stream has been synchronised. */
 int32_t mpcgpu_last_timing(void* handle, double* prep_ms, double* solve_ms);
 
+/* (ABI 7) The solve time of mpcgpu_last_timing split at the tail promotion (MPCGPU_OPT_TAIL_PROMOTION): main_ms = the throughput
+ * (or latency) kernel including the ordering kernels in front of it, tail_ms = the continuation launch of the latency kernel
+ * behind it (0 when none was enqueued).  main_ms + tail_ms = solve_ms. */
+int32_t mpcgpu_last_tail_timing(void* handle, double* main_ms, double* tail_ms);
+
 /* Work counters of the last solve call, per problem: psi evaluations executed and how many of them also produced
  * grad psi (the counts OpEn's generated `cost` / `grad_cost` functions would see, minus the redundant re-evaluation of
  * psi(u) in the Lipschitz update; the latency kernel reports the counts of the SEQUENTIAL algorithm, not its speculative

@@ -32,7 +32,7 @@ def test_mpc_and_hybrid_reach_the_goal_without_collision(mode):
     loop, cfg, q, scenes = _setup(8)
     run = hybrid.BatchedHybrid(cfg, scenes, q, decision_mode=mode)
     out = run.run(200)
-    # pure MPC (mode 1) can stay stuck behind the box for a whole run (profiles/r01_hybrid_loop_B64.txt: 93 % success), and
+    # pure MPC (mode 1) can stay stuck behind the box for a whole run (profiles/archive/r01_hybrid_loop_B64.txt: 93 % success), and
     # which robot does depends on cap-limited solves, i.e. on rounding: the assertions are on rates, not on every robot
     assert out["done"].mean() >= (0.75 if mode == 1 else 1.0)
     assert not out["collided"].any()

@@ -34,6 +34,8 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 NUM_CUS, SIMDS_PER_CU = 256, 4
+SOLVE_KERNEL = "solve_kernel_pair"   # the dominant kernel (one problem per wavefront); "solve_kernel" alone would also match ...
+TAIL_KERNEL = "solve_kernel_team"    # ... the latency kernel, which finishes the last problems of a launch since round 5
 HBM_PEAK_GBS = 8000.0
 FP64_VECTOR_PEAK_TF = 78.6
 
@@ -128,16 +130,22 @@ def rebuild(raw_dir, out_path):
     algo = 8 * np_ + 16 * N * 2 + 40
     kt = os.path.join(raw_dir, "kt_kernel_stats.csv")
     if os.path.exists(kt):
-        avg_ns, calls = _kernel_avg_ns(kt, "solve_kernel")
+        avg_ns, calls = _kernel_avg_ns(kt, SOLVE_KERNEL)
         prep_ns, _ = _kernel_avg_ns(kt, "prep_kernel")
         time_source = "rocprofv3 --kernel-trace --stats pass"
     else:   # bench.py's in-run passes: no kernel-trace pass, the dispatch timestamps of the SQ counter pass itself
-        avg_ns, calls = _dispatch_avg_ns(os.path.join(raw_dir, "pmc_sq_counter_collection.csv"), "solve_kernel")
+        avg_ns, calls = _dispatch_avg_ns(os.path.join(raw_dir, "pmc_sq_counter_collection.csv"), SOLVE_KERNEL)
         prep_ns, _ = _dispatch_avg_ns(os.path.join(raw_dir, "pmc_sq_counter_collection.csv"), "prep_kernel")
         time_source = "dispatch timestamps of the SQ counter pass"
-    sq, n_sq = _read_counters(os.path.join(raw_dir, "pmc_sq_counter_collection.csv"), "solve_kernel")
-    fe, n_fe = _read_counters(os.path.join(raw_dir, "pmc_fetch_counter_collection.csv"), "solve_kernel")
-    wr, n_wr = _read_counters(os.path.join(raw_dir, "pmc_write_counter_collection.csv"), "solve_kernel")
+    sq, n_sq = _read_counters(os.path.join(raw_dir, "pmc_sq_counter_collection.csv"), SOLVE_KERNEL)
+    fe, n_fe = _read_counters(os.path.join(raw_dir, "pmc_fetch_counter_collection.csv"), SOLVE_KERNEL)
+    wr, n_wr = _read_counters(os.path.join(raw_dir, "pmc_write_counter_collection.csv"), SOLVE_KERNEL)
+    # the continuation launch of the tail promotion (round 5): the latency kernel on the problems that left the throughput launch
+    try:
+        tail_ns, tail_calls = (_kernel_avg_ns(kt, TAIL_KERNEL) if os.path.exists(kt) else
+                               _dispatch_avg_ns(os.path.join(raw_dir, "pmc_sq_counter_collection.csv"), TAIL_KERNEL))
+    except KeyError:
+        tail_ns, tail_calls = 0.0, 0
     pf, n_pf = _read_counters(os.path.join(raw_dir, "pmc_fetch_counter_collection.csv"), "prep_kernel")
     sq = {k: v / n_sq for k, v in sq.items()}
     fetch_kib, write_kib = fe["FETCH_SIZE"] / n_fe, wr["WRITE_SIZE"] / n_wr
@@ -152,6 +160,7 @@ def rebuild(raw_dir, out_path):
         "kernel": wl.get("kernel", "solve_kernel_pair"),
         "kernel_avg_ms_kernel_trace": avg_ns * 1e-6, "kernel_calls_kernel_trace": calls, "kernel_time_source": time_source,
         "prep_kernel_avg_ms": prep_ns * 1e-6,
+        "tail_kernel": TAIL_KERNEL, "tail_kernel_avg_ms": tail_ns * 1e-6, "tail_kernel_calls": tail_calls,
         "raw_per_launch": {"sq_pass": sq, "FETCH_SIZE_KiB": fetch_kib, "WRITE_SIZE_KiB": write_kib,
                            "prep_kernel_FETCH_SIZE_KiB": prep_fetch / 1024.0},
         "fetch_calibration_prep_kernel_measured_over_expected": calib,

@@ -33,7 +33,8 @@ struct Handle {
     KParams kp{};
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // prep start/end, solve start/end
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // prep start/end, solve start/end, [4] between the throughput kernel and its continuation
+    bool tail_timed = false;   // ev[4] was recorded by the last solve (tail promotion enqueued a continuation launch)
     bool timing_valid = false;
     std::string err;
     // grow-only device buffers
@@ -424,6 +425,7 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
     const int team_cap = h->team_max_batch >= 0 ? h->team_max_batch : 4 * h->num_cus;  // measured break-even: 1000-1500 problems (tools/team_sweep.py)
     h->last_team = 0;
     h->last_yield_cap = 0;
+    h->tail_timed = false;
     h->kp.yield_from = 0;
     bool prepared = false;
 #ifdef MPC_TRACE
@@ -588,9 +590,10 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
     int yield_K = 0, yield_tw = 0;
     KParams kt_y{};
     size_t lds_y = 0;
-    // Not with a launch that starts its problems longest first: its tail is short already and the continuation only adds its own
-    // launch and the wait for the inner-problem boundaries (measured: 210 -> 213 ms at B = 8192, profiles/r05_tail_promotion_ab.txt).
-    if (MPC_STEP_LOOP && h->yield_opt != 0 && !h->last_pairing && !lin40 && !(h->last_ordered && h->yield_opt < 0)) {
+    // Also on launches that start their problems longest first: with PERFECT hints (a bench step that repeats its batch) the tail is
+    // short already and the continuation costs 1 % (210 -> 213 ms at B = 8192), but with the REAL hints of a receding-horizon loop
+    // the two add up (8192 robots, cold: 168 ms per tick plain, 159 promoted, 160 ordered, 152 both: profiles/r05_closed_loop_ab.txt).
+    if (MPC_STEP_LOOP && h->yield_opt != 0 && !h->last_pairing && !lin40) {
         // How many problems of the latency kernel a compute unit holds: 8 wavefronts of that kernel by registers, and the LDS carve
         // (tables for this batch's maxima).  Automatic rule: four wavefronts per problem, K = what is resident at once.
         auto team_shape = [&](int tw, KParams& kt, size_t& lds_t) -> int {
@@ -663,7 +666,9 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
 #undef LAUNCH_PAIR_WA
 #undef LAUNCH_PAIR_W
     HIP_OK(h, hipGetLastError());
+    h->tail_timed = false;
     if (yield_K > 0) {
+        if (!h->capturing) { HIP_OK(h, hipEventRecord(h->ev[4], s)); h->tail_timed = true; }
         // the continuation: grid = capacity of the list, workgroups beyond its device-side length leave at once
 #define LAUNCH_RESUME(NT, TW)                                                                                        \
     do {                                                                                                             \
@@ -986,6 +991,24 @@ int32_t mpcgpu_last_timing(void* handle, double* prep_ms, double* solve_ms) {
     return 0;
 }
 
+int32_t mpcgpu_last_tail_timing(void* handle, double* main_ms, double* tail_ms) {
+    Handle* h = (Handle*)handle;
+    if (!h) return -1;
+    if (!h->timing_valid) return fail(h, -4, "no solve call has been timed yet");
+    HIP_OK(h, hipSetDevice(h->device));
+    HIP_OK(h, hipEventSynchronize(h->ev[3]));
+    float a = 0.f, b = 0.f;
+    if (h->tail_timed) {
+        HIP_OK(h, hipEventElapsedTime(&a, h->ev[2], h->ev[4]));
+        HIP_OK(h, hipEventElapsedTime(&b, h->ev[4], h->ev[3]));
+    } else {
+        HIP_OK(h, hipEventElapsedTime(&a, h->ev[2], h->ev[3]));
+    }
+    if (main_ms) *main_ms = a;
+    if (tail_ms) *tail_ms = b;
+    return 0;
+}
+
 int32_t mpcgpu_last_eval_counts(void* handle, int32_t B, int32_t* n_psi, int32_t* n_grad, void* stream) {
     Handle* h = (Handle*)handle;
     if (!h) return -1;
@@ -1054,6 +1077,24 @@ int32_t mpcgpu_reserve_batch(void* handle, int32_t B) {
     if (int r = ensure(h, h->perm, (size_t)B * sizeof(int32_t))) return r;
     if (int r = ensure(h, h->bins, ORD_BINS * sizeof(int))) return r;
     if (int r = ensure(h, h->nlist, (size_t)B * sizeof(int32_t))) return r;
+    {   // tail promotion: the list of promoted problems, and the continuation kernel's LDS size when the carve is known (reservation)
+        const int K = h->yield_opt > 4 * h->num_cus ? h->yield_opt : 4 * h->num_cus;
+        if (int r = ensure(h, h->ylist, (size_t)K * sizeof(int32_t))) return r;
+        if (h->reserved && h->yield_opt != 0) {
+            for (int tw : {TEAM_WAVES, 2}) {
+                KParams kt = h->kp;
+                fill_team_layout(kt, tw, h->res_shape[0], h->res_shape[1], h->res_shape[2]);
+                const size_t lds_t = kt.l_total * sizeof(double);
+                if (lds_t + PREP_STATIC_LDS > 160 * 1024) continue;
+                const int nt = compiled_horizon(h);
+                const void* kern = tw == TEAM_WAVES ? (nt == 20 ? (const void*)solve_kernel_team<20, TEAM_WAVES> : nt == 40 ? (const void*)solve_kernel_team<40, TEAM_WAVES>
+                                                                                                                     : (const void*)solve_kernel_team<0, TEAM_WAVES>)
+                                                    : (nt == 20 ? (const void*)solve_kernel_team<20, 2> : nt == 40 ? (const void*)solve_kernel_team<40, 2>
+                                                                                                                 : (const void*)solve_kernel_team<0, 2>);
+                if (int r = opt_in_lds(h, kern, lds_t)) return r;
+            }
+        }
+    }
     // A batch of the latency range is captured in its one-launch form (tables for the configured maxima: more than 64 KiB of
     // dynamic LDS for the yaml's slot counts), whatever form an eager call of the same size takes: opt that kernel in now.
     const int team_cap = h->team_max_batch >= 0 ? h->team_max_batch : 4 * h->num_cus;

@@ -62,7 +62,7 @@ class _CConfig(C.Structure):
 EXPORTS = ("mpcgpu_abi_version", "mpcgpu_create", "mpcgpu_destroy", "mpcgpu_last_error", "mpcgpu_num_params",
            "mpcgpu_solve_batch", "mpcgpu_solve_batch_dev", "mpcgpu_cost_grad_batch", "mpcgpu_last_timing",
            "mpcgpu_last_eval_counts", "mpcgpu_last_shape", "mpcgpu_last_waves_per_simd", "mpcgpu_reserve_shape",
-           "mpcgpu_set_option", "mpcgpu_last_problems_per_wavefront", "mpcgpu_last_ordered", "mpcgpu_last_tail_promotion", "mpcgpu_last_latency_kernel", "mpcgpu_reserve_batch", "mpcgpu_last_table_kind", "mpcgpu_tracker_window_dev",
+           "mpcgpu_set_option", "mpcgpu_last_problems_per_wavefront", "mpcgpu_last_ordered", "mpcgpu_last_tail_promotion", "mpcgpu_last_tail_timing", "mpcgpu_last_latency_kernel", "mpcgpu_reserve_batch", "mpcgpu_last_table_kind", "mpcgpu_tracker_window_dev",
            "mpcgpu_tracker_step_dev", "mpcgpu_rl_reference_dev", "mpcgpu_hint_switch_dev", "mpcgpu_debug_read_workspace",
            "mpcgpu_workspace_stride", "mpcgpu_workspace_record", "mpcgpu_debug_prep", "mpcgpu_debug_tracker_assemble",
            "mpcgpu_debug_lbfgs_direction")
@@ -150,6 +150,8 @@ def load_library(path: Optional[str] = None):
     if hasattr(L, "mpcgpu_last_tail_promotion"):   # (absent only in an old build loaded for an A/B run, see MPCGPU_ALLOW_ABI)
         L.mpcgpu_last_tail_promotion.argtypes = [vp, ip, vp]
         L.mpcgpu_last_tail_promotion.restype = C.c_int32
+        L.mpcgpu_last_tail_timing.argtypes = [vp, dp, dp]
+        L.mpcgpu_last_tail_timing.restype = C.c_int32
     L.mpcgpu_reserve_shape.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.mpcgpu_reserve_shape.restype = C.c_int32
     tp = C.POINTER(CTracker)
@@ -486,9 +488,16 @@ class BatchSolver:
         return out
 
     def last_timing(self):
+        """prep_ms, solve_ms (HIP events around the compaction and around everything the solve enqueued) and the split of solve_ms
+        at the tail promotion: main_ms (throughput kernel) + tail_ms (continuation launch of the latency kernel, 0 without one)."""
         a, b = C.c_double(), C.c_double()
         self._check(self._L.mpcgpu_last_timing(self._h, C.byref(a), C.byref(b)), "mpcgpu_last_timing")
-        return dict(prep_ms=a.value, solve_ms=b.value)
+        out = dict(prep_ms=a.value, solve_ms=b.value, main_ms=b.value, tail_ms=0.0)
+        if hasattr(self._L, "mpcgpu_last_tail_timing"):
+            m, t = C.c_double(), C.c_double()
+            self._check(self._L.mpcgpu_last_tail_timing(self._h, C.byref(m), C.byref(t)), "mpcgpu_last_tail_timing")
+            out["main_ms"], out["tail_ms"] = m.value, t.value
+        return out
 
     def last_eval_counts(self, B: int, stream: Optional[int] = None):
         """(psi evaluations, of which with gradient) per problem of the last solve of B problems (``stream``: the
