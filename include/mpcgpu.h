@@ -205,12 +205,14 @@ int32_t mpcgpu_reserve_batch(void* handle, int32_t B);
  *       r04_linear_tables_ab.txt), which is why the product does not carry it.  0: always the stored centres.
  *   MPCGPU_OPT_TAIL_PROMOTION  (ABI 7) the tail of a throughput launch.  A solve is one long dependency chain, so the last problems
  *       of a large batch finish on a draining GPU (0.07-0.08 s per launch whatever the batch).  -1 (default): once all but
- *       K = 2 x #CUs problems of the launch have finished, every wavefront that is still running leaves at its next PANOC step
- *       boundary -- the state of its iteration goes into the problem's workspace record -- and a continuation launch of the
- *       LATENCY kernel on the same stream (four wavefronts per problem: the evaluations of a step side by side, 2.3 x faster per
- *       problem on an empty GPU) finishes those problems from exactly that boundary.  > 0: that K (up to 2 x #CUs: four wavefronts per
- *       problem, beyond: two); 0: off.  Same step functions on the same state: every output is BITWISE what the throughput kernel
- *       alone writes (tests/test_gpu_yield.py); nothing is read back, the call stays capturable.  The reference has no counterpart.
+ *       K problems of the launch have finished, every wavefront that is still running leaves at the START OF ITS NEXT INNER
+ *       PROBLEM -- point, multipliers, penalty, tolerance and the outer loop's counters go into the problem's workspace record --
+ *       and a continuation launch of the LATENCY kernel on the same stream (four wavefronts per problem: the evaluations of a step
+ *       side by side, 2.3 x faster per problem on an empty GPU) finishes those problems from exactly that point.  Automatic K:
+ *       twice the teams that are resident at once (N_hor = 20: 4 x #CUs = 1024; N_hor = 40: #CUs, one team per compute unit by
+ *       its LDS carve).  > 0: that K (beyond four times the residency: two wavefronts per problem); 0: off.  Same step functions
+ *       on the same state: every output is BITWISE what the throughput kernel alone writes (tests/test_gpu_yield.py); nothing is
+ *       read back, the call stays capturable.  The reference has no counterpart.
  *   MPCGPU_OPT_TAIL_POLL  (ABI 7) PANOC steps between two looks at the launch's finished-counter (a power of two, default 16;
  *       only the A/B build -DMPC_YIELD_STEP=1 looks inside an inner problem at all).
  *   MPCGPU_OPT_TAIL_WAVES  (ABI 7) wavefronts per promoted problem: 0 (default) by K as above, 2 or 4.

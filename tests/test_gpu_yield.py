@@ -42,9 +42,9 @@ def test_promoted_problems_finish_bitwise_like_the_throughput_kernel(N, B, fam):
     r0, e0, cap0, moved0, t0 = _solve(cfg, sc["p"], 0)
     assert cap0 == 0 and moved0 == 0
     figures = [f"off {t0:.1f} ms"]
-    for K in (-1, 1024, B):     # the library's rule (2 per CU, four wavefronts each); two wavefronts each; everything (after the first finisher)
+    for K in (-1, 512, B):      # the library's rule; half of it; everything (after the first finisher; two wavefronts per problem)
         r, e, cap, moved, t = _solve(cfg, sc["p"], K)
-        assert cap == ((512 if N != 40 else 256) if K == -1 else K)     # automatic: what four-wavefront teams hold at once (LDS carve at N_hor = 40: one per CU)
+        assert cap == ((1024 if N != 40 else 256) if K == -1 else K)    # automatic: twice what four-wavefront teams hold at once (N_hor = 40: one team per CU by its LDS carve)
         assert moved > 0, (K, moved)
         _same(r0, r)
         assert np.array_equal(e0[0], e[0]) and np.array_equal(e0[1], e[1])
@@ -173,5 +173,5 @@ def test_captured_launch_carries_the_continuation():
         torch.cuda.synchronize()
         for k in ref:
             assert torch.equal(ref[k], out[k]), k
-    assert bs.last_tail_promotion()[0] == 512
+    assert bs.last_tail_promotion()[0] == 1024
     ref_solver.close(); bs.close()

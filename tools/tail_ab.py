@@ -16,14 +16,15 @@ reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 fam = sys.argv[5] if len(sys.argv) > 5 else "bench"
 order = sys.argv[6] if len(sys.argv) > 6 else "as_given"
 poll = int(os.environ["MPCGPU_TAIL_POLL"]) if os.environ.get("MPCGPU_TAIL_POLL") else None
+waves = int(os.environ["MPCGPU_TAIL_WAVES"]) if os.environ.get("MPCGPU_TAIL_WAVES") else None
 cfg = MpcConfig(N_hor=N)
-print(f"# {os.environ.get('MPCGPU_LIB', 'libmpcgpu.so')}  N_hor={N} family={fam} order={order} poll={poll}")
+print(f"# {os.environ.get('MPCGPU_LIB', 'libmpcgpu.so')}  N_hor={N} family={fam} order={order} poll={poll} waves={waves}")
 for B in Bs:
     sc = scenes.make_batch(cfg, B, n_dyn=8, seed=1236) if fam == "bench" else scenes.make_family(cfg, B, fam, n_dyn=8, seed=1236)
     for K in Ks:
         bs = BatchSolver(cfg, order=order, tail_promotion=K)
-        if poll:
-            bs.set_tail_promotion(K, poll)
+        if poll or waves:
+            bs.set_tail_promotion(K, poll, waves)
         ts, moved = [], 0
         for _ in range(reps + (1 if order == "longest_first" else 0)):
             res = bs.solve(sc["p"])

@@ -148,6 +148,9 @@ struct KParams {
 #ifndef MPC_YIELD_STEP
 #define MPC_YIELD_STEP 0
 #endif
+#ifndef MPC_DUP_SHARED
+#define MPC_DUP_SHARED 0   // 1: measurement build, see eval_point
+#endif
 enum { YS_C = 0, YS_GAMMA, YS_IG, YS_LIP, YS_SIGMA, YS_COST, YS_GG, YS_D2H, YS_AKKT, YS_NFPR, YS_IP, YS_DYN, YS_F2N, YS_LASTFPR, YS_FFINAL,
        YS_HGAMMA, YS_ELAPSED, YS_ITER, YS_NUMITER, YS_FLAGS /* 1 cont_iters, 2 cont_time, 4 a step has completed, 8 L-BFGS buffer empty, 16 left at the start of an inner problem */,
        YS_ALMIT, YS_NOUTER, YS_INNERTOT, YS_STATUS, YS_NEVAL, YS_NEVALG, YS_LBACTIVE, YS_LBHEAD, YS_TRN, YS_TRPSI, YS_SCALARS = 32 };
@@ -1019,6 +1022,27 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
             s0 = shift_up1(s2, lane, HD(H_STH0));
         }
     }
+#if MPC_DUP_SHARED
+    // MEASUREMENT BUILD (round 5, `make variants`: libmpcgpu_dupshared.so): what could "two evaluation points per pass" save at
+    // best?  A pass that carries the half step of the Lipschitz test next to the first line-search trial (rows 2-3) would share the
+    // heading chain -- half-angle polynomials, the complex prefix product, the rotations -- between the two points; everything
+    // behind it (positions, item phases, per-step terms, psi) runs once per point.  Here the gradient-free evaluation (the
+    // Lipschitz test: one per PANOC step) executes that chain TWICE, on an opaque copy of its input, and throws the copy away: the
+    // time this build loses is the time the pairing could win.  Same results (profiles/r05_two_point_ceiling.txt).
+    if (!want_grad) {
+        double w2 = w;
+        asm volatile("" : "+v"(w2));
+        const double hd2 = 0.5 * ts * w2;
+        double sh, ch;
+        sincos_small(hd2, cx.hd + KC_BASE, sh, ch);
+        double er = ch * ch - sh * sh, ei = 2.0 * sh * ch;
+        P::template cprod<RV>(er, ei);
+        const double d2 = HD(H_CTH0) * er - HD(H_STH0) * ei, e2 = HD(H_CTH0) * ei + HD(H_STH0) * er;
+        const double d0 = shift_up1(d2, lane, HD(H_CTH0)), e0 = shift_up1(e2, lane, HD(H_STH0));
+        const double dm = d0 * ch - e0 * sh, em = d0 * sh + e0 * ch;
+        asm volatile("" :: "v"(d2), "v"(e2), "v"(dm), "v"(em));
+    }
+#endif
     PROF_MARK(0);  // headings
     const double sixth = KC(K_SIXTH);
     double kCx = 0.0, kSy = 0.0, kdCw = 0.0, kdSw = 0.0;   // stash stride 0: the Simpson values stay here

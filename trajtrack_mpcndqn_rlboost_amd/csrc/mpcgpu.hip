@@ -606,8 +606,11 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
         };
         int tw = h->yield_waves ? h->yield_waves : TEAM_WAVES;
         int per_cu = team_shape(tw, kt_y, lds_y);
-        int K = h->yield_opt > 0 ? h->yield_opt : per_cu * h->num_cus;
-        if (!h->yield_waves && h->yield_opt > per_cu * h->num_cus) { tw = 2; per_cu = team_shape(tw, kt_y, lds_y); }   // more than four-wavefront teams hold at once: two each
+        // Automatic capacity: TWICE what is resident at once when a compute unit holds two teams (N_hor = 20: 1024 -- the second
+        // half starts as the first finishes; 252.7 -> 248.4 ms at B = 8192, profiles/r05_tail_promotion_ab.txt), else what is
+        // resident (N_hor = 40: 256).  An explicit capacity beyond four times the residency takes two wavefronts per problem.
+        int K = h->yield_opt > 0 ? h->yield_opt : (per_cu >= 2 ? 2 : 1) * per_cu * h->num_cus;
+        if (!h->yield_waves && h->yield_opt > 4 * per_cu * h->num_cus) { tw = 2; per_cu = team_shape(tw, kt_y, lds_y); }
         if (K > B) K = B;
         if (per_cu >= 1 && K > 0) {
             if (int r = ensure(h, h->ylist, (size_t)K * sizeof(int32_t))) return r;
