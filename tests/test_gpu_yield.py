@@ -175,3 +175,19 @@ def test_captured_launch_carries_the_continuation():
             assert torch.equal(ref[k], out[k]), k
     assert bs.last_tail_promotion()[0] == 1024
     ref_solver.close(); bs.close()
+
+
+def test_closed_loop_trajectories_do_not_depend_on_the_promotion():
+    """The device-resident tracker loop (tools/closed_loop.device_closed_loop, bench.py's `config.closed_loop`): records written by
+    the assembly kernel, promotion inside every tick, with and without the dispatch order -- the robots must end exactly where
+    the plain launches take them."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tools.closed_loop import device_closed_loop
+    cfg = make_cfg(20, solver_max_inner_iterations=60, solver_max_outer_iterations=4)
+    for warm in (False, True):
+        ref = device_closed_loop(cfg, 6144, 4, 2, 4, warm, "as_given", tail_promotion=0)
+        for order, K in (("as_given", None), ("longest_first", None), ("as_given", 3000)):
+            r = device_closed_loop(cfg, 6144, 4, 2, 4, warm, order, tail_promotion=K)
+            assert np.array_equal(ref["_final_states"], r["_final_states"]), (warm, order, K)
+            assert ref["status_histogram_per_tick"] == r["status_histogram_per_tick"]
