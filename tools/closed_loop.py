@@ -125,8 +125,74 @@ def device_closed_loop(cfg, B=8192, ticks=30, warmup_ticks=5, n_dyn=4, warm=Fals
     return res
 
 
+def device_closed_loop_streams(cfg, B=8192, streams=2, ticks=30, warmup_ticks=5, n_dyn=4, warm=False, order="longest_first", device=0, seed=5):
+    """The same loop with the fleet split into `streams` sub-fleets, each with its own DeviceTracker, solver handle and HIP stream,
+    ticking back to back without waiting for one another: the launch of one sub-fleet fills the compute units that the tail of
+    another one is draining (the robots of a tick are independent: src/scenario_simulator.py:226-233 couples them only through the
+    PREVIOUS tick's predictions).  What matters for a controller that has to act every `ts`: the PERIOD of a sub-fleet's ticks
+    (start to start on its stream = its own tick duration under the others' load).  Returns per-tick periods of every sub-fleet."""
+    import torch
+    from trajtrack_mpcndqn_rlboost_amd import BatchSolver
+    from trajtrack_mpcndqn_rlboost_amd.device_tracker import DeviceTracker
+    from trajtrack_mpcndqn_rlboost_amd.feeders import DYN_OBS_SIZE
+    N = int(cfg.N_hor)
+    dev = torch.device("cuda", device)
+    sizes = [B // streams + (1 if i < B % streams else 0) for i in range(streams)]
+    total = warmup_ticks + ticks
+    k = torch.arange(1, N + 1, dtype=torch.float64, device=dev)
+    fleets = []
+    for i, b in enumerate(sizes):
+        solver = BatchSolver(cfg, device=device, order=order)
+        dt = DeviceTracker(cfg, b, device=device, solver=solver)
+        y0, pos_h, vel_h, static = scene_one(b, n_dyn, seed + 101 * i)
+        setup(dt, b, y0, static)
+        pred = torch.zeros(b, n_dyn, N, 6, dtype=torch.float64, device=dev)
+        pred[..., 2] = DYN_OBS_SIZE; pred[..., 3] = DYN_OBS_SIZE; pred[..., 5] = 1.0
+        fleets.append(dict(solver=solver, dt=dt, pos=torch.from_numpy(pos_h).to(dev), vel=torch.from_numpy(vel_h).to(dev), pred=pred, b=b,
+                           stream=torch.cuda.Stream(device=dev), guess=None,
+                           ev=[torch.cuda.Event(enable_timing=True) for _ in range(total + 1)],
+                           statuses=torch.zeros(total, b, dtype=torch.int32, device=dev)))
+    torch.cuda.synchronize()
+    for t in range(total):
+        for f in fleets:
+            with torch.cuda.stream(f["stream"]):
+                f["ev"][t].record()
+                f["pred"][..., 0] = f["pos"][..., None, 0] + f["vel"][..., None, 0] * k
+                f["pred"][..., 1] = f["pos"][..., None, 1] + f["vel"][..., None, 1] * k
+                f["dt"].set_dynamic_constraints(f["pred"])
+                out = f["dt"].step(initial_guess=f["guess"])
+                if t == 0:
+                    f["stream"].synchronize()
+                    sh = f["solver"].last_shape()
+                    f["solver"].reserve_shape(max_static=sh["max_static"], max_fleet=sh["max_fleet"], max_dyn=sh["max_dyn"],
+                                              var_shape=not sh["shape_const"], axis_aligned=sh["axis_aligned"])
+                    f["solver"].reserve_batch(f["b"])
+                f["statuses"][t].copy_(out["status"])
+                if warm:
+                    u = out["u"].view(f["b"], N, 2)
+                    f["guess"] = torch.cat([u[:, 1:], u[:, -1:]], dim=1).reshape(f["b"], 2 * N).contiguous()
+                f["pos"] += f["vel"]
+    for f in fleets:
+        with torch.cuda.stream(f["stream"]):
+            f["ev"][total].record()
+    torch.cuda.synchronize()
+    periods = [[f["ev"][t].elapsed_time(f["ev"][t + 1]) for t in range(warmup_ticks, total)] for f in fleets]
+    span = max(fleets[0]["ev"][warmup_ticks].elapsed_time(f["ev"][total]) for f in fleets)
+    hist = np.stack([np.bincount(np.concatenate([f["statuses"][t].cpu().numpy() for f in fleets]), minlength=5)[:5] for t in range(warmup_ticks, total)])
+    if hist[:, 3:].sum():
+        raise RuntimeError("closed loop (streams): non-finite or shape-exceeded solves")
+    res = {"batch": B, "streams": streams, "sub_fleets": sizes, "ticks": ticks, "start": "warm" if warm else "cold", "order": order,
+           "worst_period_ms": float(max(max(p) for p in periods)), "mean_period_ms": float(np.mean(periods)),
+           "periods_ms": [[round(float(x), 2) for x in p] for p in periods],
+           "value": B * ticks / (span * 1e-3), "unit": "solves/s", "converged_fraction": float(hist[:, 0].sum() / (B * ticks)),
+           "status_histogram_last_tick": hist[-1, :3].tolist()}
+    for f in fleets:
+        f["solver"].close()
+    return res
+
+
 def realtime_capacity(cfg, warm=False, order="longest_first", lo=2048, hi=8192, step=512, ticks=30, warmup_ticks=5, n_dyn=4, device=0,
-                      limit_ms=None):
+                      limit_ms=None, streams=1):
     """The largest fleet per GPU (a multiple of `step`) whose WORST control tick of the scene-1 run stays within the sampling
     time `ts` of the yaml (config/mpc_default.yaml: 0.2 s) -- what the reference prints per step as its solve time
     (src/main.py:230-238), asked of a fleet.  Bisection over device_closed_loop runs; returns the sizes tried with their worst /
@@ -136,7 +202,12 @@ def realtime_capacity(cfg, warm=False, order="longest_first", lo=2048, hi=8192, 
 
     def worst(B):
         if B not in tried:
-            r = device_closed_loop(cfg, B, ticks, warmup_ticks, n_dyn, warm, order, device=device)
+            if streams > 1:
+                r = device_closed_loop_streams(cfg, B, streams, ticks, warmup_ticks, n_dyn, warm, order, device=device)
+                r["ms_per_tick_min_max"] = [0.0, r["worst_period_ms"]]; r["ms_per_tick"] = r["mean_period_ms"]
+                r["ms_of_every_tick"] = r["periods_ms"]
+            else:
+                r = device_closed_loop(cfg, B, ticks, warmup_ticks, n_dyn, warm, order, device=device)
             tried[B] = r
         return tried[B]["ms_per_tick_min_max"][1]
     a, b = lo // step, hi // step
@@ -150,7 +221,7 @@ def realtime_capacity(cfg, warm=False, order="longest_first", lo=2048, hi=8192, 
             if worst(m * step) <= limit_ms: a = m
             else: b = m
         best = a * step
-    out = {"limit_ms": limit_ms, "start": "warm" if warm else "cold", "order": order, "robots": best, "step": step,
+    out = {"limit_ms": limit_ms, "start": "warm" if warm else "cold", "order": order, "robots": best, "step": step, "streams": streams,
            "tried": {str(B): {"worst_ms": round(r["ms_per_tick_min_max"][1], 2), "mean_ms": round(r["ms_per_tick"], 2)} for B, r in sorted(tried.items())}}
     if best:
         out["ms_of_every_tick"] = tried[best]["ms_of_every_tick"]
@@ -194,9 +265,17 @@ if __name__ == "__main__":
     if "capacity" in sys.argv[4:]:
         import json
         from trajtrack_mpcndqn_rlboost_amd import MpcConfig
-        for warm in (False, True):
-            r = realtime_capacity(MpcConfig(), warm=warm, n_dyn=K)
-            print(json.dumps(r))
+        for streams, hi in ((1, 8192), (2, 12288)):
+            for warm in (False, True):
+                r = realtime_capacity(MpcConfig(), warm=warm, n_dyn=K, streams=streams, hi=hi)
+                r.pop("ms_of_every_tick", None)
+                print(json.dumps(r), flush=True)
+    elif "streams" in sys.argv[4:]:
+        from trajtrack_mpcndqn_rlboost_amd import MpcConfig
+        for streams in (1, 2, 3):
+            r = device_closed_loop_streams(MpcConfig(), B, streams, T, 5, K, WARM)
+            print(f"[device loop] {streams} stream(s) x {r['sub_fleets']}: {r['value']:.0f} solves/s, tick period mean {r['mean_period_ms']:.1f} ms, worst {r['worst_period_ms']:.1f} ms, "
+                  f"converged {r['converged_fraction']:.3f}, last tick {r['status_histogram_last_tick']}", flush=True)
     elif "host" in sys.argv[4:]:
         host_loop(B, T, K, WARM)
     else:
