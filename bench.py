@@ -31,7 +31,7 @@ Rank 0 prints ONE JSON line (contract in the task description) with extra object
                    when rocprofv3 is there (N = 1): after the timed legs, three `rocprofv3 --pmc` passes (SQ counters,
                    FETCH_SIZE, WRITE_SIZE: one pass each, never combined with a trace) over a child bench.py on the
                    same parameter vectors, rebuilt by tools/roofline.py -- `measured_in_run: true`.  Without the
-                   profiler (or with --no-pmc) the fields come from profiles/r03_roofline_bench.json -- the committed
+                   profiler (or with --no-pmc) the fields come from profiles/r05_roofline_bench.json -- the committed
                    passes on this very workload -- and are marked `measured_in_run: false` with the reason.
   config.convergent -- the same step on the "passing" scene family (same N, obstacle counts and batch; a
                    collision-free plan exists), where about half of the solves converge: the headline family is the
@@ -74,7 +74,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VECTOR_PEAK_TF = 78.6   # MI355X vector FP64: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
-ROOFLINE_JSON = os.path.join(ROOT, "profiles", "r04_roofline_bench.json")
+ROOFLINE_JSON = os.path.join(ROOT, "profiles", "r05_roofline_bench.json")
 SWEEP_BATCHES = (32768, 8192)   # reference batches reported next to the headline (round 1's bench batch; SURVEY.md 8(d)'s metric batch)
 
 

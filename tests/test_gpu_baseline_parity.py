@@ -136,7 +136,7 @@ def first_divergence(tg, to):
     # ... and the reference's real call pattern: cold start u0 = 0 (src/interface_mpc.py:82) with the yaml's caps.  The Lipschitz
     # estimate then perturbs by h = 1e-12, so L -- and with it gamma and every scalar after it -- is rounding-noise limited
     # (~1e-4 relative) in ANY float64 implementation: the scalars part at once (no early_tol / min_sd), the DISCRETE decisions
-    # still coincide for a median of 20 steps (measured; profiles/r03_parity_report.txt)
+    # still coincide for a median of 20 steps (measured; profiles/archive/r03_parity_report.txt)
     (20, "last_trial", 500, 10, 12, 0, None, "throughput", True),
     (20, "last_trial", 40, 6, 12, 0, None, "latency", True)])
 def test_decision_trace_matches_oracle(N, fallback, max_inner, max_outer, min_fd, min_sd, early_tol, kernel, cold):

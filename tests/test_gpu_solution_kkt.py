@@ -3,7 +3,7 @@ the reference's constrained problem (tests/support/kkt.py): feasible to delta, s
 hard constraints, started at u*) neither moves the point by more than 1e-3 nor lowers f by more than 1e-6 relative, and the
 projected-gradient residual of the Lagrangian at (u*, y*) is below 1e-3.  This is evidence about the SOLUTIONS that does not
 pass through the builder's PANOC / ALM restatement: the only things shared with the solver are the problem functions, which
-the fixtures generated from the reference's own CasADi graph pin bit for bit.  Histograms: profiles/r03_kkt_report.txt
+the fixtures generated from the reference's own CasADi graph pin bit for bit.  Histograms: profiles/archive/r03_kkt_report.txt
 (tests/tools/kkt_report.py, cap-limited solves included -- reported, not asserted)."""
 import os
 import sys

@@ -10,8 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tools import roofline  # noqa: E402
 
-RAW = os.path.join(ROOT, "profiles", "raw_r03")
-COMMITTED = os.path.join(ROOT, "profiles", "r03_roofline_bench.json")
+RAW = os.path.join(ROOT, "profiles", "raw_r05")
+COMMITTED = os.path.join(ROOT, "profiles", "r05_roofline_bench.json")
 
 
 def test_committed_roofline_json_is_reproduced_from_the_raw_csvs(tmp_path):
@@ -43,3 +43,17 @@ def test_in_run_form_without_a_kernel_trace_pass(tmp_path):
     assert abs(d["kernel_avg_ms_kernel_trace"] / c["kernel_avg_ms_kernel_trace"] - 1.0) < 0.05
     assert roofline.load_pmc_for(str(tmp_path / "out.json"), 20, 8, c["workload"]["batch_per_gpu"]) is not None
     assert roofline.load_pmc_for(str(tmp_path / "out.json"), 40, 8, c["workload"]["batch_per_gpu"]) is None
+
+
+def test_the_tail_kernel_is_kept_apart_from_the_dominant_kernel():
+    """Since round 5 a launch is two kernels -- solve_kernel_pair and the continuation solve_kernel_team: the roofline figures
+    are those of the pair kernel alone, the continuation's average duration is reported next to them."""
+    with open(COMMITTED) as fh:
+        c = json.load(fh)
+    assert c["tail_kernel_calls"] == c["kernel_calls_kernel_trace"] and 0.0 < c["tail_kernel_avg_ms"] < 0.05 * c["kernel_avg_ms_kernel_trace"]
+    with open(os.path.join(ROOT, "profiles", "r05_bench_line.json")) as fh:
+        line = json.load(fh)
+    ro = line["roofline"]
+    assert ro["kernel"] == "solve_kernel_pair" and abs(ro["kernel_ms"] / c["kernel_avg_ms_kernel_trace"] - 1.0) < 0.01      # HIP events vs kernel trace
+    assert abs(ro["achieved"] - 21944 * 131072 / (ro["kernel_ms"] * 1e-3) / 1e9) < 1e-9
+    assert ro["kernel_ms"] + ro["tail_kernel_ms"] <= line["ms_per_step"] * 1.001

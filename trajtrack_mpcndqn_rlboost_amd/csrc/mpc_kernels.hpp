@@ -87,7 +87,7 @@ constexpr int MAX_MEM = 16;
 // Reference segments per item lane that are evaluated unconditionally before the suffix-circle test takes over.  Rounds 1-3: 2
 // (the 6 nearest segments of a step at N_hor = 20; the pruned loop then ran in 0.1 % of the evaluations).  1 = the 3 nearest:
 // the pruned loop runs in 2.2 % of the evaluations and one unconditional trip per evaluation is gone: -3.0 % kernel time at
-// N_hor = 20, -1.6 % at N_hor = 40, same bits (the same segments win in the same order; profiles/r03_step_loop_ab.txt).
+// N_hor = 20, -1.6 % at N_hor = 40, same bits (the same segments win in the same order; profiles/archive/r03_step_loop_ab.txt).
 constexpr int SEG_WIN = 1;
 
 // header slots (doubles); 0..17 are p[0..17] of the reference layout
@@ -1557,7 +1557,7 @@ enum { ST_INIT0 = 0, ST_INIT1, ST_LIP, ST_NOLS, ST_LS, ST_OUTER };
 // (v_mov_b64), four went through scratch (store at the latch, reload at the use -- the ~3 TB of write traffic per launch the
 // rocprof passes of rounds 1-3 showed) and 18 SGPR state words were copied.  In the step loop the line search carries (tau, the
 // trial point) and nothing else; u, gamma fpr, the direction and the step's scalars are loop-invariant around it.  Measured
-// (profiles/r03_step_loop_ab.txt): 1018 -> 896 ms at B = 32 768 (-12 %), 322 -> 281 ms at B = 8192, code 27 -> 44 KB.
+// (profiles/archive/r03_step_loop_ab.txt): 1018 -> 896 ms at B = 32 768 (-12 %), 322 -> 281 ms at B = 8192, code 27 -> 44 KB.
 #ifndef MPC_STEP_LOOP
 #define MPC_STEP_LOOP 1
 #endif
@@ -2052,7 +2052,7 @@ struct PanocLbfgsGram {
     }
 };
 
-// Where the Gram form is used.  N_hor = 20: -7 % against the two-loop recursion (profiles/r03_lbfgs_gram_ab.txt).  N_hor = 40: the
+// Where the Gram form is used.  N_hor = 20: -7 % against the two-loop recursion (profiles/archive/r03_lbfgs_gram_ab.txt).  N_hor = 40: the
 // first measurement said +7 % -- the 1.2 KB of Gram matrices had cost a resident wavefront per CU (LDS comes in 1280-byte granules);
 // at EQUAL residency it is 4 % faster there too, and with the stash-free carve (stash_stride_c: 12 368 B = 12 per CU) the kernel
 // went from 954 to 913 ms at B = 16 384.  One lane group does all 2 mem rows in pass 2 there (64 / N = 1).  The runtime-horizon

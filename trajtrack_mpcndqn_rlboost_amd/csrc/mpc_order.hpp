@@ -2,7 +2,7 @@
 //
 // One wavefront solves one problem from start to end and the hardware hands out workgroups in index order.  Solves differ in
 // length (10^1 .. 10^4 PANOC steps); whatever is long and starts LAST finishes on a draining GPU -- at 8192 problems per launch
-// a quarter of the kernel time (profiles/r03_order_ab.txt).  In a receding-horizon loop problem i of this call is robot i one
+// a quarter of the kernel time (profiles/archive/r03_order_ab.txt).  In a receding-horizon loop problem i of this call is robot i one
 // tick later: how long it took LAST time is a good guess of how long it takes now.  The library keeps the psi-evaluation counts
 // of its previous call anyway (mpcgpu_last_eval_counts); three small kernels turn them into a permutation, longest first
 // (counting sort on 1024 coarse bins: the order inside a bin is whatever the atomics give, which changes nothing -- every
