@@ -150,6 +150,9 @@ constexpr bool LBFGS_IN_WORKSPACE = MPC_LBFGS_IN_WORKSPACE != 0;
 #ifndef MPC_TRY_FOUR_WAVES
 #define MPC_TRY_FOUR_WAVES 1
 #endif
+#ifndef MPC_FOUR_WAVES_FROM
+#define MPC_FOUR_WAVES_FROM (4 * MPC_MIN_WAVES)   // problems per compute unit from which the 128-VGPR build is taken (more than the other build holds at once)
+#endif
 
 void fill_static_params(Handle* h) {
     const mpcgpu_config& c = h->cfg;
@@ -556,7 +559,7 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
     } while (0)
 #define LAUNCH_PAIR(NT, SC) LAUNCH_PAIR_W(NT, SC, MPC_MIN_WAVES)
     const bool sc = h->shape_const;
-    const bool four = MPC_TRY_FOUR_WAVES && lds <= 10 * 1024 && B > 4 * MPC_MIN_WAVES * h->num_cus;
+    const bool four = MPC_TRY_FOUR_WAVES && lds <= 10 * 1024 && B > MPC_FOUR_WAVES_FROM * h->num_cus;
     h->last_min_waves = (four && compiled_horizon(h) == 20) || lin40 ? 4 : MPC_MIN_WAVES;
     // MPCGPU_OPT_ORDER (mpc_order.hpp): longest first by the evaluation counts the previous call of this batch size left in
     // `evals` -- only when the batch is larger than what is resident at once (else everything starts together anyway).  The three
