@@ -854,6 +854,10 @@ __device__ __forceinline__ void set_balanced_trips(Ctx& cx, int N, int lanes) {
     cx.balT = T; cx.balT2 = t2;
 }
 constexpr int KC_BASE = 32;
+constexpr int HD_AKKT = 59;   // LDS header only (slots 59..63 are free behind the literal table): the inner tolerance eps_nu of the running
+                              // inner problem.  It changes ten times per solve and is read once per PANOC step, next to a square root on
+                              // the decision path: as a solver variable the 128-VGPR build kept it in a VGPR, spilled it and reloaded
+                              // it from scratch in every step (512 B per step and wavefront through an L2 the L-BFGS rings overflow).
 #define KC(i) (cx.hd[KC_BASE + (i)])
 #define HD(i) (cx.hd[(i)])
 
@@ -1636,6 +1640,11 @@ __device__ __forceinline__ void panoc_lip_update(const KParams& kp, bool vl, dou
     nfpr = P::uni(sqrt(rr));
     ip = dot2r<P, P::RV>(gv, gw, rv, rw);
 }
+// the inner tolerance of the running inner problem, where panoc_step_residual reads it (HD_AKKT)
+__device__ __forceinline__ void set_inner_tolerance(const Ctx& cx, int lane, double akkt_tol) {
+    if (lane == 0) const_cast<double*>(cx.hd)[HD_AKKT] = akkt_tol;
+    wave_sync();
+}
 // gamma*fpr of the step, its norm, <grad, gamma fpr>; true when the inner problem is solved: ||gamma fpr|| < eps and the
 // AKKT residual || gfpr/gamma + grad - grad_prev || < eps_nu (grad_prev is the zero vector on the first step of an inner
 // problem and the current gradient afterwards)
@@ -1650,7 +1659,7 @@ __device__ __forceinline__ bool panoc_step_residual(const Ctx& cx, const KParams
     bool ex = nfpr < kp.tol;
     if (ex) {
         const double a0 = rv / gamma + (iter == 0 ? gv : 0.0), a1 = rw / gamma + (iter == 0 ? gw : 0.0);
-        ex = sqrt(dot2r<P, P::RV>(a0, a1, a0, a1)) < akkt_tol;
+        ex = sqrt(dot2r<P, P::RV>(a0, a1, a0, a1)) < cx.hd[HD_AKKT];   // == akkt_tol (set_inner_tolerance)
     }
     return ex;
 }
@@ -1933,7 +1942,7 @@ struct PanocLbfgsGram {
                 }
             }
             wave_sync();
-            if (lane < mem) m.GG[h * mem + lane] = 0.0;
+            if (lane < mem) m.GG[h * mem + lane] = zero_here();   // (a hoisted 0.0 sat in a spill slot and came back from scratch in every step)
             if (lane == 0) {
                 m.GG[mem * mem + yy_index(h, h)] = yy;
                 m.LRHO[h] = 1.0 / ys;
@@ -2219,6 +2228,7 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
     double gamma = 0, ig = 0, Lip = 0, sigma = 0, cost = 0, nfpr = 0, tau = 1, rhs = 0, nh = 1, gg = 0, d2h = 0;
     double ip = 0.0;  // <grad, gamma*fpr> of the current step (Lipschitz test)
     double akkt_tol = kp.init_tol;
+    set_inner_tolerance(cx, lane, akkt_tol);
     int iter = 0, num_iter = 0, lip_it = 0, nls = 0;
     bool cont_iters = true, cont_time = true;
     typename LbfgsOf<P::DUO, NT>::type lb;
@@ -2378,6 +2388,7 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
                 c = P::uni(c * kp.penalty_update); icm = P::uni(1.0 / fmax(c, 1.0));
             }
             akkt_tol = P::uni(fmax(akkt_tol * kp.tol_update, kp.tol));
+            set_inner_tolerance(cx, lane, akkt_tol);
             ++alm_iteration; ++num_outer;
             dy_norm = dy_norm_plus; f2_norm = f2_norm_plus;
             ya = clampd(ypa, -KC(K_YBOUND), KC(K_YBOUND)); yb = clampd(ypb, -KC(K_YBOUND), KC(K_YBOUND));  // y <- Proj_Y(y+)

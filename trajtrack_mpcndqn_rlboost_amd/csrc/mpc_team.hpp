@@ -219,6 +219,7 @@ __global__ __launch_bounds__(WAVE * TW) void solve_kernel_team(KParams kp, Batch
 #endif
         wave_sync();
     }
+    set_inner_tolerance(cx, lane, akkt_tol);
     double ev = uv, ew = uw;
     bool want_grad = true;
     EvalOut o;
@@ -428,6 +429,7 @@ __global__ __launch_bounds__(WAVE * TW) void solve_kernel_team(KParams kp, Batch
                 c = uniform(c * kp.penalty_update); icm = uniform(1.0 / fmax(c, 1.0));
             }
             akkt_tol = uniform(fmax(akkt_tol * kp.tol_update, kp.tol));
+            set_inner_tolerance(cx, lane, akkt_tol);   // (every replica writes the same bits into the shared header)
             ++alm_iteration; ++num_outer;
             dy_norm = dy_norm_plus; f2_norm = f2_norm_plus;
             ya = clampd(ypa, -KC(K_YBOUND), KC(K_YBOUND)); yb = clampd(ypb, -KC(K_YBOUND), KC(K_YBOUND));
