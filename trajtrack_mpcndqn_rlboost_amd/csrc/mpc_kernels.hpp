@@ -831,6 +831,7 @@ struct Ctx {
     // literals are kept in LDS and read where they are used: as SGPR residents they overflowed the scalar file and
     // every spilled access became a v_readlane on the (saturated) VALU.
     const double* hd;   // [64]: header slots H_*, then KTAB at KC_BASE
+    double* akkt;       // one double of LDS owned by this wavefront: the inner tolerance of the running inner problem (HD_AKKT)
     bool pad_f, pad_d, terminal;  // any zero-padded other-robot / dynamic rows; non-zero terminal weights
     int Ks, Kf, Kd;
     // lane roles
@@ -854,7 +855,7 @@ __device__ __forceinline__ void set_balanced_trips(Ctx& cx, int N, int lanes) {
     cx.balT = T; cx.balT2 = t2;
 }
 constexpr int KC_BASE = 32;
-constexpr int HD_AKKT = 59;   // LDS header only (slots 59..63 are free behind the literal table): the inner tolerance eps_nu of the running
+constexpr int HD_AKKT = 59;   // LDS header (slots 59..63 are free behind the literal table; the latency kernel uses a slot per wavefront): the inner tolerance eps_nu of the running
                               // inner problem.  It changes ten times per solve and is read once per PANOC step, next to a square root on
                               // the decision path: as a solver variable the 128-VGPR build kept it in a VGPR, spilled it and reloaded
                               // it from scratch in every step (512 B per step and wavefront through an L2 the L-BFGS rings overflow).
@@ -887,6 +888,7 @@ __device__ __forceinline__ void load_problem(const KParams& kp, const double* __
     if (lane < KC_BASE) hd[lane] = ws[lane];
     if (lane < 27) hd[KC_BASE + lane] = KTAB[lane];
     cx.hd = hd;
+    cx.akkt = hd + HD_AKKT;
     auto U = [&](int i) { return P::uni(ws[i]); };
     cx.Ks = (int)U(H_KS); cx.Kf = (int)U(H_KF); cx.Kd = (int)U(H_KD);
     cx.pad_f = U(H_NPF) > 0.0; cx.pad_d = U(H_NPD) > 0.0;
@@ -1642,7 +1644,7 @@ __device__ __forceinline__ void panoc_lip_update(const KParams& kp, bool vl, dou
 }
 // the inner tolerance of the running inner problem, where panoc_step_residual reads it (HD_AKKT)
 __device__ __forceinline__ void set_inner_tolerance(const Ctx& cx, int lane, double akkt_tol) {
-    if (lane == 0) const_cast<double*>(cx.hd)[HD_AKKT] = akkt_tol;
+    if (lane == 0) *cx.akkt = akkt_tol;
     wave_sync();
 }
 // gamma*fpr of the step, its norm, <grad, gamma fpr>; true when the inner problem is solved: ||gamma fpr|| < eps and the
@@ -1659,7 +1661,7 @@ __device__ __forceinline__ bool panoc_step_residual(const Ctx& cx, const KParams
     bool ex = nfpr < kp.tol;
     if (ex) {
         const double a0 = rv / gamma + (iter == 0 ? gv : 0.0), a1 = rw / gamma + (iter == 0 ? gw : 0.0);
-        ex = sqrt(dot2r<P, P::RV>(a0, a1, a0, a1)) < cx.hd[HD_AKKT];   // == akkt_tol (set_inner_tolerance)
+        ex = sqrt(dot2r<P, P::RV>(a0, a1, a0, a1)) < *cx.akkt;   // == akkt_tol (set_inner_tolerance)
     }
     return ex;
 }

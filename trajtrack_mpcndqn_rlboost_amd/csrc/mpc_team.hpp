@@ -97,6 +97,7 @@ __global__ __launch_bounds__(WAVE * TW) void solve_kernel_team(KParams kp, Batch
         if (threadIdx.x < KC_BASE) hd[threadIdx.x] = ws[threadIdx.x];
         if (threadIdx.x >= WAVE && threadIdx.x < WAVE + 27) hd[KC_BASE + threadIdx.x - WAVE] = KTAB[threadIdx.x - WAVE];
         cx.hd = hd;
+        cx.akkt = lds + kp.l_xch + wid * TEAM_XCH + 2;   // this wavefront's own slot of the exchange area ([0], [1]: verdict banks, [7]: clock)
         auto U = [&](int i) { return uniform(ws[i]); };
         cx.Ks = (int)U(H_KS); cx.Kf = (int)U(H_KF); cx.Kd = (int)U(H_KD);
         cx.pad_f = U(H_NPF) > 0.0; cx.pad_d = U(H_NPD) > 0.0;
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(WAVE * TW) void solve_kernel_team(KParams kp, Batch
                 c = uniform(c * kp.penalty_update); icm = uniform(1.0 / fmax(c, 1.0));
             }
             akkt_tol = uniform(fmax(akkt_tol * kp.tol_update, kp.tol));
-            set_inner_tolerance(cx, lane, akkt_tol);   // (every replica writes the same bits into the shared header)
+            set_inner_tolerance(cx, lane, akkt_tol);
             ++alm_iteration; ++num_outer;
             dy_norm = dy_norm_plus; f2_norm = f2_norm_plus;
             ya = clampd(ypa, -KC(K_YBOUND), KC(K_YBOUND)); yb = clampd(ypb, -KC(K_YBOUND), KC(K_YBOUND));
