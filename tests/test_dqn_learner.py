@@ -180,38 +180,17 @@ def test_two_graph_update_with_the_rccl_all_reduce_on_the_gpu():
     the flat 1 177-float all-reduce on RCCL (backend "nccl"), graph B (average, clip, Adam) -- executed on the GPU.  With one
     device visible the process group has a single rank (the collective still goes through RCCL on the device); the result
     must equal the plain eager update.  Two or more devices: see test_two_rank_training_on_two_gpus."""
-    import torch.distributed as dist
-    dev = "cuda:0"
-    torch.cuda.set_device(0)
-    import socket
-    with socket.socket() as sk:                                   # a free port for the one-rank rendezvous
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    created = not dist.is_initialized()
-    if created:
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(dev))
-    try:
-        def batch(seed, n=32):
-            g = torch.Generator().manual_seed(seed)
-            return {k: v.to(dev) for k, v in dict(obs=torch.rand(n, 46, generator=g) * 2 - 1, actions=torch.randint(0, 9, (n,), generator=g),
-                                                   rewards=torch.randn(n, generator=g), next_obs=torch.rand(n, 46, generator=g) * 2 - 1,
-                                                   dones=(torch.rand(n, generator=g) < 0.1).float()).items()}
-        outs = []
-        for collective in (False, True):
-            torch.manual_seed(0)
-            tr = dqn_train.DqnTrainer(device=dev, target_update_interval=3, force_collective=collective)
-            if collective:
-                tr.enable_graph(32)
-                assert hasattr(tr, "_graph_b")                       # the two-graph structure was captured
-            losses = [float((tr.update_graphed if collective else tr.update)(batch(20 + i))) for i in range(8)]
-            outs.append((torch.cat([p.detach().reshape(-1) for p in tr.q_net.parameters()]).cpu(), losses))
-        assert np.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-7)
-        assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-5, atol=1e-7)
-    finally:
-        if created:
-            dist.destroy_process_group()
+    import subprocess
+    script = os.path.join(ROOT, "tests", "support", "rccl_one_rank_update.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    # A process of its own: a failure of RCCL / HSA at process-group start aborts the interpreter (seen once on a pool box), and that
+    # must cost this test, not the pytest session.  One retry for exactly that case (killed by a signal); a wrong result is rc 1.
+    for attempt in range(2):
+        r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=600, env=env)
+        if r.returncode >= 0:
+            break
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+    assert "two-graph update == eager update" in r.stdout
 
 
 @pytest.mark.gpu
