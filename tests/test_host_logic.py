@@ -159,3 +159,27 @@ def test_no_product_module_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "mpc_oracle" not in src, f
+
+
+def test_realtime_capacity_search_is_a_bisection_over_fleet_sizes(monkeypatch):
+    """tools/closed_loop.realtime_capacity (bench.py: config.closed_loop.realtime_robots_per_gpu): the largest multiple of `step`
+    robots whose WORST tick stays within the limit -- with the device loop replaced by a model T(B) = 80 ms + B / 41.5 per ms."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from tools import closed_loop
+    calls = []
+
+    def fake(cfg, B, ticks, warmup, n_dyn, warm, order, device=0, **kw):
+        calls.append(B)
+        worst = 80.0 + B / 41.5
+        return {"ms_per_tick_min_max": [10.0, worst], "ms_per_tick": 0.6 * worst, "ms_of_every_tick": [worst] * ticks, "converged_fraction": 0.4}
+    monkeypatch.setattr(closed_loop, "device_closed_loop", fake)
+
+    class Cfg:
+        ts = 0.2
+    r = closed_loop.realtime_capacity(Cfg(), lo=2048, hi=8192, step=512)
+    assert r["limit_ms"] == 200.0 and r["robots"] == 4608            # 80 + 4608 / 41.5 = 191 ms; 5120 -> 203 ms
+    assert r["robots"] % 512 == 0 and len(calls) <= 6 and calls[0] == 2048 and calls[1] == 8192
+    assert set(r["tried"]) == {str(b) for b in calls} and len(r["ms_of_every_tick"]) == 30
+    assert closed_loop.realtime_capacity(Cfg(), lo=2048, hi=4096, step=512)["robots"] == 4096      # the whole range fits
+    assert closed_loop.realtime_capacity(Cfg(), lo=6144, hi=8192, step=512)["robots"] == 0         # nothing fits
