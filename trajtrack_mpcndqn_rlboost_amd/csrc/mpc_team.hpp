@@ -447,7 +447,9 @@ __global__ __launch_bounds__(WAVE * TW) void solve_kernel_team(KParams kp, Batch
                 if (cont_iters && cont_time) {
                     ++num_iter;
                     cont_iters = num_iter < kp.max_inner;
-                    if (kp.max_ticks > 0) cont_time = time_left();
+                    // the wall clock is looked at every 16th step (a barrier per look: wavefront 0 decides for all); the throughput
+                    // kernel looks every step -- a time-out is not reproducible to the step in either
+                    if (kp.max_ticks > 0 && (num_iter & 15) == 0) cont_time = time_left();
                 } else {
                     inner_done = true;
                 }
