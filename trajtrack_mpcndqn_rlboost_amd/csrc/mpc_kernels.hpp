@@ -101,7 +101,7 @@ enum { CNT_KS = 0, CNT_KF = 1, CNT_KD = 2, CNT_VARSHAPE = 3, CNT_ROTATED = 4 /* 
        CNT_NONLINEAR = 5 /* some active dynamic row is not a straight-line prediction */,
        CNT_NL_COUNT = 6 /* length of the list of such problems (nl_list_kernel) */,
        CNT_FINISHED = 8 /* problems of the running throughput launch that have written their results (tail promotion, see YIELD) */,
-       CNT_YIELDED = 9 /* length of the list of problems that left the throughput launch at a step boundary */, CNT_WORDS = 12 };
+       CNT_YIELDED = 9 /* length of the list of problems that left the throughput launch for the latency kernel */, CNT_WORDS = 12 };
 
 struct KParams {
     int N, Nother, Nstcobs, Ndynobs, np, mem;
@@ -121,9 +121,9 @@ struct KParams {
     int reserved;  // 1: the carve comes from mpcgpu_reserve_shape, problems are checked against it on the device
     int l_seg, l_stc, l_fxy, l_dyn, l_dync, l_dynl, l_qd, l_pos, l_H, l_W, l_part, l_bal, l_stash, l_hd, l_S, l_Y, l_rho, l_alpha, l_old, l_gg, l_total;
     int l_wstride, l_xch;  // team kernel (mpc_team.hpp): doubles per wavefront work block, offset of the exchange area
-    // tail promotion (YIELD below): a problem of the throughput launch leaves at a PANOC step boundary once `yield_from` problems
-    // of the launch have finished; 0 = off.  yield_cap: capacity of the list, yield_mask: the counter is polled when
-    // (step & yield_mask) == 0, ws_yield: offset of the saved iteration state in the workspace record.
+    // tail promotion (YIELD below): a problem of the throughput launch leaves at the start of an inner problem once `yield_from`
+    // problems of the launch have finished; 0 = off.  yield_cap: capacity of the list, ws_yield: offset of the saved iteration state in
+    // the workspace record; yield_mask (builds with -DMPC_YIELD_STEP=1 only): the counter is also polled when (step & yield_mask) == 0.
     int yield_from, yield_cap, yield_mask, ws_yield;
 };
 
@@ -132,13 +132,13 @@ struct KParams {
 // draining GPU: 0.07-0.08 s per launch whatever the batch (a quarter of a launch of 8192 problems).  The latency kernel
 // (mpc_team.hpp) runs the SAME iteration 2.3 x faster per problem -- when the GPU is empty.  So: every problem of the throughput
 // launch counts itself as finished (CNT_FINISHED); once all but `yield_cap` problems of the launch have finished, a wavefront that
-// reaches a PANOC step boundary writes the state of its iteration into its workspace record (the L-BFGS ring, the previous
-// iterate and the multipliers live there already), appends its problem to a list and leaves; a continuation launch of the latency
-// kernel on the same stream (solve_kernel_team with io.ylist set, grid = yield_cap, workgroups beyond the device-side list length leave
-// at once) picks the iteration up at that boundary.  Both kernels run the same step functions on the same state: every output is
+// reaches the START OF AN INNER PROBLEM writes the state of its outer loop -- point, multipliers, penalty, tolerance, counters, the
+// position of the L-BFGS ring: the PANOC cache and the buffer are empty there -- into its workspace record, appends its problem to a
+// list and leaves; a continuation launch of the latency kernel on the same stream (solve_kernel_team with io.ylist set, grid =
+// yield_cap, workgroups beyond the device-side list length leave at once) starts that inner problem.  Both kernels run the same step functions on the same state: every output is
 // BITWISE what the throughput kernel alone would have written (tests/test_gpu_yield.py).  Nothing is read back; capturable.
 // Record at ws_yield (doubles): YS_* scalars, then [N][8] = (u, grad, half step, multipliers) of every step, then the L-BFGS
-// scalars that live in LDS (rho, Gram matrices).
+// scalars that live in LDS (rho, Gram matrices) -- gradient, half step and the L-BFGS part are written by MPC_YIELD_STEP builds only.
 // ------------------------------------------------------------------------------------------------
 // Where a problem may leave.  0 (product): at the start of an inner problem only -- the state machine of solve_body, ten times per
 // solve; the loop of the PANOC steps is untouched (a running problem takes up to one inner problem, <= max_inner steps, to get
@@ -274,7 +274,7 @@ struct BatchPtrs {
     const int32_t* perm;  // throughput kernel: workgroup g solves problem perm[g] (NULL: problem g) -- MPCGPU_OPT_ORDER, mpc_order.hpp
     const int* nsel;      // != NULL: only the first *nsel entries of `perm` are problems of this launch (device-side count: the
                           // launch that picks up the problems a linear-table launch left out)
-    int32_t* ylist;       // tail promotion: problems that left the throughput launch at a step boundary (length: counts[CNT_YIELDED])
+    int32_t* ylist;       // tail promotion: problems that left the throughput launch for the latency kernel (length: counts[CNT_YIELDED])
     double* trace;   // -DMPC_TRACE builds only: [B][trace_cap][TRACE_W] decision trace, one record per PANOC step
     int trace_cap;
 };

@@ -56,9 +56,9 @@ struct Handle {
     int last_team = 0;        // wavefronts per problem of the latency kernel the last solve ran (4 or 2); 0: throughput kernel
     int pairing = -1;   // MPCGPU_OPT_PAIRING: -1 automatic, 0 one problem per wavefront, 1 two per wavefront (N_hor = 20)
     int last_pairing = 0;  // layout of the last solve / cost_grad launch
-    int yield_opt = -1;  // MPCGPU_OPT_TAIL_PROMOTION: -1 automatic (the last 2 x #CUs problems of a throughput launch), 0 off, > 0 that many
-    int yield_poll = 16; // ... the finished-counter is polled every this many PANOC steps (power of two)
-    int yield_waves = 0; // MPCGPU_OPT_TAIL_WAVES: wavefronts per promoted problem (0: four up to 2 problems per compute unit, else two)
+    int yield_opt = -1;  // MPCGPU_OPT_TAIL_PROMOTION: -1 automatic (twice the resident four-wavefront teams), 0 off, > 0 that many problems
+    int yield_poll = 16; // ... builds with -DMPC_YIELD_STEP=1 only: the finished-counter is also polled every this many PANOC steps (power of two)
+    int yield_waves = 0; // MPCGPU_OPT_TAIL_WAVES: wavefronts per promoted problem (0: four; two for an explicit capacity beyond four times the residency)
     int last_yield_cap = 0;  // capacity of the continuation launch of the last solve (0: none was enqueued)
     int trace_cap = 0;  // -DMPC_TRACE builds: PANOC steps recorded per problem (0 = tracing off)
     // mpcgpu_reserve_shape: upper bounds of active rows promised by the caller -> no count read-back before the launch
@@ -588,8 +588,8 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
     }
     h->evals_B = B;
     // Tail promotion (mpc_kernels.hpp YIELD): once all but K problems of this launch have finished, the wavefronts that are still
-    // running leave at their next PANOC step boundary and a continuation launch of the latency kernel (four wavefronts per problem,
-    // K <= 2 per compute unit; two wavefronts up to 4 per compute unit) finishes them -- bitwise the same results.
+    // running leave at the start of their next inner problem and a continuation launch of the latency kernel (four wavefronts per
+    // problem) finishes them -- bitwise the same results.
     int yield_K = 0, yield_tw = 0;
     KParams kt_y{};
     size_t lds_y = 0;
@@ -598,7 +598,7 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
     // the two add up (8192 robots, cold: 168 ms per tick plain, 159 promoted, 160 ordered, 152 both: profiles/r05_closed_loop_ab.txt).
     if (MPC_STEP_LOOP && h->yield_opt != 0 && !h->last_pairing && !lin40) {
         // How many problems of the latency kernel a compute unit holds: 8 wavefronts of that kernel by registers, and the LDS carve
-        // (tables for this batch's maxima).  Automatic rule: four wavefronts per problem, K = what is resident at once.
+        // (tables for this batch's maxima).
         auto team_shape = [&](int tw, KParams& kt, size_t& lds_t) -> int {
             kt = h->kp;
             fill_team_layout(kt, tw, h->kp.mKs, h->kp.mKf, h->kp.mKd);
