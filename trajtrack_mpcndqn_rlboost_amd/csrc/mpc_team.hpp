@@ -43,8 +43,18 @@ enum { TS_INIT0 = 0, TS_INIT1, TS_FIRST, TS_SPEC, TS_LIPSEQ, TS_BATCH, TS_FALLBA
 // the workspace record at the start of an inner problem -- point, multipliers, penalty, tolerance, the outer loop's scalars and
 // counters, the ring position -- into every replica and starts that inner problem.  Same step functions, same state: bitwise
 // what the throughput kernel would have gone on to write.
+// Wavefronts per SIMD the latency kernel is compiled for: 2 = as many registers as it likes (192 / 210 VGPRs, no scratch), 3 = 168
+// VGPRs (a few values of the outer loop in scratch) and three four-wavefront teams per compute unit instead of two.
+#ifndef MPC_TEAM_WPE
+#define MPC_TEAM_WPE 2
+#endif
+#if MPC_TEAM_WPE == 2
+#define MPC_TEAM_ATTR
+#else
+#define MPC_TEAM_ATTR __attribute__((amdgpu_waves_per_eu(MPC_TEAM_WPE, MPC_TEAM_WPE)))
+#endif
 template <int NT, int TW>
-__global__ __launch_bounds__(WAVE * TW) void solve_kernel_team(KParams kp, BatchPtrs io, int B) {
+__global__ __launch_bounds__(WAVE * TW) MPC_TEAM_ATTR void solve_kernel_team(KParams kp, BatchPtrs io, int B) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     using P = Solo<NT>;
     constexpr bool SC = false;  // general tables: no batch-wide shape information is needed before the launch

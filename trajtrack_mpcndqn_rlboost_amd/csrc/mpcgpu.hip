@@ -501,7 +501,7 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
         fill_team_layout(kt, tw, h->kp.mKs, h->kp.mKf, h->kp.mKd);
         kt.reserved = 1;                       // every problem is checked against the tables' size on the device
         const size_t lds_t = kt.l_total * sizeof(double);
-        const int per_cu = tw == 2 ? 4 : 2;    // 256 VGPRs per wavefront: eight wavefronts per compute unit
+        const int per_cu = 4 * MPC_TEAM_WPE / tw;   // 256 VGPRs per wavefront: eight wavefronts per compute unit
         if ((lds_t + PREP_STATIC_LDS) * per_cu <= 160 * 1024) {
             io.p = nullptr;                    // the records exist already
             if (!h->capturing) HIP_OK(h, hipEventRecord(h->ev[2], s));
@@ -604,7 +604,7 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
             fill_team_layout(kt, tw, h->kp.mKs, h->kp.mKf, h->kp.mKd);
             kt.reserved = 1;
             lds_t = kt.l_total * sizeof(double);
-            const int by_lds = (int)((160 * 1024) / (lds_t + PREP_STATIC_LDS)), by_regs = 8 / tw;
+            const int by_lds = (int)((160 * 1024) / (lds_t + PREP_STATIC_LDS)), by_regs = 4 * MPC_TEAM_WPE / tw;
             return by_lds < by_regs ? by_lds : by_regs;
         };
         int tw = h->yield_waves ? h->yield_waves : TEAM_WAVES;
