@@ -2260,7 +2260,7 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
 #endif
     // tail promotion (see YIELD at KParams): this problem leaves at a step boundary once the launch is draining
     constexpr bool CAN_YIELD = MPC_STEP_LOOP && !P::DUO && !LIN;
-    bool yielded = false, count_step = false;
+    [[maybe_unused]] bool yielded = false, count_step = false;
     int yslot = 0;
 
     for (;;) {
