@@ -216,9 +216,15 @@ int32_t mpcgpu_reserve_batch(void* handle, int32_t B);
  *   MPCGPU_OPT_TAIL_POLL  (ABI 7) PANOC steps between two looks at the launch's finished-counter (a power of two, default 16;
  *       only the A/B build -DMPC_YIELD_STEP=1 looks inside an inner problem at all).
  *   MPCGPU_OPT_TAIL_WAVES  (ABI 7) wavefronts per promoted problem: 0 (default) by K as above, 2 or 4.
+ *   MPCGPU_OPT_TAIL_CONCURRENT  (ABI 7) 1: the continuation does not wait for the throughput launch to end -- it runs on a stream of
+ *       the handle's own while that launch drains (behind a gate that opens with the first promotion; its workgroups take the
+ *       promoted problems one after the other as they appear), and the launch stream waits for it at the end of the call.  Same
+ *       results, bit for bit.  0: the continuation is the launch behind the throughput kernel (always so while the call is being
+ *       captured into a hipGraph).
  */
 enum { MPCGPU_OPT_LINESEARCH_FALLBACK = 1, MPCGPU_OPT_PAIRING = 2, MPCGPU_OPT_TEAM_BATCH = 3, MPCGPU_OPT_ORDER = 4,
-       MPCGPU_OPT_LINEAR_TABLES = 5, MPCGPU_OPT_TAIL_PROMOTION = 6, MPCGPU_OPT_TAIL_POLL = 7, MPCGPU_OPT_TAIL_WAVES = 8 };
+       MPCGPU_OPT_LINEAR_TABLES = 5, MPCGPU_OPT_TAIL_PROMOTION = 6, MPCGPU_OPT_TAIL_POLL = 7, MPCGPU_OPT_TAIL_WAVES = 8,
+       MPCGPU_OPT_TAIL_CONCURRENT = 9 };
 int32_t mpcgpu_set_option(void* handle, int32_t option, double value);
 
 /* Register-allocation variant the last solve call was launched with: 3 (148 / 168 VGPRs) or 4 wavefronts per SIMD

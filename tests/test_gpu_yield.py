@@ -22,10 +22,12 @@ def _same(a, b):
         assert np.array_equal(x, y, equal_nan=True), (f, int(np.sum(x != y)))
 
 
-def _solve(cfg, p, K, poll=None, library=None, **kw):
+def _solve(cfg, p, K, poll=None, library=None, concurrent=None, **kw):
     bs = BatchSolver(cfg, latency_batch=0, order="as_given", tail_promotion=K, library=library)
     if poll is not None:
         bs.set_tail_promotion(K, poll)
+    if concurrent is not None:      # MPCGPU_OPT_TAIL_CONCURRENT: the continuation while the throughput launch drains / behind it
+        bs.set_tail_concurrent(concurrent)
     r = bs.solve(p, **kw)
     B = p.shape[0]
     ev = bs.last_eval_counts(B)
@@ -42,13 +44,16 @@ def test_promoted_problems_finish_bitwise_like_the_throughput_kernel(N, B, fam):
     r0, e0, cap0, moved0, t0 = _solve(cfg, sc["p"], 0)
     assert cap0 == 0 and moved0 == 0
     figures = [f"off {t0:.1f} ms"]
-    for K in (-1, 512, B):      # the library's rule; half of it; everything (after the first finisher; two wavefronts per problem)
-        r, e, cap, moved, t = _solve(cfg, sc["p"], K)
-        assert cap == ((1024 if N != 40 else 256) if K == -1 else K)    # automatic: twice what four-wavefront teams hold at once (N_hor = 40: one team per CU by its LDS carve)
+    # the library's rule; half of it; everything (after the first finisher; two wavefronts per problem) -- each with the
+    # continuation on its own stream while the launch drains (the default where it applies) and as the launch behind it
+    for K, conc in ((-1, True), (-1, False), (512, True), (512, False), (B, None)):
+        r, e, cap, moved, t = _solve(cfg, sc["p"], K, concurrent=conc)
+        # automatic: twice what four-wavefront teams hold at once (N_hor = 40: one team per CU by its LDS carve; once, when the continuation is the launch behind)
+        assert cap == ((1024 if N != 40 else 512 if conc else 256) if K == -1 else K)
         assert moved > 0, (K, moved)
         _same(r0, r)
         assert np.array_equal(e0[0], e[0]) and np.array_equal(e0[1], e[1])
-        figures.append(f"K={cap}: {moved} moved, {t:.1f} ms")
+        figures.append(f"K={cap}{'' if conc is None else ' concurrent' if conc else ' behind'}: {moved} moved, {t:.1f} ms")
     assert B // 20 < int(np.sum(r0.status == 0)) < B - B // 20       # the batch holds converging AND cap-limited solves
     print(f"\nN_hor {N}, B {B}, {fam}: " + "; ".join(figures))
 

@@ -101,7 +101,9 @@ enum { CNT_KS = 0, CNT_KF = 1, CNT_KD = 2, CNT_VARSHAPE = 3, CNT_ROTATED = 4 /* 
        CNT_NONLINEAR = 5 /* some active dynamic row is not a straight-line prediction */,
        CNT_NL_COUNT = 6 /* length of the list of such problems (nl_list_kernel) */,
        CNT_FINISHED = 8 /* problems of the running throughput launch that have written their results (tail promotion, see YIELD) */,
-       CNT_YIELDED = 9 /* length of the list of problems that left the throughput launch for the latency kernel */, CNT_WORDS = 12 };
+       CNT_YIELDED = 9 /* length of the list of problems that left the throughput launch for the latency kernel */,
+       CNT_LISTED = 10 /* entries of that list that are complete (record + list slot written): FINISHED + LISTED = every problem decided */,
+       CNT_WORDS = 12 };
 
 struct KParams {
     int N, Nother, Nstcobs, Ndynobs, np, mem;
@@ -125,6 +127,9 @@ struct KParams {
     // problems of the launch have finished; 0 = off.  yield_cap: capacity of the list, ws_yield: offset of the saved iteration state in
     // the workspace record; yield_mask (builds with -DMPC_YIELD_STEP=1 only): the counter is also polled when (step & yield_mask) == 0.
     int yield_from, yield_cap, yield_mask, ws_yield;
+    // concurrent continuation (mpc_team.hpp, CONCURRENT): 1 = the workgroups of the latency kernel wait for their list entries while
+    // the throughput launch is still running; yield_total = problems of that launch (the list is final once FINISHED + LISTED reach it)
+    int yield_persist, yield_total;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -2514,7 +2519,13 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
 #ifdef MPC_TRACE
                 yr[YS_TRN] = tr_n;
 #endif
-                io.ylist[yslot] = b;
+            }
+            // The record first, then the list entry: the continuation may run CONCURRENTLY (another stream, any XCD) and takes the
+            // entry as soon as it sees it.  One release fence per wavefront covers the stores of all its lanes.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            if (lane == 0) {
+                __hip_atomic_store(io.ylist + yslot, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(io.counts + CNT_LISTED, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             }
 #ifdef MPC_PROFILE
             prof.mark(22); prof.flush();
@@ -2538,7 +2549,7 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
 #ifdef MPC_TRACE
             yr[YS_TRN] = tr_n; yr[YS_TRPSI] = tr_psi_u;
 #endif
-            io.ylist[yslot] = b;
+            io.ylist[yslot] = b;   // (this build's continuation is the launch BEHIND the throughput kernel only)
         }
         {   // the L-BFGS scalars that live in LDS: rho and the Gram matrices (or nothing worth keeping, two-loop form)
             double* yl = yr + YS_SCALARS + N * YS_VECW;

@@ -53,6 +53,13 @@ enum { TS_INIT0 = 0, TS_INIT1, TS_FIRST, TS_SPEC, TS_LIPSEQ, TS_BATCH, TS_FALLBA
 #else
 #define MPC_TEAM_ATTR __attribute__((amdgpu_waves_per_eu(MPC_TEAM_WPE, MPC_TEAM_WPE)))
 #endif
+// CONCURRENT (round 5): with kp.yield_persist the kernel runs on a second stream WHILE the throughput launch drains (behind
+// tail_gate_kernel, which holds it back until the launch starts to promote).  Workgroup g waits for list entry g -- entries appear
+// in index order and workgroups are dispatched in index order, so the resident ones wait for the entries that come next -- or until
+// every problem of the throughput launch has finished or is listed (FINISHED + LISTED = yield_total: the list is final and entry g
+// is not part of it), solves the problem and marks the entry done (-2).  A sweep launch of the same kernel (yield_persist = 0)
+// behind both takes whatever is still >= 0 in the list: normally nothing.  No wait is unbounded (wall-clock limits): a scheduling
+// surprise costs time, not a hang.
 template <int NT, int TW>
 __global__ __launch_bounds__(WAVE * TW) MPC_TEAM_ATTR void solve_kernel_team(KParams kp, BatchPtrs io, int B) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -60,12 +67,39 @@ __global__ __launch_bounds__(WAVE * TW) MPC_TEAM_ATTR void solve_kernel_team(KPa
     constexpr bool SC = false;  // general tables: no batch-wide shape information is needed before the launch
     const int N = NT ? NT : kp.N;  // compile-time horizon (0 = runtime horizon from KParams)
     const bool resume = io.ylist != nullptr;
+    const bool persist = resume && kp.yield_persist != 0;
     int b = blockIdx.x;
-    if (resume) {
+    if (persist) {
+        double* claim = lds + kp.l_xch + 3;   // a spare double of wavefront 0's exchange block
+        if (threadIdx.x == 0) {
+            const int idx = blockIdx.x;
+            int bb = -1;
+            const long long t0 = wall_clock64();
+            for (;;) {
+                int v = __hip_atomic_load(io.ylist + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v >= 0) { bb = v; break; }
+                const int fin = __hip_atomic_load(io.counts + CNT_FINISHED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int listed = __hip_atomic_load(io.counts + CNT_LISTED, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                if (fin + listed >= kp.yield_total) {   // the list is final: is this entry part of it?
+                    v = __hip_atomic_load(io.ylist + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v >= 0) bb = v;
+                    break;
+                }
+                if (wall_clock64() - t0 > 200000000LL) break;   // 2 s (100 MHz): give up, the sweep takes the entry
+                __builtin_amdgcn_s_sleep(64);
+            }
+            claim[0] = (double)bb;
+        }
+        __syncthreads();
+        b = (int)uniform(claim[0]);
+        if (b < 0) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the record the throughput kernel wrote before the entry
+    } else if (resume) {
         int n = io.counts[CNT_YIELDED];
         n = n < kp.yield_cap ? n : kp.yield_cap;
         if (b >= n) return;
         b = __builtin_amdgcn_readfirstlane(io.ylist[b]);
+        if (b < 0) return;   // solved by the concurrent continuation (-2) -- this launch is the sweep behind it
     }
     if (b >= B) return;
     long long t_start = wall_clock64();
@@ -508,8 +542,19 @@ __global__ __launch_bounds__(WAVE * TW) MPC_TEAM_ATTR void solve_kernel_team(KPa
             if (io.fpr) io.fpr[b] = last_fpr;
             if (io.f2norm) io.f2norm[b] = f2_norm_plus;
             if (io.ms) io.ms[b] = (double)(wall_clock64() - t_start) * 1e-5;
+            if (persist) __hip_atomic_store(io.ylist + blockIdx.x, -2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // done: nothing for the sweep
         }
     }
+}
+
+// Holds the stream of the concurrent continuation back until the throughput launch starts to promote (FINISHED >= yield_from):
+// workgroups of the latency kernel that arrive earlier would take registers and LDS from a GPU that is still full.  One lane, asleep
+// between looks; bounded by a wall-clock limit like every wait of this scheme.
+__global__ __launch_bounds__(WAVE) void tail_gate_kernel(const int* counts, int yield_from, long long max_ticks) {
+    if (threadIdx.x != 0) return;
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(counts + CNT_FINISHED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < yield_from && wall_clock64() - t0 < max_ticks)
+        __builtin_amdgcn_s_sleep(127);
 }
 
 }  // namespace mpcgpu

@@ -60,6 +60,10 @@ struct Handle {
     int yield_poll = 16; // ... builds with -DMPC_YIELD_STEP=1 only: the finished-counter is also polled every this many PANOC steps (power of two)
     int yield_waves = 0; // MPCGPU_OPT_TAIL_WAVES: wavefronts per promoted problem (0: four; two for an explicit capacity beyond four times the residency)
     int last_yield_cap = 0;  // capacity of the continuation launch of the last solve (0: none was enqueued)
+    int tail_concurrent = 1; // MPCGPU_OPT_TAIL_CONCURRENT: 1 = the continuation runs on `side` while the throughput launch drains (mpc_team.hpp CONCURRENT)
+    hipStream_t side = nullptr;                      // stream of the concurrent continuation
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr; // launch stream -> side (records written), side -> launch stream (promoted problems solved)
+    bool last_concurrent = false;
     int trace_cap = 0;  // -DMPC_TRACE builds: PANOC steps recorded per problem (0 = tracing off)
     // mpcgpu_reserve_shape: upper bounds of active rows promised by the caller -> no count read-back before the launch
     bool capturing = false;  // the launch stream of the current call is being captured into a hipGraph: no event records
@@ -195,7 +199,7 @@ void fill_static_params(Handle* h) {
     // tail promotion (mpc_kernels.hpp YIELD): the iteration state a problem leaves behind when it moves to the latency kernel
     k.ws_yield = o; o += YS_SCALARS + N * YS_VECW + even(c.lbfgs_mem) + gg_doubles_c(N, c.lbfgs_mem, gram_shape(N, c.lbfgs_mem));
     k.ws_stride = (o + 15) & ~15;
-    k.yield_from = 0; k.yield_cap = 0; k.yield_mask = 15;
+    k.yield_from = 0; k.yield_cap = 0; k.yield_mask = 15; k.yield_persist = 0; k.yield_total = 0;
 }
 
 // sizes of the fixed regions: mpc_kernels.hpp (part_doubles_c, stash_doubles_c, fixed_lds) -- shared with the kernels
@@ -376,6 +380,9 @@ int32_t mpcgpu_create(const mpcgpu_config* cfg, void** handle) {
     CREATE_OK(hipDeviceGetAttribute(&h->num_cus, hipDeviceAttributeMultiprocessorCount, h->device));
     CREATE_OK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     for (auto& ev : h->ev) CREATE_OK(hipEventCreate(&ev));
+    CREATE_OK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    CREATE_OK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    CREATE_OK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     CREATE_OK(hipHostMalloc((void**)&h->h_counts, CNT_WORDS * sizeof(int), hipHostMallocDefault));
 #undef CREATE_OK
     *handle = h;
@@ -387,6 +394,7 @@ void mpcgpu_destroy(void* handle) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->side) (void)hipStreamSynchronize(h->side);
     DevBuf* bufs[] = {&h->ws, &h->counts, &h->evals, &h->perm, &h->bins, &h->nlist, &h->ylist, &h->trace, &h->p, &h->u0, &h->y0, &h->c0, &h->u, &h->cost, &h->status, &h->inner,
                       &h->outer, &h->fpr, &h->f2, &h->y, &h->ms, &h->xi, &h->psi, &h->f, &h->grad, &h->F1, &h->F2};
     for (DevBuf* b : bufs)
@@ -394,6 +402,9 @@ void mpcgpu_destroy(void* handle) {
     if (h->h_counts) (void)hipHostFree(h->h_counts);
     for (auto& ev : h->ev)
         if (ev) (void)hipEventDestroy(ev);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->side) (void)hipStreamDestroy(h->side);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -429,6 +440,7 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
     h->last_team = 0;
     h->last_yield_cap = 0;
     h->tail_timed = false;
+    h->last_concurrent = false;
     h->kp.yield_from = 0;
     bool prepared = false;
 #ifdef MPC_TRACE
@@ -612,7 +624,10 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
         // Automatic capacity: TWICE what is resident at once when a compute unit holds two teams (N_hor = 20: 1024 -- the second
         // half starts as the first finishes; 252.7 -> 248.4 ms at B = 8192, profiles/r05_tail_promotion_ab.txt), else what is
         // resident (N_hor = 40: 256).  An explicit capacity beyond four times the residency takes two wavefronts per problem.
-        int K = h->yield_opt > 0 ? h->yield_opt : (per_cu >= 2 ? 2 : 1) * per_cu * h->num_cus;
+        // With the continuation running while the launch drains (the default outside a capture) the teams take over as they come
+        // free: twice the residency in either case (N_hor = 40: 512 -- 294.7 -> 280 ms at B = 4096, profiles/r05_tail_concurrent_ab.txt).
+        const bool may_overlap = h->tail_concurrent && !h->capturing && !MPC_YIELD_STEP;
+        int K = h->yield_opt > 0 ? h->yield_opt : (per_cu >= 2 || may_overlap ? 2 : 1) * per_cu * h->num_cus;
         if (!h->yield_waves && h->yield_opt > 4 * per_cu * h->num_cus) { tw = 2; per_cu = team_shape(tw, kt_y, lds_y); }
         if (K > B) K = B;
         if (per_cu >= 1 && K > 0) {
@@ -624,7 +639,20 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
             io.ylist = (int32_t*)h->ylist.ptr;
             kt_y.yield_cap = K;
             kt_y.yield_mask = h->yield_poll - 1;
+            kt_y.yield_total = B;
+            // every entry starts out EMPTY (-1): the concurrent continuation waits for an entry to appear, the sweep skips what is not >= 0
+            HIP_OK(h, hipMemsetAsync(h->ylist.ptr, 0xFF, (size_t)K * sizeof(int32_t), s));
         }
+    }
+    // Concurrent continuation (MPCGPU_OPT_TAIL_CONCURRENT): the latency kernel on the side stream, behind a gate that opens when the
+    // throughput launch starts to promote; its workgroups take list entries as they appear.  Not while capturing (the launch behind
+    // the throughput kernel is what a graph records), not in the build that leaves inside an inner problem (its record is bigger),
+    // and only when every unfinished problem is resident by the time the gate opens (K <= what the throughput kernel holds at once):
+    // workgroups of the latency kernel must never wait for list entries while they keep problems of the launch from starting.
+    const bool concurrent = yield_K > 0 && h->tail_concurrent && !h->capturing && !MPC_YIELD_STEP && yield_K <= resident;
+    if (concurrent) {
+        HIP_OK(h, hipEventRecord(h->ev_fork, s));            // the records (compaction) and the empty list are in place
+        HIP_OK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
     }
 #define LAUNCH_DUO(NT, SC)                                                                                          \
     do {                                                                                                             \
@@ -676,18 +704,32 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
     if (yield_K > 0) {
         if (!h->capturing) { HIP_OK(h, hipEventRecord(h->ev[4], s)); h->tail_timed = true; }
         // the continuation: grid = capacity of the list, workgroups beyond its device-side length leave at once
-#define LAUNCH_RESUME(NT, TW)                                                                                        \
+#define LAUNCH_RESUME(NT, TW, GRID, STREAM)                                                                          \
     do {                                                                                                             \
         auto kern = solve_kernel_team<NT, TW>;                                                                       \
         if (int r_ = opt_in_lds(h, (const void*)kern, lds_y)) return r_;                                             \
-        hipLaunchKernelGGL(kern, dim3(yield_K), dim3(WAVE * TW), lds_y, s, kt_y, io, B);                             \
+        hipLaunchKernelGGL(kern, dim3(GRID), dim3(WAVE * TW), lds_y, STREAM, kt_y, io, B);                           \
     } while (0)
+#define LAUNCH_RESUME_N(GRID, STREAM)                                                                                \
+    switch (compiled_horizon(h)) {                                                                                   \
+        case 20: if (yield_tw == 2) LAUNCH_RESUME(20, 2, GRID, STREAM); else LAUNCH_RESUME(20, TEAM_WAVES, GRID, STREAM); break; \
+        case 40: if (yield_tw == 2) LAUNCH_RESUME(40, 2, GRID, STREAM); else LAUNCH_RESUME(40, TEAM_WAVES, GRID, STREAM); break; \
+        default: if (yield_tw == 2) LAUNCH_RESUME(0, 2, GRID, STREAM); else LAUNCH_RESUME(0, TEAM_WAVES, GRID, STREAM); break;   \
+    }
         io.p = nullptr; io.perm = nullptr;
-        switch (compiled_horizon(h)) {
-            case 20: if (yield_tw == 2) LAUNCH_RESUME(20, 2); else LAUNCH_RESUME(20, TEAM_WAVES); break;
-            case 40: if (yield_tw == 2) LAUNCH_RESUME(40, 2); else LAUNCH_RESUME(40, TEAM_WAVES); break;
-            default: if (yield_tw == 2) LAUNCH_RESUME(0, 2); else LAUNCH_RESUME(0, TEAM_WAVES); break;
+        if (concurrent) {
+            // side stream: gate (opens at FINISHED >= yield_from; 60 s limit), then one workgroup per list entry
+            hipLaunchKernelGGL(tail_gate_kernel, dim3(1), dim3(WAVE), 0, h->side, (const int*)io.counts, h->kp.yield_from, 6000000000LL);
+            kt_y.yield_persist = 1;
+            LAUNCH_RESUME_N(yield_K, h->side)
+            HIP_OK(h, hipGetLastError());
+            HIP_OK(h, hipEventRecord(h->ev_join, h->side));
+            HIP_OK(h, hipStreamWaitEvent(s, h->ev_join, 0));
+            kt_y.yield_persist = 0;   // the sweep below: entries the side launch did not get to (normally none)
+            h->last_concurrent = true;
         }
+        LAUNCH_RESUME_N(yield_K, s)
+#undef LAUNCH_RESUME_N
 #undef LAUNCH_RESUME
         HIP_OK(h, hipGetLastError());
         h->last_yield_cap = yield_K;
@@ -1150,6 +1192,10 @@ int32_t mpcgpu_set_option(void* handle, int32_t option, double value) {
         case MPCGPU_OPT_TAIL_WAVES:
             if (value != 0.0 && value != 2.0 && value != 4.0) return fail(h, -1, "tail waves must be 0 (automatic), 2 or 4, got %g", value);
             h->yield_waves = (int)value;
+            return 0;
+        case MPCGPU_OPT_TAIL_CONCURRENT:
+            if (value != 0.0 && value != 1.0) return fail(h, -1, "tail concurrent must be 0 or 1, got %g", value);
+            h->tail_concurrent = (int)value;
             return 0;
         case MPCGPU_OPT_TAIL_POLL: {
             const int v = (int)value;

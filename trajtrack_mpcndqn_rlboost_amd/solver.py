@@ -32,6 +32,7 @@ OPT_LINEAR_TABLES = 5             # MPCGPU_OPT_LINEAR_TABLES
 OPT_TAIL_PROMOTION = 6            # MPCGPU_OPT_TAIL_PROMOTION
 OPT_TAIL_POLL = 7                 # MPCGPU_OPT_TAIL_POLL
 OPT_TAIL_WAVES = 8                # MPCGPU_OPT_TAIL_WAVES
+OPT_TAIL_CONCURRENT = 9           # MPCGPU_OPT_TAIL_CONCURRENT
 
 
 def _stream_arg(stream):
@@ -282,6 +283,8 @@ class BatchSolver:
             tail_promotion = int(os.environ["MPCGPU_TAIL_PROMOTION"])
         if tail_promotion is not None:
             self.set_tail_promotion(tail_promotion)
+        if os.environ.get("MPCGPU_TAIL_CONCURRENT"):
+            self.set_tail_concurrent(int(os.environ["MPCGPU_TAIL_CONCURRENT"]) != 0)
 
     def set_tail_promotion(self, problems: int, poll_steps: Optional[int] = None, waves: Optional[int] = None):
         """MPCGPU_OPT_TAIL_PROMOTION (-1 automatic, 0 off, K problems) and, for the A/B build that can leave inside an inner
@@ -291,6 +294,11 @@ class BatchSolver:
             self._check(self._L.mpcgpu_set_option(self._h, OPT_TAIL_POLL, float(poll_steps)), "mpcgpu_set_option")
         if waves is not None:
             self._check(self._L.mpcgpu_set_option(self._h, OPT_TAIL_WAVES, float(waves)), "mpcgpu_set_option")
+
+    def set_tail_concurrent(self, on: bool):
+        """MPCGPU_OPT_TAIL_CONCURRENT: the continuation of the tail promotion runs on a stream of the handle's own while the
+        throughput launch drains (True) or as the launch behind it (False).  Results do not depend on it (bitwise)."""
+        self._check(self._L.mpcgpu_set_option(self._h, OPT_TAIL_CONCURRENT, 1.0 if on else 0.0), "mpcgpu_set_option")
 
     def last_tail_promotion(self, stream: Optional[int] = None):
         """(capacity of the continuation launch of the last solve call, problems that actually moved to the latency kernel)."""
