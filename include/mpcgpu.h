@@ -209,18 +209,22 @@ int32_t mpcgpu_reserve_batch(void* handle, int32_t B);
  *       PROBLEM -- point, multipliers, penalty, tolerance and the outer loop's counters go into the problem's workspace record --
  *       and a continuation launch of the LATENCY kernel on the same stream (four wavefronts per problem: the evaluations of a step
  *       side by side, 2.3 x faster per problem on an empty GPU) finishes those problems from exactly that point.  Automatic K:
- *       twice the teams that are resident at once (N_hor = 20: 4 x #CUs = 1024; N_hor = 40: #CUs, one team per compute unit by
- *       its LDS carve).  > 0: that K (beyond four times the residency: two wavefronts per problem); 0: off.  Same step functions
+ *       twice the teams that are resident at once (N_hor = 20: 4 x #CUs = 1024; N_hor = 40, one team per compute unit by its LDS
+ *       carve: 2 x #CUs = 512 -- #CUs when the continuation is the launch BEHIND the throughput kernel, see
+ *       MPCGPU_OPT_TAIL_CONCURRENT).  > 0: that K (beyond four times the residency: two wavefronts per problem); 0: off.  Same step functions
  *       on the same state: every output is BITWISE what the throughput kernel alone writes (tests/test_gpu_yield.py); nothing is
  *       read back, the call stays capturable.  The reference has no counterpart.
  *   MPCGPU_OPT_TAIL_POLL  (ABI 7) PANOC steps between two looks at the launch's finished-counter (a power of two, default 16;
  *       only the A/B build -DMPC_YIELD_STEP=1 looks inside an inner problem at all).
  *   MPCGPU_OPT_TAIL_WAVES  (ABI 7) wavefronts per promoted problem: 0 (default) by K as above, 2 or 4.
- *   MPCGPU_OPT_TAIL_CONCURRENT  (ABI 7) 1: the continuation does not wait for the throughput launch to end -- it runs on a stream of
- *       the handle's own while that launch drains (behind a gate that opens with the first promotion; its workgroups take the
- *       promoted problems one after the other as they appear), and the launch stream waits for it at the end of the call.  Same
- *       results, bit for bit.  0: the continuation is the launch behind the throughput kernel (always so while the call is being
- *       captured into a hipGraph).
+ *   MPCGPU_OPT_TAIL_CONCURRENT  (ABI 7) 1 (default): the continuation does not wait for the throughput launch to end -- it runs on a
+ *       stream of the handle's own WHILE that launch drains (behind a one-lane gate kernel that opens when the launch starts to
+ *       promote; workgroup g waits for list entry g, every wait bounded by a wall-clock limit), the launch stream waits for it at
+ *       the end of the call, and a sweep launch behind both takes what might be left (normally nothing).  Same results, bit for
+ *       bit; 247 -> 237 ms at B = 8192, 146 -> 133 ms at 4096, N_hor = 40 B = 4096: 295 -> 280 ms.  0: the continuation is the launch
+ *       behind the throughput kernel -- always so while the call is being captured into a hipGraph, and when K exceeds what the
+ *       throughput kernel keeps resident (workgroups of the latency kernel must not hold compute units while problems of the
+ *       launch are still waiting to start).
  */
 enum { MPCGPU_OPT_LINESEARCH_FALLBACK = 1, MPCGPU_OPT_PAIRING = 2, MPCGPU_OPT_TEAM_BATCH = 3, MPCGPU_OPT_ORDER = 4,
        MPCGPU_OPT_LINEAR_TABLES = 5, MPCGPU_OPT_TAIL_PROMOTION = 6, MPCGPU_OPT_TAIL_POLL = 7, MPCGPU_OPT_TAIL_WAVES = 8,

@@ -139,9 +139,12 @@ struct KParams {
 // launch counts itself as finished (CNT_FINISHED); once all but `yield_cap` problems of the launch have finished, a wavefront that
 // reaches the START OF AN INNER PROBLEM writes the state of its outer loop -- point, multipliers, penalty, tolerance, counters, the
 // position of the L-BFGS ring: the PANOC cache and the buffer are empty there -- into its workspace record, appends its problem to a
-// list and leaves; a continuation launch of the latency kernel on the same stream (solve_kernel_team with io.ylist set, grid =
-// yield_cap, workgroups beyond the device-side list length leave at once) starts that inner problem.  Both kernels run the same step functions on the same state: every output is
-// BITWISE what the throughput kernel alone would have written (tests/test_gpu_yield.py).  Nothing is read back; capturable.
+// list and leaves; a continuation launch of the latency kernel (solve_kernel_team with io.ylist set, grid = yield_cap) starts that
+// inner problem -- behind the throughput kernel on the same stream (workgroups beyond the device-side list length leave at once;
+// the form a hipGraph records), or, by default, on a stream of the handle's own WHILE the throughput launch drains (mpc_team.hpp,
+// CONCURRENT: the record is published with a release fence, the list entry after it).  Both kernels run the same step functions
+// on the same state: every output is BITWISE what the throughput kernel alone would have written (tests/test_gpu_yield.py).
+// Nothing is read back; capturable.
 // Record at ws_yield (doubles): YS_* scalars, then [N][8] = (u, grad, half step, multipliers) of every step, then the L-BFGS
 // scalars that live in LDS (rho, Gram matrices) -- gradient, half step and the L-BFGS part are written by MPC_YIELD_STEP builds only.
 // ------------------------------------------------------------------------------------------------
