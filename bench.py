@@ -318,6 +318,9 @@ def main():
         b = int(p.shape[0])
         halves = [p[: b // 2], p[b // 2:]]
         svs = [new_solver(), new_solver()]
+        for sv in svs:   # two launches in flight: the OTHER stream's launch fills the drain, so the continuation of the tail promotion
+            if hasattr(sv, "set_tail_concurrent"):   # stays the launch behind its own throughput kernel (MPCGPU_OPT_TAIL_CONCURRENT = 0)
+                sv.set_tail_concurrent(False)
         outs = [new_out(int(h.shape[0])) for h in halves]
         if stub:
             streams = [None, None]

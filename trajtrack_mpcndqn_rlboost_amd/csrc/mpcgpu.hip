@@ -380,7 +380,13 @@ int32_t mpcgpu_create(const mpcgpu_config* cfg, void** handle) {
     CREATE_OK(hipDeviceGetAttribute(&h->num_cus, hipDeviceAttributeMultiprocessorCount, h->device));
     CREATE_OK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     for (auto& ev : h->ev) CREATE_OK(hipEventCreate(&ev));
-    CREATE_OK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    {   // The side stream of the concurrent continuation must not share a hardware queue with the launch stream (packets of one
+        // queue run in order: the gate would sit behind the throughput kernel and the continuation would be the launch behind it
+        // again).  The runtime hands out queues per priority class: take the highest one -- the tail of a launch IS its critical path.
+        int least = 0, greatest = 0;
+        CREATE_OK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        CREATE_OK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, greatest));
+    }
     CREATE_OK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     CREATE_OK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     CREATE_OK(hipHostMalloc((void**)&h->h_counts, CNT_WORDS * sizeof(int), hipHostMallocDefault));
