@@ -516,9 +516,10 @@ def main():
                        "lds_bytes_per_wavefront": solver.last_shape()["lds_bytes"],
                        "wavefronts_per_simd": solver.last_shape()["waves_per_simd"],
                        "tail_promotion": {"what": "MPCGPU_OPT_TAIL_PROMOTION (library default): the last problems of a plain launch "
-                                                  "move to the latency kernel at the start of their next inner problem; bitwise the same results",
+                                                  "move to the latency kernel at the start of their next inner problem, which runs them on a side stream "
+                                                  "while the launch drains (MPCGPU_OPT_TAIL_CONCURRENT); bitwise the same results",
                                           "capacity": leg["tail_promotion"][0], "promoted_last_step": leg["tail_promotion"][1],
-                                          "continuation_kernel_ms": leg["tail_ms"]}},
+                                          "continuation_ms_after_the_throughput_kernel": leg["tail_ms"]}},
         }
         if conv is not None:
             cl = conv["leg"]
@@ -573,7 +574,8 @@ def main():
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
                     "kernel": "solve_kernel_pair", "kernel_ms": k_ms, "prep_kernel_ms": leg["prep_ms"],
-                    "tail_kernel": "solve_kernel_team (continuation launch of the tail promotion: the last problems of the launch)",
+                    "tail_kernel": "solve_kernel_team (continuation of the tail promotion: the last problems of the launch; it starts on a side stream while "
+                                   "solve_kernel_pair drains -- tail_kernel_ms is the part of it AFTER that kernel has ended, by HIP events)",
                     "tail_kernel_ms": leg["tail_ms"],
                     "algorithmic_bytes_per_solve": algo_bytes // B,
                     "measured_in_run": {"achieved": True, "kernel_ms": True, "frac": True, "flops": True,

@@ -109,6 +109,14 @@ def test_c_abi_library_exports_every_declared_symbol():
     assert lib.mpcgpu_abi_version() == 7
 
 
+def test_option_numbers_of_the_ctypes_side_match_the_header():
+    """mpcgpu_set_option takes a number: solver.py's OPT_* constants are the header's MPCGPU_OPT_* enumerators, every one of them."""
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mpcgpu.h")).read(), flags=re.S)
+    header = {k: int(v) for k, v in re.findall(r"\bMPCGPU_(OPT_[A-Z_]+)\s*=\s*(\d+)", text)}
+    python = {k: v for k, v in vars(solver_mod).items() if k.startswith("OPT_")}
+    assert header == python and len(set(header.values())) == len(header) >= 9
+
+
 def test_variant_builds_export_the_abi_and_their_debug_hooks():
     """Test-only builds (csrc/Makefile `variants`, compiled by __graft_entry__.build()): same C-ABI; the trace build adds
     its two debug entry points, the product library must not carry them."""

@@ -50,7 +50,9 @@ def test_the_tail_kernel_is_kept_apart_from_the_dominant_kernel():
     are those of the pair kernel alone, the continuation's average duration is reported next to them."""
     with open(COMMITTED) as fh:
         c = json.load(fh)
-    assert c["tail_kernel_calls"] == c["kernel_calls_kernel_trace"] and 0.0 < c["tail_kernel_avg_ms"] < 0.05 * c["kernel_avg_ms_kernel_trace"]
+    # one continuation launch per solve call, or two (the one that runs while the throughput launch drains + the sweep behind it)
+    assert c["tail_kernel_calls"] in (c["kernel_calls_kernel_trace"], 2 * c["kernel_calls_kernel_trace"])
+    assert 0.0 < c["tail_kernel_ms_per_solve_call"] < 0.05 * c["kernel_avg_ms_kernel_trace"]
     with open(os.path.join(ROOT, "profiles", "r05_bench_line.json")) as fh:
         line = json.load(fh)
     ro = line["roofline"]

@@ -23,7 +23,7 @@ ls $O/dqn_ckpt >> $O/dqn_config5.txt; rm -rf $O/dqn_ckpt
 bash tools/collect_profiles.sh gpurun_out/raw_r05 > $O/collect.log 2>&1
 bash tools/pmc_stalls.sh 8192 gpurun_out/pmc_stalls_r05 > $O/pmc_stalls_B8192.txt 2>&1
 (echo "# dispatch order (MPCGPU_OPT_ORDER): tools/prof_solve.py B 4 8 N, kernel ms of four consecutive calls of one handle (the first has no hints)"; for a in "8192 4 8 20" "32768 4 8 20" "4096 4 8 40" "16384 4 8 40"; do for o in as_given longest_first; do echo "## $a  MPCGPU_ORDER=$o"; MPCGPU_ORDER=$o python tools/prof_solve.py $a 2>&1 | grep solve_ms | sed "s/inner.*//"; done; done) > $O/order_table.txt 2>&1
-(python tools/tail_ab.py 20 8192,32768,131072 0,-1 2; python tools/tail_ab.py 40 4096,16384 0,-1 2; python tools/tail_ab.py 20 8192 0,-1 2 avoidance; python tools/tail_ab.py 20 8192 0,-1 2 passing) 2>&1 | grep -v amdgpu.ids > $O/tail_promotion_final.txt
+(echo "# tail promotion off (K = 0) / on with the continuation on the side stream while the launch drains (K = -1: the library default)"; python tools/tail_ab.py 20 4096,8192,32768,131072 0,-1 2; python tools/tail_ab.py 40 4096,16384 0,-1 2; python tools/tail_ab.py 20 8192 0,-1 2 avoidance; python tools/tail_ab.py 20 8192 0,-1 2 passing; echo "# ... with the continuation as the launch BEHIND the throughput kernel (MPCGPU_TAIL_CONCURRENT=0: what a captured call records)"; MPCGPU_TAIL_CONCURRENT=0 python tools/tail_ab.py 20 4096,8192,32768 -1 2; MPCGPU_TAIL_CONCURRENT=0 python tools/tail_ab.py 40 4096,16384 -1 2) 2>&1 | grep -v amdgpu.ids > $O/tail_promotion_final.txt
 (python tools/closed_loop.py 8192 30 4 cold capacity) 2>&1 | grep -v amdgpu.ids > $O/realtime_capacity.txt
 (python tools/closed_loop.py 8192 30 4 cold streams) 2>&1 | grep -v amdgpu.ids > $O/closed_loop_streams.txt
 tail -2 $O/bench.err; cat $O/bench_line.json | cut -c1-400

@@ -160,7 +160,10 @@ def rebuild(raw_dir, out_path):
         "kernel": wl.get("kernel", "solve_kernel_pair"),
         "kernel_avg_ms_kernel_trace": avg_ns * 1e-6, "kernel_calls_kernel_trace": calls, "kernel_time_source": time_source,
         "prep_kernel_avg_ms": prep_ns * 1e-6,
+        # two launches of it per solve call when the continuation runs while the throughput launch drains (side stream + sweep):
+        # per solve call = total duration / calls of the dominant kernel (the side-stream launch OVERLAPS the end of the dominant one)
         "tail_kernel": TAIL_KERNEL, "tail_kernel_avg_ms": tail_ns * 1e-6, "tail_kernel_calls": tail_calls,
+        "tail_kernel_ms_per_solve_call": tail_ns * 1e-6 * tail_calls / max(calls, 1),
         "raw_per_launch": {"sq_pass": sq, "FETCH_SIZE_KiB": fetch_kib, "WRITE_SIZE_KiB": write_kib,
                            "prep_kernel_FETCH_SIZE_KiB": prep_fetch / 1024.0},
         "fetch_calibration_prep_kernel_measured_over_expected": calib,
