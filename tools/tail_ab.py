@@ -2,7 +2,8 @@
 """Tail promotion A/B (MPCGPU_OPT_TAIL_PROMOTION): kernel time of plain launches for several capacities K of the continuation
 launch (0 = off), on the bench family, with the hash of the results (must be the same in every column).
 usage: tail_ab.py [N_hor] [B,B,...] [K,K,...] [reps] [family: bench|passing|avoidance] [order: as_given|longest_first]
-MPCGPU_LIB=<.so> selects the build (e.g. variants/libmpcgpu_yieldstep.so with MPCGPU_TAIL_POLL=<steps>)."""
+MPCGPU_LIB=<.so> selects the build (e.g. variants/libmpcgpu_yieldstep.so with MPCGPU_TAIL_POLL=<steps>); MPCGPU_TAIL_CONCURRENT=0 puts the
+continuation behind the throughput launch instead of beside it (read by BatchSolver)."""
 import hashlib, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,7 +19,7 @@ order = sys.argv[6] if len(sys.argv) > 6 else "as_given"
 poll = int(os.environ["MPCGPU_TAIL_POLL"]) if os.environ.get("MPCGPU_TAIL_POLL") else None
 waves = int(os.environ["MPCGPU_TAIL_WAVES"]) if os.environ.get("MPCGPU_TAIL_WAVES") else None
 cfg = MpcConfig(N_hor=N)
-print(f"# {os.environ.get('MPCGPU_LIB', 'libmpcgpu.so')}  N_hor={N} family={fam} order={order} poll={poll} waves={waves}")
+print(f"# {os.environ.get('MPCGPU_LIB', 'libmpcgpu.so')}  N_hor={N} family={fam} order={order} poll={poll} waves={waves} concurrent={os.environ.get('MPCGPU_TAIL_CONCURRENT', 'default (1)')}")
 for B in Bs:
     sc = scenes.make_batch(cfg, B, n_dyn=8, seed=1236) if fam == "bench" else scenes.make_family(cfg, B, fam, n_dyn=8, seed=1236)
     for K in Ks:

@@ -239,7 +239,8 @@ class BatchSolver:
         overrides None; an experiment that only the variant build libmpcgpu_linear40.so carries).  Results do not depend on it.
         ``tail_promotion``: how many problems at the end of a throughput launch move to the latency kernel at the start of their
         next inner problem (MPCGPU_OPT_TAIL_PROMOTION): None / -1 = the library's rule (2 per compute unit), 0 = off (env
-        MPCGPU_TAIL_PROMOTION overrides None).  Results do not depend on it (bitwise)."""
+        MPCGPU_TAIL_PROMOTION overrides None).  Results do not depend on it (bitwise).  Where those problems run -- beside the
+        draining launch on a stream of the handle's own (default) or behind it: ``set_tail_concurrent`` / env MPCGPU_TAIL_CONCURRENT."""
         self.config = config if config is not None else MpcConfig()
         self._L = load_library(library)
         self._h = C.c_void_p()
