@@ -79,8 +79,9 @@ __global__ __launch_bounds__(WAVE * TW) MPC_TEAM_ATTR void solve_kernel_team(KPa
                 int v = __hip_atomic_load(io.ylist + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (v >= 0) { bb = v; break; }
                 const int fin = __hip_atomic_load(io.counts + CNT_FINISHED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int listed = __hip_atomic_load(io.counts + CNT_LISTED, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                const int listed = __hip_atomic_load(io.counts + CNT_LISTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (fin + listed >= kp.yield_total) {   // the list is final: is this entry part of it?
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (here, not in every look: an acquire invalidates this CU's vector cache)
                     v = __hip_atomic_load(io.ylist + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (v >= 0) bb = v;
                     break;
