@@ -196,3 +196,13 @@ def test_closed_loop_trajectories_do_not_depend_on_the_promotion():
             r = device_closed_loop(cfg, 6144, 4, 2, 4, warm, order, tail_promotion=K)
             assert np.array_equal(ref["_final_states"], r["_final_states"]), (warm, order, K)
             assert ref["status_histogram_per_tick"] == r["status_histogram_per_tick"]
+
+
+def test_random_batches_on_reused_handles_keep_their_bits():
+    """tools/probes/concurrent_stress.py, a short run: random horizons, batch sizes, families, orders and starts, three calls per
+    handle (list, counters and side stream reused) -- promotion with the continuation beside the draining launch against none."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "probes", "concurrent_stress.py"), "6", "7"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 calls with different bits" in r.stdout
