@@ -2552,7 +2552,6 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
 #ifdef MPC_TRACE
             yr[YS_TRN] = tr_n; yr[YS_TRPSI] = tr_psi_u;
 #endif
-            io.ylist[yslot] = b;   // (this build's continuation is the launch BEHIND the throughput kernel only)
         }
         {   // the L-BFGS scalars that live in LDS: rho and the Gram matrices (or nothing worth keeping, two-loop form)
             double* yl = yr + YS_SCALARS + N * YS_VECW;
@@ -2564,6 +2563,11 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
             double* wr = io.ws + (size_t)b * kp.ws_stride;
             for (int i = lane; i < (2 * mem + 1) * N * 2; i += P::W) wr[kp.ws_lbs + i] = lm.LM[i];
             for (int i = lane; i < N * 4; i += P::W) wr[kp.ws_lold + i] = lm.LOLD[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // record, L-BFGS scalars and ring first, then the list entry (see above)
+        if (lane == 0) {
+            __hip_atomic_store(io.ylist + yslot, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(io.counts + CNT_LISTED, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
 #ifdef MPC_PROFILE
         prof.mark(22); prof.flush();

@@ -632,7 +632,7 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
         // resident (N_hor = 40: 256).  An explicit capacity beyond four times the residency takes two wavefronts per problem.
         // With the continuation running while the launch drains (the default outside a capture) the teams take over as they come
         // free: twice the residency in either case (N_hor = 40: 512 -- 294.7 -> 280 ms at B = 4096, profiles/r05_tail_concurrent_ab.txt).
-        const bool may_overlap = h->tail_concurrent && !h->capturing && !MPC_YIELD_STEP;
+        const bool may_overlap = h->tail_concurrent && !h->capturing;
         int K = h->yield_opt > 0 ? h->yield_opt : (per_cu >= 2 || may_overlap ? 2 : 1) * per_cu * h->num_cus;
         if (!h->yield_waves && h->yield_opt > 4 * per_cu * h->num_cus) { tw = 2; per_cu = team_shape(tw, kt_y, lds_y); }
         if (K > B) K = B;
@@ -652,10 +652,9 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
     }
     // Concurrent continuation (MPCGPU_OPT_TAIL_CONCURRENT): the latency kernel on the side stream, behind a gate that opens when the
     // throughput launch starts to promote; its workgroups take list entries as they appear.  Not while capturing (the launch behind
-    // the throughput kernel is what a graph records), not in the build that leaves inside an inner problem (its record is bigger),
-    // and only when every unfinished problem is resident by the time the gate opens (K <= what the throughput kernel holds at once):
+    // the throughput kernel is what a graph records), and only when every unfinished problem is resident by the time the gate opens (K <= what the throughput kernel holds at once):
     // workgroups of the latency kernel must never wait for list entries while they keep problems of the launch from starting.
-    const bool concurrent = yield_K > 0 && h->tail_concurrent && !h->capturing && !MPC_YIELD_STEP && yield_K <= resident;
+    const bool concurrent = yield_K > 0 && h->tail_concurrent && !h->capturing && yield_K <= resident;
     if (concurrent) {
         HIP_OK(h, hipEventRecord(h->ev_fork, s));            // the records (compaction) and the empty list are in place
         HIP_OK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
