@@ -637,7 +637,7 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
         if (!h->yield_waves && h->yield_opt > 4 * per_cu * h->num_cus) { tw = 2; per_cu = team_shape(tw, kt_y, lds_y); }
         // a small batch: no more than 9/16 of it (B = 1280: 93.7 ms with 768 against 99.6 with 1024; from 2048 problems on the
         // automatic capacity is below that anyway: profiles/r05_tail_concurrent_ab.txt, block 7)
-        if (h->yield_opt < 0 && K > B * 9 / 16) K = B * 9 / 16;
+        if (h->yield_opt < 0 && B > per_cu * h->num_cus && K > B * 9 / 16) K = B * 9 / 16;   // (a batch the teams hold at once: all of it)
         if (K > B) K = B;
         if (per_cu >= 1 && K > 0) {
             if (int r = ensure(h, h->ylist, (size_t)K * sizeof(int32_t))) return r;
