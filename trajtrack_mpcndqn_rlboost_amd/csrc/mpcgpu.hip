@@ -384,8 +384,12 @@ int32_t mpcgpu_create(const mpcgpu_config* cfg, void** handle) {
         // queue run in order: the gate would sit behind the throughput kernel and the continuation would be the launch behind it
         // again).  The runtime hands out queues per priority class: take the highest one -- the tail of a launch IS its critical path.
         int least = 0, greatest = 0;
-        CREATE_OK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        CREATE_OK(hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, greatest));
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
+            hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, greatest) != hipSuccess) {
+            (void)hipGetLastError();   // no priorities here: an ordinary stream (sharing a queue only costs the overlap, never the result)
+            h->side = nullptr;
+            CREATE_OK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        }
     }
     CREATE_OK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     CREATE_OK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
