@@ -314,13 +314,11 @@ def main():
     def pipelined_leg(p, steps, warmup):
         """The same K passes with the batch split into two half shards on two handles and two streams; nothing is read back
         and nothing waits on the host inside the timed region, so launch k + 1 of one stream fills the compute units that
-        launch k of the other stream is draining."""
+        launch k of the other stream is draining.  (The library sees the other handle's launch in flight and keeps the continuation of
+        the tail promotion behind its own throughput kernel: MPCGPU_OPT_TAIL_CONCURRENT applies to one launch at a time.)"""
         b = int(p.shape[0])
         halves = [p[: b // 2], p[b // 2:]]
         svs = [new_solver(), new_solver()]
-        for sv in svs:   # two launches in flight: the OTHER stream's launch fills the drain, so the continuation of the tail promotion
-            if hasattr(sv, "set_tail_concurrent"):   # stays the launch behind its own throughput kernel (MPCGPU_OPT_TAIL_CONCURRENT = 0)
-                sv.set_tail_concurrent(False)
         outs = [new_out(int(h.shape[0])) for h in halves]
         if stub:
             streams = [None, None]

@@ -222,9 +222,10 @@ int32_t mpcgpu_reserve_batch(void* handle, int32_t B);
  *       promote; workgroup g waits for list entry g, every wait bounded by a wall-clock limit), the launch stream waits for it at
  *       the end of the call, and a sweep launch behind both takes what might be left (normally nothing).  Same results, bit for
  *       bit; 247 -> 237 ms at B = 8192, 146 -> 133 ms at 4096, N_hor = 40 B = 4096: 295 -> 280 ms.  0: the continuation is the launch
- *       behind the throughput kernel -- always so while the call is being captured into a hipGraph, and when K exceeds what the
- *       throughput kernel keeps resident (workgroups of the latency kernel must not hold compute units while problems of the
- *       launch are still waiting to start).
+ *       behind the throughput kernel -- always so while the call is being captured into a hipGraph, when K exceeds what the
+ *       throughput kernel keeps resident, and while a launch of ANOTHER handle of this process is in flight on the device (seen by
+ *       its end-of-call event; two handles that keep two streams busy: the other launch fills the drain, and workgroups of the
+ *       latency kernel must not hold compute units that problems of a launch are waiting for).
  */
 enum { MPCGPU_OPT_LINESEARCH_FALLBACK = 1, MPCGPU_OPT_PAIRING = 2, MPCGPU_OPT_TEAM_BATCH = 3, MPCGPU_OPT_ORDER = 4,
        MPCGPU_OPT_LINEAR_TABLES = 5, MPCGPU_OPT_TAIL_PROMOTION = 6, MPCGPU_OPT_TAIL_POLL = 7, MPCGPU_OPT_TAIL_WAVES = 8,

@@ -143,8 +143,6 @@ def device_closed_loop_streams(cfg, B=8192, streams=2, ticks=30, warmup_ticks=5,
     fleets = []
     for i, b in enumerate(sizes):
         solver = BatchSolver(cfg, device=device, order=order)
-        if streams > 1:
-            solver.set_tail_concurrent(False)    # several launches in flight: the continuation stays behind its own launch (include/mpcgpu.h)
         dt = DeviceTracker(cfg, b, device=device, solver=solver)
         y0, pos_h, vel_h, static = scene_one(b, n_dyn, seed + 101 * i)
         setup(dt, b, y0, static)

@@ -16,6 +16,8 @@
 #include <new>
 #include <string>
 #include <unordered_map>
+#include <mutex>
+#include <vector>
 
 using namespace mpcgpu;
 
@@ -73,6 +75,21 @@ struct Handle {
     bool last_captured = false;         // the last solve was recorded into a hipGraph (no completion event exists for it)
     std::unordered_map<const void*, int> lds_attr;  // kernel -> largest dynamic-LDS size opted into (hipFuncSetAttribute once, not per launch)
 };
+
+// Handles of this process (mpcgpu_create / mpcgpu_destroy): a solve call looks at the others' end-of-call events to see whether
+// another launch is in flight on its device (the concurrent continuation is for ONE launch at a time, see solve_common).
+std::mutex g_handles_mu;
+std::vector<Handle*> g_handles;
+
+bool another_launch_in_flight(const Handle* h) {
+    std::lock_guard<std::mutex> lock(g_handles_mu);
+    for (const Handle* o : g_handles)
+        if (o != h && o->device == h->device && o->ev[3] && hipEventQuery(o->ev[3]) == hipErrorNotReady) {
+            (void)hipGetLastError();   // "not ready" is an answer, not an error to carry along
+            return true;
+        }
+    return false;
+}
 
 int fail(Handle* h, int code, const char* fmt, ...) {
     char buf[512];
@@ -395,6 +412,10 @@ int32_t mpcgpu_create(const mpcgpu_config* cfg, void** handle) {
     CREATE_OK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     CREATE_OK(hipHostMalloc((void**)&h->h_counts, CNT_WORDS * sizeof(int), hipHostMallocDefault));
 #undef CREATE_OK
+    {
+        std::lock_guard<std::mutex> lock(g_handles_mu);
+        g_handles.push_back(h);
+    }
     *handle = h;
     return 0;
 }
@@ -402,6 +423,11 @@ int32_t mpcgpu_create(const mpcgpu_config* cfg, void** handle) {
 void mpcgpu_destroy(void* handle) {
     Handle* h = (Handle*)handle;
     if (!h) return;
+    {
+        std::lock_guard<std::mutex> lock(g_handles_mu);
+        for (size_t i = 0; i < g_handles.size(); ++i)
+            if (g_handles[i] == h) { g_handles.erase(g_handles.begin() + i); break; }
+    }
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->side) (void)hipStreamSynchronize(h->side);
@@ -659,9 +685,12 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
     }
     // Concurrent continuation (MPCGPU_OPT_TAIL_CONCURRENT): the latency kernel on the side stream, behind a gate that opens when the
     // throughput launch starts to promote; its workgroups take list entries as they appear.  Not while capturing (the launch behind
-    // the throughput kernel is what a graph records), and only when every unfinished problem is resident by the time the gate opens (K <= what the throughput kernel holds at once):
-    // workgroups of the latency kernel must never wait for list entries while they keep problems of the launch from starting.
-    const bool concurrent = yield_K > 0 && h->tail_concurrent && !h->capturing && yield_K <= resident;
+    // the throughput kernel is what a graph records), and only when every unfinished problem is resident by the time the gate opens
+    // (K <= what the throughput kernel holds at once): workgroups of the latency kernel must never wait for list entries while they
+    // keep problems of the launch from starting.  For the same reason not while ANOTHER handle's launch is in flight on this device
+    // (two streams kept busy by two handles: that launch fills the drain of this one, and the teams would wait for registers it
+    // holds -- 3.37e4 -> 2.91e4 solves/s measured).
+    const bool concurrent = yield_K > 0 && h->tail_concurrent && !h->capturing && yield_K <= resident && !another_launch_in_flight(h);
     if (concurrent) {
         HIP_OK(h, hipEventRecord(h->ev_fork, s));            // the records (compaction) and the empty list are in place
         HIP_OK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
