@@ -135,7 +135,8 @@ struct KParams {
 // ------------------------------------------------------------------------------------------------
 // TAIL PROMOTION (round 5).  A solve is one long dependency chain, so the last problems of a throughput launch finish on a
 // draining GPU: 0.07-0.08 s per launch whatever the batch (a quarter of a launch of 8192 problems).  The latency kernel
-// (mpc_team.hpp) runs the SAME iteration 2.3 x faster per problem -- when the GPU is empty.  So: every problem of the throughput
+// (mpc_team.hpp) runs the SAME iteration 1.6 x faster than a wavefront that has its SIMD to itself (34 vs 55 ms for a cap-length solve; ~97 ms for
+// one of four wavefronts on a full SIMD) -- when the GPU has room.  So: every problem of the throughput
 // launch counts itself as finished (CNT_FINISHED); once all but `yield_cap` problems of the launch have finished, a wavefront that
 // reaches the START OF AN INNER PROBLEM writes the state of its outer loop -- point, multipliers, penalty, tolerance, counters, the
 // position of the L-BFGS ring: the PANOC cache and the buffer are empty there -- into its workspace record, appends its problem to a
