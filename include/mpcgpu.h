@@ -218,8 +218,9 @@ int32_t mpcgpu_reserve_batch(void* handle, int32_t B);
  *       only the A/B build -DMPC_YIELD_STEP=1 looks inside an inner problem at all).
  *   MPCGPU_OPT_TAIL_WAVES  (ABI 7) wavefronts per promoted problem: 0 (default) by K as above, 2 or 4.
  *   MPCGPU_OPT_TAIL_CONCURRENT  (ABI 7) 1 (default): the continuation does not wait for the throughput launch to end -- it runs on a
- *       stream of the handle's own WHILE that launch drains (behind a one-lane gate kernel that opens when the launch starts to
- *       promote; workgroup g waits for list entry g, every wait bounded by a wall-clock limit), the launch stream waits for it at
+ *       stream of the handle's own (lowest priority) WHILE that launch drains (behind a one-lane gate kernel that opens when the
+ *       launch starts to promote and all its problems have begun; workgroup g waits for list entry g, every wait bounded by a
+ *       wall-clock limit: 0.5 s there, 60 s at the gate), the launch stream waits for it at
  *       the end of the call, and a sweep launch behind both takes what might be left (normally nothing).  Same results, bit for
  *       bit; 247 -> 237 ms at B = 8192, 146 -> 133 ms at 4096, N_hor = 40 B = 4096: 295 -> 280 ms.  0: the continuation is the launch
  *       behind the throughput kernel -- always so while the call is being captured into a hipGraph, when K exceeds what the

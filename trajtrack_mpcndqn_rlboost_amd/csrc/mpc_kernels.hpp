@@ -103,6 +103,7 @@ enum { CNT_KS = 0, CNT_KF = 1, CNT_KD = 2, CNT_VARSHAPE = 3, CNT_ROTATED = 4 /* 
        CNT_FINISHED = 8 /* problems of the running throughput launch that have written their results (tail promotion, see YIELD) */,
        CNT_YIELDED = 9 /* length of the list of problems that left the throughput launch for the latency kernel */,
        CNT_LISTED = 10 /* entries of that list that are complete (record + list slot written): FINISHED + LISTED = every problem decided */,
+       CNT_STARTED = 11 /* problems of the running throughput launch that have begun (gate of the concurrent continuation) */,
        CNT_WORDS = 12 };
 
 struct KParams {
@@ -2277,6 +2278,9 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
             // Start of an inner problem: the launch is draining when all but yield_cap of its problems have finished -- hand this one
             // to the latency kernel.  Here the state of the iteration is small (point, multipliers, penalty, tolerance, counters: the
             // PANOC cache and the L-BFGS buffer are empty) and nothing is added to the loop of the PANOC steps.
+            // (first look of this problem: it counts itself as started -- the gate of the concurrent continuation waits until every
+            //  problem of the launch has, mpc_team.hpp tail_gate_kernel)
+            if (num_outer == 1 && lane == 0) __hip_atomic_fetch_add(io.counts + CNT_STARTED, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (__hip_atomic_load(io.counts + CNT_FINISHED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= kp.yield_from) {
                 if (lane == 0) yslot = __hip_atomic_fetch_add(io.counts + CNT_YIELDED, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 yslot = __builtin_amdgcn_readfirstlane(yslot);

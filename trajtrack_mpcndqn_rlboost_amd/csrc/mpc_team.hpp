@@ -86,7 +86,7 @@ __global__ __launch_bounds__(WAVE * TW) MPC_TEAM_ATTR void solve_kernel_team(KPa
                     if (v >= 0) bb = v;
                     break;
                 }
-                if (wall_clock64() - t0 > 200000000LL) break;   // 2 s (100 MHz): give up, the sweep takes the entry
+                if (wall_clock64() - t0 > 50000000LL) break;   // 0.5 s (100 MHz): give up, the sweep takes the entry
                 __builtin_amdgcn_s_sleep(64);
             }
             claim[0] = (double)bb;
@@ -548,13 +548,17 @@ __global__ __launch_bounds__(WAVE * TW) MPC_TEAM_ATTR void solve_kernel_team(KPa
     }
 }
 
-// Holds the stream of the concurrent continuation back until the throughput launch starts to promote (FINISHED >= yield_from):
-// workgroups of the latency kernel that arrive earlier would take registers and LDS from a GPU that is still full.  One lane, asleep
-// between looks; bounded by a wall-clock limit like every wait of this scheme.
-__global__ __launch_bounds__(WAVE) void tail_gate_kernel(const int* counts, int yield_from, long long max_ticks) {
+// Holds the stream of the concurrent continuation back until the throughput launch starts to promote (FINISHED >= yield_from) AND
+// every problem of that launch has begun (STARTED = total).  Workgroups of the latency kernel that arrive earlier would take
+// registers and LDS from a GPU that is still full; and a launch of short problems is limited by the dispatch rate, not by residency:
+// its last workgroups are still waiting when it starts to promote, and teams that fill the compute units must not wait for list
+// entries those very workgroups would write (seen once before this condition existed: a tick of 2.2 s = the wall-clock limit of
+// the wait in solve_kernel_team at the time).  One lane, asleep between looks; bounded by a wall-clock limit like every wait here.
+__global__ __launch_bounds__(WAVE) void tail_gate_kernel(const int* counts, int yield_from, int total, long long max_ticks) {
     if (threadIdx.x != 0) return;
     const long long t0 = wall_clock64();
-    while (__hip_atomic_load(counts + CNT_FINISHED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < yield_from && wall_clock64() - t0 < max_ticks)
+    while ((__hip_atomic_load(counts + CNT_FINISHED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < yield_from ||
+            __hip_atomic_load(counts + CNT_STARTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total) && wall_clock64() - t0 < max_ticks)
         __builtin_amdgcn_s_sleep(127);
 }
 

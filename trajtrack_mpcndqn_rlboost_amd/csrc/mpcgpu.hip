@@ -399,10 +399,11 @@ int32_t mpcgpu_create(const mpcgpu_config* cfg, void** handle) {
     for (auto& ev : h->ev) CREATE_OK(hipEventCreate(&ev));
     {   // The side stream of the concurrent continuation must not share a hardware queue with the launch stream (packets of one
         // queue run in order: the gate would sit behind the throughput kernel and the continuation would be the launch behind it
-        // again).  The runtime hands out queues per priority class: take the highest one -- the tail of a launch IS its critical path.
+        // again).  The runtime hands out queues per priority class: take the LOWEST one -- workgroups of the latency kernel that
+        // wait for a place must never hold back workgroups of the throughput launch (same overlap as the highest class, measured).
         int least = 0, greatest = 0;
         if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
-            hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, greatest) != hipSuccess) {
+            hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, least) != hipSuccess) {
             (void)hipGetLastError();   // no priorities here: an ordinary stream (sharing a queue only costs the overlap, never the result)
             h->side = nullptr;
             CREATE_OK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
@@ -759,8 +760,8 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
     }
         io.p = nullptr; io.perm = nullptr;
         if (concurrent) {
-            // side stream: gate (opens at FINISHED >= yield_from; 60 s limit), then one workgroup per list entry
-            hipLaunchKernelGGL(tail_gate_kernel, dim3(1), dim3(WAVE), 0, h->side, (const int*)io.counts, h->kp.yield_from, 6000000000LL);
+            // side stream: gate (opens at FINISHED >= yield_from and STARTED = B; 60 s limit), then one workgroup per list entry
+            hipLaunchKernelGGL(tail_gate_kernel, dim3(1), dim3(WAVE), 0, h->side, (const int*)io.counts, h->kp.yield_from, B, 6000000000LL);
             kt_y.yield_persist = 1;
             LAUNCH_RESUME_N(yield_K, h->side)
             HIP_OK(h, hipGetLastError());
