@@ -2194,7 +2194,10 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
                 if (io.fpr) io.fpr[b] = nan;         // every optional output is written: no stale value of an earlier call survives
                 if (io.f2norm) io.f2norm[b] = nan;
                 if (io.ms) io.ms[b] = 0.0;
-                if (kp.yield_from > 0) __hip_atomic_fetch_add(io.counts + CNT_FINISHED, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (kp.yield_from > 0) {   // begun and finished at once (the counters of the tail promotion: every problem is in both)
+                    __hip_atomic_fetch_add(io.counts + CNT_STARTED, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(io.counts + CNT_FINISHED, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
             return;
         }

@@ -557,9 +557,13 @@ __global__ __launch_bounds__(WAVE * TW) MPC_TEAM_ATTR void solve_kernel_team(KPa
 __global__ __launch_bounds__(WAVE) void tail_gate_kernel(const int* counts, int yield_from, int total, long long max_ticks) {
     if (threadIdx.x != 0) return;
     const long long t0 = wall_clock64();
-    while ((__hip_atomic_load(counts + CNT_FINISHED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < yield_from ||
-            __hip_atomic_load(counts + CNT_STARTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total) && wall_clock64() - t0 < max_ticks)
+    for (;;) {
+        const int fin = __hip_atomic_load(counts + CNT_FINISHED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (fin >= yield_from && __hip_atomic_load(counts + CNT_STARTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= total) break;
+        if (fin + __hip_atomic_load(counts + CNT_LISTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= total) break;   // the launch is over
+        if (wall_clock64() - t0 >= max_ticks) break;
         __builtin_amdgcn_s_sleep(127);
+    }
 }
 
 }  // namespace mpcgpu
