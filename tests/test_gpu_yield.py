@@ -4,6 +4,7 @@ state, so EVERY output must be bitwise what the throughput kernel alone writes -
 evaluation counts, multipliers, residuals -- whatever the number of promoted problems, the kernel variant (four / two
 wavefronts per problem), the horizon, the start (cold, warm, multipliers and penalties given) and the line-search reading."""
 import os
+import time
 
 import numpy as np
 import pytest
@@ -92,8 +93,12 @@ def test_problems_that_exceed_a_reservation_are_counted_as_finished():
         bs.reserve_shape(max_static=5, max_fleet=0, max_dyn=4, var_shape=False, axis_aligned=True)
         out = dict(u=torch.empty(B, 40, dtype=torch.float64, device=dev), cost=torch.empty(B, dtype=torch.float64, device=dev),
                    status=torch.empty(B, dtype=torch.int32, device=dev), inner_it=torch.empty(B, dtype=torch.int32, device=dev))
+        t0 = time.perf_counter()
         bs.solve_device(pt, out, stream=0)
         torch.cuda.synchronize()
+        # ... and as begun: the gate of the concurrent continuation waits for every problem of the launch (a problem missing from
+        # that count would cost the gate's wall-clock limit, a minute)
+        assert time.perf_counter() - t0 < 10.0
         cap, moved = bs.last_tail_promotion(stream=0)
         bs.close()
         return {k: v.cpu().numpy() for k, v in out.items()}, moved
