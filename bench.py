@@ -54,7 +54,9 @@ Rank 0 prints ONE JSON line (contract in the task description) with extra object
   The side legs (convergent, avoidance, ordered, batch_sweep, closed_loop, counter passes, cpu_baseline) run with ONE rank only
   (world == 1) unless --full is given: an N-rank run is the headline leg and nothing else.
   cpu_baseline  -- the oracle (plain-C restatement, "port") on the host cores this process may use, on a bounded
-                   sample.
+                   sample.  Its answers double as the checker of THIS run: `cpu_baseline.parity_on_sample` compares the control
+                   sequences the timed launches wrote for the same problems (converged pairs: max |du| against the 1e-3 tolerance;
+                   agreement on which problems converge; the cap-limited rest is reported, not judged).
 """
 from __future__ import annotations
 
@@ -380,6 +382,8 @@ def main():
     gen_s = time.perf_counter() - t_gen
     side = world == 1 or args.full   # side legs: one rank (or --full)
     leg = timed_leg(p, args.steps, args.warmup)
+    # the control sequences of the first problems of the headline batch, for the parity figures next to the CPU baseline (below)
+    head_u = None if stub else out["u"][:16384].cpu().numpy().copy()
     elapsed, per_rank_s = over_ranks(leg["elapsed"])
 
     def ordered_leg(pb, steps, sv=None, o=None):
@@ -607,7 +611,7 @@ def main():
                                                else os.path.relpath(ROOFLINE_JSON, ROOT)}
             line["roofline"] = roof
         if args.cpu_seconds > 0 and world == 1 and not stub:
-            line["cpu_baseline"] = cpu_baseline(cfg, p[:16384].cpu().numpy(), args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(cfg, p[:16384].cpu().numpy(), args.cpu_seconds, gpu_u=head_u, gpu_status=leg["status"][:16384])
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
@@ -649,9 +653,11 @@ def host_cores():
                 threads_per_core=threads_per_core, usable=usable)
 
 
-def cpu_baseline(cfg, p_all, budget_s):
+def cpu_baseline(cfg, p_all, budget_s, gpu_u=None, gpu_status=None):
     """The oracle (C restatement of the same algorithm, kind = "port") on the host cores this process may use, on the
-    first S problems of the very same workload; S is calibrated so the run takes about `budget_s` seconds."""
+    first S problems of the very same workload; S is calibrated so the run takes about `budget_s` seconds.  With the GPU's control
+    sequences and statuses of the same problems (`gpu_u`, `gpu_status`: the timed launches' own outputs) the oracle's answers -- here
+    the checker -- give the parity figures of THIS run: `parity_on_sample`."""
     import oracle
     ocfg = oracle.OracleConfig.from_dict(cfg.solver_dict())
     hc = host_cores()
@@ -664,10 +670,22 @@ def cpu_baseline(cfg, p_all, budget_s):
     S = max(cores, (S // cores) * cores)
     S = min(S, len(p_all))
     t = time.perf_counter()
-    _, _, res, used = oracle.solve_batch(ocfg, p_all[:S], nthreads=cores)
+    u_cpu, _, res, used = oracle.solve_batch(ocfg, p_all[:S], nthreads=cores)
     dt = time.perf_counter() - t
     smt = hc["threads_per_core"]
-    return {"value": S / dt, "unit": "solves/s", "cores": used, "kind": "port",
+    parity = None
+    if gpu_u is not None and gpu_status is not None and len(gpu_u) >= S:
+        st_c, st_g = np.asarray(res["status"])[:S], np.asarray(gpu_status)[:S]
+        du = np.max(np.abs(np.asarray(u_cpu)[:S] - np.asarray(gpu_u)[:S]), axis=1)
+        both = (st_c == 0) & (st_g == 0)
+        parity = {"problems": int(S), "converged_on_both_sides": int(both.sum()),
+                  "max_abs_du_on_them": float(du[both].max()) if both.any() else None, "tolerance": 1e-3,
+                  "same_converged_or_not": float(np.mean((st_c == 0) == (st_g == 0))),
+                  "median_abs_du_of_the_cap_limited": float(np.median(du[~both])) if (~both).any() else None,
+                  "note": "GPU control sequences of the timed launches against the oracle's on the same problems; solves that run "
+                          "into the iteration cap are chaotic in any float64 implementation (DESIGN.md section 3): compared on the "
+                          "converged pairs, reported for the others"}
+    return {"value": S / dt, "unit": "solves/s", "cores": used, "kind": "port", "parity_on_sample": parity,
             "per_core_solves_per_s": S / dt / used,
             "host": {"logical_cpus": hc["logical_cpus"], "sched_affinity": hc["affinity"],
                      "cgroup_quota_cpus": hc["cgroup_quota_cpus"], "threads_per_core": smt,

@@ -94,3 +94,31 @@ def test_the_drivers_eight_rank_launch_is_rehearsed_with_stubbed_ranks():
         assert k not in line["config"], k             # an N-rank run is the headline leg and nothing else
     assert "roofline" not in line and "cpu_baseline" not in line
     assert wall < 120, wall
+
+
+def test_cpu_baseline_reports_parity_of_the_run_on_its_sample():
+    """bench.py's cpu_baseline leg times the oracle AND uses its answers as the checker of the run: handed the control sequences
+    of the timed launches for the same problems it reports the converged pairs, their largest difference and the agreement on
+    which problems converge.  (CPU: the oracle's own answers stand in for the GPU's, one of them moved by 1e-6.)"""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import bench
+    import oracle
+    from conftest import make_cfg
+    from trajtrack_mpcndqn_rlboost_amd import scenes
+    cfg = make_cfg(20, solver_max_inner_iterations=120, solver_max_outer_iterations=4)
+    p = scenes.make_family(cfg, 64, "passing", n_dyn=4, seed=3)["p"]
+    u, _, res, _ = oracle.solve_batch(oracle.OracleConfig.from_dict(cfg.solver_dict()), p)
+    st = np.asarray(res["status"]).copy()
+    conv = np.flatnonzero(st == 0)
+    assert len(conv) >= 2 and len(conv) < 64            # the sample holds converged AND cap-limited solves
+    u_gpu = np.array(u, copy=True)
+    u_gpu[conv[0], 3] += 1e-6
+    out = bench.cpu_baseline(cfg, p, 0.2, gpu_u=u_gpu, gpu_status=st)
+    par = out["parity_on_sample"]
+    S = par["problems"]
+    assert out["kind"] == "port" and out["value"] > 0 and 1 <= S <= 64
+    n_conv = int(np.sum(st[:S] == 0))
+    assert par["converged_on_both_sides"] == n_conv and par["same_converged_or_not"] == 1.0 and par["tolerance"] == 1e-3
+    if conv[0] < S:
+        assert abs(par["max_abs_du_on_them"] - 1e-6) < 1e-12
