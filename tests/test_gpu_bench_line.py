@@ -36,6 +36,11 @@ def test_bench_line_contract_and_in_run_counters():
     assert sum(d["config"]["status_histogram"]) == B
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    # the oracle's answers on its sample check the run they are timed beside: same problems converge, converged pairs within 1e-3
+    par = cb["parity_on_sample"]
+    assert par["problems"] >= cb["cores"] and par["tolerance"] == 1e-3 and par["same_converged_or_not"] >= 0.95
+    if par["converged_on_both_sides"]:
+        assert par["max_abs_du_on_them"] < 1e-3
     if ro["measured_in_run"]["traffic"]:
         assert shutil.which("rocprofv3") and ro["measured_in_run"]["secondary"]
         assert ro["traffic"] > 21944 * B                                   # the kernel's own cold state on top of the inputs
