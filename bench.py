@@ -78,6 +78,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VECTOR_PEAK_TF = 78.6   # MI355X vector FP64: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
 ROOFLINE_JSON = os.path.join(ROOT, "profiles", "r05_roofline_bench.json")
 SWEEP_BATCHES = (32768, 8192)   # reference batches reported next to the headline (round 1's bench batch; SURVEY.md 8(d)'s metric batch)
+PARITY_SAMPLE = 512   # problems per convergent side-leg family handed to the oracle in the cpu_baseline leg (seconds of CPU)
 
 
 def shard(total: int, rank: int, world: int):
@@ -419,6 +420,9 @@ def main():
             cleg = timed_leg(pc, min(args.steps, 5), min(args.warmup, 1), sv_s, o_s)
             c_elapsed, _ = over_ranks(cleg["elapsed"])
             side_legs[fam] = dict(leg=cleg, elapsed=c_elapsed, steps=min(args.steps, 5))
+            if not stub:   # the first problems of this family with what the timed launches wrote for them: checked in the cpu_baseline leg
+                side_legs[fam]["sample"] = dict(p=pc[:PARITY_SAMPLE].cpu().numpy().copy(), u=o_s["u"][:PARITY_SAMPLE].cpu().numpy().copy(),
+                                                status=cleg["status"][:PARITY_SAMPLE].copy())
             if hasattr(sv_s, "close"):
                 sv_s.close()
             del pc, o_s
@@ -611,7 +615,8 @@ def main():
                                                else os.path.relpath(ROOFLINE_JSON, ROOT)}
             line["roofline"] = roof
         if args.cpu_seconds > 0 and world == 1 and not stub:
-            line["cpu_baseline"] = cpu_baseline(cfg, p[:16384].cpu().numpy(), args.cpu_seconds, gpu_u=head_u, gpu_status=leg["status"][:16384])
+            line["cpu_baseline"] = cpu_baseline(cfg, p[:16384].cpu().numpy(), args.cpu_seconds, gpu_u=head_u, gpu_status=leg["status"][:16384],
+                                                family_samples={f: v["sample"] for f, v in side_legs.items() if "sample" in v})
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
@@ -653,11 +658,12 @@ def host_cores():
                 threads_per_core=threads_per_core, usable=usable)
 
 
-def cpu_baseline(cfg, p_all, budget_s, gpu_u=None, gpu_status=None):
+def cpu_baseline(cfg, p_all, budget_s, gpu_u=None, gpu_status=None, family_samples=None):
     """The oracle (C restatement of the same algorithm, kind = "port") on the host cores this process may use, on the
     first S problems of the very same workload; S is calibrated so the run takes about `budget_s` seconds.  With the GPU's control
     sequences and statuses of the same problems (`gpu_u`, `gpu_status`: the timed launches' own outputs) the oracle's answers -- here
-    the checker -- give the parity figures of THIS run: `parity_on_sample`."""
+    the checker -- give the parity figures of THIS run: `parity_on_sample`; `family_samples` (the first problems of the convergent
+    side legs with the GPU's answers) get the same check, untimed: `parity_on_families` -- there half of the solves converge."""
     import oracle
     ocfg = oracle.OracleConfig.from_dict(cfg.solver_dict())
     hc = host_cores()
@@ -673,19 +679,29 @@ def cpu_baseline(cfg, p_all, budget_s, gpu_u=None, gpu_status=None):
     u_cpu, _, res, used = oracle.solve_batch(ocfg, p_all[:S], nthreads=cores)
     dt = time.perf_counter() - t
     smt = hc["threads_per_core"]
+    def compare(u_c, st_c, u_g, st_g):
+        n = len(st_c)
+        st_c, st_g = np.asarray(st_c)[:n], np.asarray(st_g)[:n]
+        du = np.max(np.abs(np.asarray(u_c)[:n] - np.asarray(u_g)[:n]), axis=1)
+        both = (st_c == 0) & (st_g == 0)
+        far = both & (du > 1e-3)      # converged on both sides, yet apart: two local minima (a detour on either side of an obstacle;
+        near = both & ~far            # the oracle against its own 1-ulp twin shows the same: profiles/r05_fuzz_parity.txt)
+        return {"problems": int(n), "converged_on_both_sides": int(both.sum()),
+                "max_abs_du_on_them": float(du[both].max()) if both.any() else None, "tolerance": 1e-3,
+                "pairs_beyond_tolerance": int(far.sum()), "max_abs_du_of_the_pairs_within": float(du[near].max()) if near.any() else None,
+                "same_converged_or_not": float(np.mean((st_c == 0) == (st_g == 0))),
+                "median_abs_du_of_the_cap_limited": float(np.median(du[~both])) if (~both).any() else None}
     parity = None
     if gpu_u is not None and gpu_status is not None and len(gpu_u) >= S:
-        st_c, st_g = np.asarray(res["status"])[:S], np.asarray(gpu_status)[:S]
-        du = np.max(np.abs(np.asarray(u_cpu)[:S] - np.asarray(gpu_u)[:S]), axis=1)
-        both = (st_c == 0) & (st_g == 0)
-        parity = {"problems": int(S), "converged_on_both_sides": int(both.sum()),
-                  "max_abs_du_on_them": float(du[both].max()) if both.any() else None, "tolerance": 1e-3,
-                  "same_converged_or_not": float(np.mean((st_c == 0) == (st_g == 0))),
-                  "median_abs_du_of_the_cap_limited": float(np.median(du[~both])) if (~both).any() else None,
-                  "note": "GPU control sequences of the timed launches against the oracle's on the same problems; solves that run "
+        parity = compare(u_cpu[:S], np.asarray(res["status"])[:S], gpu_u, gpu_status)
+        parity["note"] = ("GPU control sequences of the timed launches against the oracle's on the same problems; solves that run "
                           "into the iteration cap are chaotic in any float64 implementation (DESIGN.md section 3): compared on the "
-                          "converged pairs, reported for the others"}
-    return {"value": S / dt, "unit": "solves/s", "cores": used, "kind": "port", "parity_on_sample": parity,
+                          "converged pairs, reported for the others")
+    families = {}
+    for fam, smp in (family_samples or {}).items():
+        u_f, _, res_f, _ = oracle.solve_batch(ocfg, smp["p"], nthreads=cores)
+        families[fam] = compare(u_f, res_f["status"], smp["u"], smp["status"])
+    return {"value": S / dt, "unit": "solves/s", "cores": used, "kind": "port", "parity_on_sample": parity, "parity_on_families": families or None,
             "per_core_solves_per_s": S / dt / used,
             "host": {"logical_cpus": hc["logical_cpus"], "sched_affinity": hc["affinity"],
                      "cgroup_quota_cpus": hc["cgroup_quota_cpus"], "threads_per_core": smt,
