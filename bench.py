@@ -56,7 +56,8 @@ Rank 0 prints ONE JSON line (contract in the task description) with extra object
   cpu_baseline  -- the oracle (plain-C restatement, "port") on the host cores this process may use, on a bounded
                    sample.  Its answers double as the checker of THIS run: `cpu_baseline.parity_on_sample` compares the control
                    sequences the timed launches wrote for the same problems (converged pairs: max |du| against the 1e-3 tolerance;
-                   agreement on which problems converge; the cap-limited rest is reported, not judged).
+                   agreement on which problems converge; the cap-limited rest is reported, not judged); `parity_on_families` does the same,
+                   untimed, for the first 512 problems of the convergent side legs, where half of the solves converge.
 """
 from __future__ import annotations
 
