@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MPCGPU_ABI_VERSION 7
+#define MPCGPU_ABI_VERSION 8
 
 /* replaces: the yaml config consumed by MpcModule.build (mpc_generator.py:151-158, config/mpc_default.yaml:7-55)
  * plus the SolverConfiguration of mpc_generator.py:285-293 (opengen defaults quoted there). */
@@ -135,7 +135,9 @@ int32_t mpcgpu_last_tail_timing(void* handle, double* main_ms, double* tail_ms);
  * psi(u) in the Lipschitz update; the latency kernel reports the counts of the SEQUENTIAL algorithm, not its speculative
  * evaluations).  Waits for the last solve (the event recorded behind it; and for `stream`, if it is another one).  When the last
  * solve was CAPTURED into a hipGraph there is no such event: pass the stream the graph is launched on -- that stream, and no
- * other, is synchronised (never the whole device); calling this inside a capture fails with -6.  HOST output pointers. */
+ * other, is synchronised (never the whole device); calling this inside a capture fails with -6.  MPCGPU_STREAM_OWN after a solve
+ * that was captured on a stream of the caller's cannot name the right stream: the whole device is drained then (which fails with
+ * -6 while any stream of the device is being captured) rather than stale counters returned.  HOST output pointers. */
 int32_t mpcgpu_last_eval_counts(void* handle, int32_t B, int32_t* n_psi, int32_t* n_grad, void* stream);
 
 /* Batch-wide maxima of active entries seen by the last solve / cost_grad call: static obstacles, fleet
@@ -172,6 +174,15 @@ int32_t mpcgpu_reserve_batch(void* handle, int32_t B);
  *       0 (default)  the last trial point (tau = 2^-10) becomes the iterate -- the effective behaviour of the published
  *                    PANOC engine, whose `tau = 0; u <- u_half` fallback is overwritten by the copy of u_plus into u
  *       1            tau = 0: the point u - gamma*fpr is evaluated and taken
+ *   MPCGPU_OPT_PENALTY_STALL  (ABI 8) when the outer loop KEEPS the penalty c instead of multiplying it by penalty_update (the
+ *       "penalty stall criterion" of the ALM / PM loop; mpc_generator.py:285-293 configures the solver this rule belongs to):
+ *       0 (default)  "either": in the first outer iteration, or when ||y+ - y|| shrank by suff_decrease OR ||F2|| did -- the
+ *                    published engine's `is_penalty_stall_criterion` as recalled (iteration == 0 || (n1 > 0 && dy+ <= theta dy + eps)
+ *                    || (n2 > 0 && ||F2+|| <= theta ||F2|| + eps)).  While the acceleration constraints are inactive y+ = y = 0, the
+ *                    first test holds and the penalty stays at init_penalty.
+ *       1            "both": only when both shrank (the default of ABI <= 7 builds).
+ *     Converged answers of the two readings are identical where neither ever raises the penalty and differ by up to ~5e-3 in u
+ *     elsewhere (profiles/r06_stall_rule.txt); the oracle has the same switch (oracle/mpc_oracle.h: stall_rule).
  *   MPCGPU_OPT_PAIRING  problems per wavefront of the solve kernel:
  *       -1 (default) automatic: the faster layout as measured on the MI355X -- today one problem per wavefront for every
  *                    horizon
@@ -216,7 +227,9 @@ int32_t mpcgpu_reserve_batch(void* handle, int32_t B);
  *       read back, the call stays capturable.  The reference has no counterpart.
  *   MPCGPU_OPT_TAIL_POLL  (ABI 7) PANOC steps between two looks at the launch's finished-counter (a power of two, default 16;
  *       only the A/B build -DMPC_YIELD_STEP=1 looks inside an inner problem at all).
- *   MPCGPU_OPT_TAIL_WAVES  (ABI 7) wavefronts per promoted problem: 0 (default) by K as above, 2 or 4.
+ *   MPCGPU_OPT_TAIL_WAVES  (ABI 7) wavefronts per promoted problem: 0 (default) by K as above, 2 or 4.  A TEST KNOB with a side effect:
+ *       a non-zero value also fixes the team width of the ordinary latency-kernel path for batches between two and four problems
+ *       per compute unit (mpcgpu_last_latency_kernel reports what ran).  Results do not depend on it (bitwise).
  *   MPCGPU_OPT_TAIL_CONCURRENT  (ABI 7) 1 (default): the continuation does not wait for the throughput launch to end -- it runs on a
  *       stream of the handle's own (lowest priority) WHILE that launch drains (behind a one-lane gate kernel that opens when the
  *       launch starts to promote and all its problems have begun; workgroup g waits for list entry g, every wait bounded by a
@@ -226,11 +239,15 @@ int32_t mpcgpu_reserve_batch(void* handle, int32_t B);
  *       behind the throughput kernel -- always so while the call is being captured into a hipGraph, when K exceeds what the
  *       throughput kernel keeps resident, and while a launch of ANOTHER handle of this process is in flight on the device (seen by
  *       its end-of-call event; two handles that keep two streams busy: the other launch fills the drain, and workgroups of the
- *       latency kernel must not hold compute units that problems of a launch are waiting for).
+ *       latency kernel must not hold compute units that problems of a launch are waiting for).  That test is race-free between the
+ *       THREADS of one process (a handle counts as in flight from the moment its solve call begins).  It cannot see other PROCESSES
+ *       that share the GPU, graph replays of another handle, or foreign kernels of the caller on other streams: those cost time only
+ *       (the lowest-priority side stream waits; every wait is bounded and a sweep launch behind the throughput kernel finishes what is
+ *       left) -- tests/test_gpu_foreign_work.py -- and a process that shares its GPU that way sets this option to 0.
  */
 enum { MPCGPU_OPT_LINESEARCH_FALLBACK = 1, MPCGPU_OPT_PAIRING = 2, MPCGPU_OPT_TEAM_BATCH = 3, MPCGPU_OPT_ORDER = 4,
        MPCGPU_OPT_LINEAR_TABLES = 5, MPCGPU_OPT_TAIL_PROMOTION = 6, MPCGPU_OPT_TAIL_POLL = 7, MPCGPU_OPT_TAIL_WAVES = 8,
-       MPCGPU_OPT_TAIL_CONCURRENT = 9 };
+       MPCGPU_OPT_TAIL_CONCURRENT = 9, MPCGPU_OPT_PENALTY_STALL = 10 };
 int32_t mpcgpu_set_option(void* handle, int32_t option, double value);
 
 /* Register-allocation variant the last solve call was launched with: 3 (148 / 168 VGPRs) or 4 wavefronts per SIMD

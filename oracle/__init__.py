@@ -41,7 +41,7 @@ class OracleConfig(C.Structure):
         ("init_penalty", C.c_double), ("penalty_update", C.c_double), ("tol_update", C.c_double),
         ("suff_decrease", C.c_double),
         ("max_inner", C.c_int32), ("max_outer", C.c_int32), ("lbfgs_mem", C.c_int32), ("ls_fallback", C.c_int32),
-        ("lbfgs_gram", C.c_int32), ("_reserved", C.c_int32),
+        ("lbfgs_gram", C.c_int32), ("stall_rule", C.c_int32),
         ("max_duration_us", C.c_double),
     ]
 
@@ -49,7 +49,7 @@ class OracleConfig(C.Structure):
     def from_dict(cls, d: dict) -> "OracleConfig":
         cfg = cls()
         for name, _ in cls._fields_:
-            setattr(cfg, name, d.get(name, 0) if name in ("ls_fallback", "lbfgs_gram", "_reserved") else d[name])
+            setattr(cfg, name, d.get(name, 0) if name in ("ls_fallback", "lbfgs_gram", "stall_rule") else d[name])
         return cfg
 
 

@@ -739,10 +739,13 @@ static int32_t solve_impl(const mpc_oracle_config* cfg, const double* p, const d
         const int crit2 = (n2 == 0) || (f2_norm_plus <= cfg->delta_tol + SMALL_EPSILON);
         const int crit3 = s->akkt_tol <= cfg->tol + SMALL_EPSILON;
         if (crit1 && crit2 && crit3) { status = inner_status; break; }
-        /* penalty update unless first iteration or sufficient decrease of both infeasibilities */
+        /* penalty update unless the stall criterion holds: first iteration, or sufficient decrease of EITHER infeasibility
+         * (stall_rule = 0: the published crate as recalled) / of BOTH (stall_rule = 1: SURVEY.md Appendix B) */
+        const int alm_shrank = (n1 > 0) && dy_norm_plus <= cfg->suff_decrease * dy_norm + SMALL_EPSILON;
+        const int pm_shrank = (n2 > 0) && f2_norm_plus <= cfg->suff_decrease * f2_norm + SMALL_EPSILON;
         const int stall = (iteration == 0) ||
-                          (((n1 == 0) || dy_norm_plus <= cfg->suff_decrease * dy_norm + SMALL_EPSILON) &&
-                           ((n2 == 0) || f2_norm_plus <= cfg->suff_decrease * f2_norm + SMALL_EPSILON));
+                          (cfg->stall_rule == 1 ? ((n1 == 0 || alm_shrank) && (n2 == 0 || pm_shrank))
+                                                : (alm_shrank || pm_shrank));
         if (!stall) c *= cfg->penalty_update;
         set_akkt_tolerance(s, fmax(s->akkt_tol * cfg->tol_update, cfg->tol));
         iteration++;

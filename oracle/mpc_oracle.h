@@ -60,7 +60,10 @@ typedef struct mpc_oracle_config {
                               the same operator (what the GPU kernel evaluates, mpc_kernels.hpp PanocLbfgs::direction: identical in
                               exact arithmetic, rounded differently); 2 = two-loop drives the iteration, the Gram form is evaluated
                               beside it and the largest relative deviation is reported in mpc_oracle_result.lbfgs_dev */
-    int32_t _reserved;
+    int32_t stall_rule;    /* when the penalty is kept ("penalty stall criterion"): 0 = in the first outer iteration or when EITHER
+                              infeasibility shrank by theta [the published crate's is_penalty_stall_criterion as recalled:
+                              iteration == 0 || (n1 > 0 && dy+ <= theta dy + eps) || (n2 > 0 && ||F2+|| <= theta ||F2|| + eps)];
+                              1 = only when BOTH shrank (the reading of rounds 1-5) */
     double max_duration_us; /* 5e6; <=0 disables the wall-clock test */
 } mpc_oracle_config;
 

@@ -145,7 +145,12 @@ def solve(cfg: OracleConfig, p, u0=None, y0=None, c0=None):
         if (outer > 1 and dy <= c * cfg.delta_tol + eps) and f2 <= cfg.delta_tol + eps and akkt_tol <= cfg.tol + eps:
             status = inner_status
             break
-        if outer > 1 and not (dy <= cfg.suff_decrease * dy_prev + eps and f2 <= cfg.suff_decrease * f2_prev + eps):
+        # penalty stall criterion: the penalty is kept in the first outer iteration and when either (stall_rule 0: the published
+        # engine as recalled) or both (stall_rule 1: SURVEY.md Appendix B) infeasibilities shrank by suff_decrease
+        alm_shrank = dy <= cfg.suff_decrease * dy_prev + eps
+        pm_shrank = f2 <= cfg.suff_decrease * f2_prev + eps
+        stalled = (alm_shrank and pm_shrank) if cfg.stall_rule == 1 else (alm_shrank or pm_shrank)
+        if outer > 1 and not stalled:
             c *= cfg.penalty_update
         akkt_tol = max(akkt_tol * cfg.tol_update, cfg.tol)
         dy_prev, f2_prev, y = dy, f2, y_plus.copy()

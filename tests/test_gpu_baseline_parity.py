@@ -225,6 +225,47 @@ def test_linesearch_fallback_switch_changes_the_iteration_identically_on_both_si
     assert np.mean(differs == differs_o) > 0.9                  # ... in the same problems
 
 
+def test_penalty_stall_switch_changes_the_iteration_identically_on_both_sides():
+    """The two readings of the ALM penalty-stall rule (yaml key solver_penalty_stall, MPCGPU_OPT_PENALTY_STALL; DESIGN.md section
+    3).  "Passing" family: the acceleration constraints stay inactive in most problems (y+ = y = 0), so under "either" the penalty
+    keeps its initial value 10 where "both" multiplies it by 5 per outer iteration whenever ||F2|| did not shrink.  Each GPU reading
+    must follow ITS oracle reading (converged pairs within the north-star tolerance, the same outer-iteration counts and -- through
+    them -- the same penalty path), and the switch must really change the iteration, in the same problems on both sides."""
+    N, B = 20, 384
+    out = {}
+    sc = None
+    for stall in ("either", "both"):
+        cfg = make_cfg(N, solver_penalty_stall=stall)
+        if sc is None:
+            sc = scenes.make_batch(cfg, B, n_dyn=8, seed=4321, dyn_clearance=0.1, box_clearance=0.3)
+        ocfg = oracle_cfg(cfg)
+        assert ocfg.stall_rule == (1 if stall == "both" else 0)
+        bs = BatchSolver(cfg)
+        res = bs.solve(sc["p"])
+        uo, _, ro, _ = oracle.solve_batch(ocfg, sc["p"])
+        both = (res.status == 0) & (ro["status"] == 0)
+        du = np.max(np.abs(res.solution - uo), axis=1)
+        print(f"\n[{stall}] converged GPU {np.sum(res.status == 0)} / oracle {np.sum(ro['status'] == 0)} / both {both.sum()} of {B}; |du|inf on both: max "
+              f"{du[both].max():.2e}; mean outer GPU {res.num_outer_iterations.mean():.2f} oracle {ro['outer_iters'].mean():.2f}; mean inner GPU "
+              f"{res.num_inner_iterations.mean():.0f} oracle {ro['inner_iters'].mean():.0f}; final penalty (oracle) median {np.median(ro['penalty']):.0f}")
+        assert both.sum() >= B // 5 and du[both].max() <= U_TOL
+        assert np.array_equal(res.num_outer_iterations[both], ro["outer_iters"][both])
+        assert np.mean((res.status == 0) == (ro["status"] == 0)) >= 0.9
+        out[stall] = (res, uo, ro)
+        bs.close()
+    differs = np.max(np.abs(out["either"][0].solution - out["both"][0].solution), axis=1) > 1e-6
+    differs_o = np.max(np.abs(out["either"][1] - out["both"][1]), axis=1) > 1e-6
+    print(f"\nthe rule changes the answer in {differs.sum()}/{B} problems on the GPU, {differs_o.sum()}/{B} in the oracle")
+    assert differs.sum() >= B // 10 and differs_o.sum() >= B // 10     # the switch is exercised ...
+    assert np.mean(differs == differs_o) > 0.9                         # ... in the same problems
+    # where neither reading ever raises the penalty the two are the same iteration: identical bits
+    same = ~differs
+    assert same.sum() >= B // 10
+    assert np.array_equal(out["either"][0].num_inner_iterations[same], out["both"][0].num_inner_iterations[same])
+    # under "either" the penalty of the oracle stays at its initial value in most problems of this family
+    assert np.median(out["either"][2]["penalty"]) == 10.0 and np.median(out["both"][2]["penalty"]) > 10.0
+
+
 @pytest.mark.parametrize("N,B", [(20, 512), (40, 128)])
 def test_lbfgs_in_lds_build_is_bitwise_equal_to_the_product_build(N, B):
     """north_star words the layout as "L-BFGS memory staged in LDS"; the product build keeps it in the workspace record

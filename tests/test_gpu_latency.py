@@ -32,9 +32,9 @@ FAMILIES = {
 
 
 @pytest.mark.parametrize("family", list(FAMILIES))
-@pytest.mark.parametrize("fallback", ["last_trial", "half_step"])
-def test_latency_kernel_is_bitwise_equal_to_the_throughput_kernel(family, fallback):
-    cfg = make_cfg(20, solver_linesearch_fallback=fallback)
+@pytest.mark.parametrize("fallback,stall", [("last_trial", "either"), ("half_step", "either"), ("last_trial", "both"), ("half_step", "both")])
+def test_latency_kernel_is_bitwise_equal_to_the_throughput_kernel(family, fallback, stall):
+    cfg = make_cfg(20, solver_linesearch_fallback=fallback, solver_penalty_stall=stall)
     B = 40
     sc = scenes.make_batch(cfg, B, seed=97, **FAMILIES[family])
     fast = BatchSolver(cfg)                       # library rule: latency kernel for small batches
@@ -45,7 +45,7 @@ def test_latency_kernel_is_bitwise_equal_to_the_throughput_kernel(family, fallba
         _same(a, b)
         ea, eb = fast.last_eval_counts(B), seq.last_eval_counts(B)
         assert np.array_equal(ea[0], eb[0]) and np.array_equal(ea[1], eb[1])
-    print(f"\n[{family}, {fallback}] statuses {np.bincount(a.status, minlength=3).tolist()}, inner iterations "
+    print(f"\n[{family}, {fallback}, {stall}] statuses {np.bincount(a.status, minlength=3).tolist()}, inner iterations "
           f"{a.num_inner_iterations.min()}..{a.num_inner_iterations.max()}")
     fast.close(); seq.close()
 

@@ -59,10 +59,13 @@ def test_promoted_problems_finish_bitwise_like_the_throughput_kernel(N, B, fam):
     print(f"\nN_hor {N}, B {B}, {fam}: " + "; ".join(figures))
 
 
-def test_starts_multipliers_penalties_and_the_other_linesearch_reading():
+def test_starts_multipliers_penalties_and_the_other_readings():
+    """Both line-search fallbacks x both penalty-stall rules: the promotion carries the penalty and the
+    infeasibility norms of the outer loop, so both rules must survive the move to the latency kernel bit for bit."""
     B = 4096
-    for fb in ("last_trial", "half_step"):
-        cfg = make_cfg(20, solver_linesearch_fallback=fb, solver_max_inner_iterations=120, solver_max_outer_iterations=6)
+    for fb, stall in (("last_trial", "either"), ("half_step", "both"), ("last_trial", "both"), ("half_step", "either")):
+        cfg = make_cfg(20, solver_linesearch_fallback=fb, solver_penalty_stall=stall, solver_max_inner_iterations=120,
+                       solver_max_outer_iterations=6)
         sc = scenes.make_batch(cfg, B, n_dyn=8, seed=17)     # benchmark family: the fallback is reached in ~10 % of the steps
         rng = np.random.default_rng(3)
         u0 = np.tile([0.6, 0.1], (B, 20)) + rng.normal(0, 0.05, (B, 40))

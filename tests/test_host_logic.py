@@ -106,7 +106,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     for sym in declared:
         assert hasattr(lib, sym), sym
     lib.mpcgpu_abi_version.restype = ctypes.c_int32
-    assert lib.mpcgpu_abi_version() == 7
+    assert lib.mpcgpu_abi_version() == 8
 
 
 def test_option_numbers_of_the_ctypes_side_match_the_header():

@@ -2,7 +2,8 @@
 """Fuzz run (GPU box; test tooling -- it imports the oracle): random horizons, obstacle / robot counts MIXED inside one batch, scene
 families, penalties and multipliers; the HIP path against the CPU oracle on psi / f / grad psi / F1 / F2 (1e-9 relative) and on short
 tracked solves (same iteration counts, |du| small).  Also perturbs the tables the scenes never produce: rotated and time-varying
-ellipses, rotated static polygons, terminal weights.  usage: python tests/tools/fuzz_parity.py [trials = 40] [seed = 0] [full-solve trials = 0]"""
+ellipses, rotated static polygons, terminal weights.  The two readings of the ALM penalty-stall rule (solver_penalty_stall) alternate
+from trial to trial, on both sides.  usage: python tests/tools/fuzz_parity.py [trials = 40] [seed = 0] [full-solve trials = 0]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -71,7 +72,9 @@ for trial in range(trials):
                 bad.append(("cost_grad", trial, N, i, k, e))
     bs.close()
     # short tracked solve
-    cfgk = MpcConfig(N_hor=N, solver_max_inner_iterations=int(rng.integers(3, 12)), solver_max_outer_iterations=2)
+    stall = ("either", "both")[trial % 2]
+    # three outer iterations: the stall rule acts from the second one on
+    cfgk = MpcConfig(N_hor=N, solver_max_inner_iterations=int(rng.integers(3, 12)), solver_max_outer_iterations=3, solver_penalty_stall=stall)
     bs = BatchSolver(cfgk, latency_batch=int(rng.choice([0, 1 << 20])))
     u0 = np.tile([0.6, 0.1], (B, N)) + rng.uniform(-0.05, 0.05, (B, 2 * N))
     res = bs.solve(p, u0)
@@ -83,7 +86,7 @@ for trial in range(trials):
         bad.append(("solve", trial, N, int(np.argmax(du)), "du", float(du.max()), bool(same_it)))
     shape = bs.last_shape()
     bs.close()
-    print(f"trial {trial:3d} N {N:2d} mode {mode} latency {shape['latency_kernel']} max_dyn {shape['max_dyn']} max_static {shape['max_static']} "
+    print(f"trial {trial:3d} N {N:2d} mode {mode} stall {stall} latency {shape['latency_kernel']} max_dyn {shape['max_dyn']} max_static {shape['max_static']} "
           f"max_fleet {shape['max_fleet']}: cost/grad ok so far {not [b for b in bad if b[0] == 'cost_grad']}, solve du median {np.median(du):.1e} max {du.max():.1e} "
           f"same iteration counts {same_it}", flush=True)
 
@@ -94,7 +97,8 @@ worst_du = 0.0
 for trial in range(n_full):
     rng = np.random.default_rng(seed0 * 1000 + 500 + trial)
     N = int(rng.choice([20, 20, 40]))
-    cfg = MpcConfig(N_hor=N)
+    stall = ("either", "both")[trial % 2]
+    cfg = MpcConfig(N_hor=N, solver_penalty_stall=stall)
     parts = []
     for sub in range(3):
         n_dyn = int(rng.integers(1, cfg.Ndynobs + 1)); n_other = int(rng.integers(0, 4))
@@ -119,7 +123,7 @@ for trial in range(n_full):
     if ok.any(): worst_du = max(worst_du, float(du[ok].max()))
     far += int((ok & (du > 1e-3)).sum())
     if ok.any() and du[ok].max() > 1e-3: bad.append(("full", trial, N, int(np.argmax(np.where(ok, du, 0))), float(du[ok].max())))
-    print(f"full {trial:3d} N {N}: converged on both {int(ok.sum())}/{B}, max |du| on them {du[ok].max() if ok.any() else 0:.1e}, same converged/not {int(((so == 0) == (sg == 0)).sum())}/{B}", flush=True)
+    print(f"full {trial:3d} N {N} stall {stall}: converged on both {int(ok.sum())}/{B}, max |du| on them {du[ok].max() if ok.any() else 0:.1e}, same converged/not {int(((so == 0) == (sg == 0)).sum())}/{B}", flush=True)
 if n_full:
     print(f"full solves: {both} of {total} converged on both sides, {far} of them farther apart than 1e-3 (worst {worst_du:.2e}), agreement on which converge {agree / total:.3f}")
     print(f"oracle vs 1-ulp oracle on the same problems: {self_both} converged on both, {self_far} of them farther apart than 1e-3")

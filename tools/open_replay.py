@@ -18,9 +18,11 @@ This script is the missing link.  It never runs on the GPU box and imports nothi
 
   step 2 (any machine with this repository and a C compiler; no GPU, no OpEn):
       python tools/open_replay.py compare open_replay_navi_default.npz
-    solves the same vectors with the oracle (`oracle.solve_batch`, both readings of the line-search fallback) and prints, per
-    fixture: agreement of the exit statuses, of the outer / inner iteration counts, max |u_open - u_oracle| over the calls that
-    converge on both sides, and the first call whose iteration counts differ.  Equal iteration counts on the short solves and
+    solves the same vectors with the oracle (`oracle.solve_batch`) under the 2 x 2 matrix of readings that cannot be checked here
+    (line-search fallback last_trial | half_step  x  penalty stall rule either | both) and prints, per reading and fixture:
+    agreement of the exit statuses, of the outer / inner iteration counts, of the FINAL PENALTY (the direct witness of the stall
+    rule), max |u_open - u_oracle| over the calls that converge on both sides, and the first call whose iteration counts differ;
+    the last line names the reading that matches the recording best.  Equal iteration counts on the short solves and
     |du| at rounding level is what "parity green" would mean; a systematic difference in the counts points at the constant or the
     rule in oracle/mpc_oracle.c that misreads the crate (DESIGN.md section 3 lists the readings that could not be checked).
 """
@@ -109,24 +111,43 @@ def compare(args):
     vectors = parameter_vectors()
     assert [l for l, _ in vectors] == labels and [len(p) for _, p in vectors] == counts, "the fixtures differ from the ones that were replayed"
     print(f"{args.file}: opengen {d['opengen_version']}, {d['config']}, {sum(counts)} calls")
+    # The readings of the published algorithm that could not be checked against the crate where this repository was built
+    # (DESIGN.md section 3): what follows a line search without acceptance x when the ALM loop keeps the penalty.  The recording
+    # decides: the final PENALTY of every call is in it (a direct witness of the stall rule: 10 * 5^k), and so are the counts.
+    scores = {}
     for fallback in ("last_trial", "half_step"):
-        cfg = mod.MpcConfig(solver_linesearch_fallback=fallback)
-        ocfg = oracle.OracleConfig.from_dict(cfg.solver_dict())
-        o = 0
-        print(f"-- oracle reading of the line search without acceptance: {fallback}")
-        for (label, P), n in zip(vectors, counts):
-            u, _, res, _ = oracle.solve_batch(ocfg, P)
-            sl = slice(o, o + n); o += n
-            st_o, st_r = np.asarray(res["status"]), d["exit_status"][sl].astype(int)
-            both = (st_o == 0) & (st_r == 0)
-            du = np.max(np.abs(u - d["solution"][sl]), axis=1)
-            inner_eq = np.asarray(res["inner_iters"]) == d["num_inner_iterations"][sl].astype(int)
-            outer_eq = np.asarray(res["outer_iters"]) == d["num_outer_iterations"][sl].astype(int)
-            first = int(np.argmin(inner_eq)) if not inner_eq.all() else -1
-            print(f"  {label:28s} n {n:4d}  same status {np.mean(st_o == st_r):.3f}  converged on both {int(both.sum()):4d}  "
-                  f"max|du| there {du[both].max() if both.any() else float('nan'):.3e}  same outer count {outer_eq.mean():.3f}  "
-                  f"same inner count {inner_eq.mean():.3f}" + (f"  first different call {first}: inner {int(res['inner_iters'][first])} vs "
-                                                                 f"{int(d['num_inner_iterations'][sl][first])}" if first >= 0 else ""))
+        for stall in ("either", "both"):
+            cfg = mod.MpcConfig(solver_linesearch_fallback=fallback, solver_penalty_stall=stall)
+            ocfg = oracle.OracleConfig.from_dict(cfg.solver_dict())
+            o = 0
+            print(f"-- oracle reading: line search without acceptance = {fallback}, penalty stall rule = {stall}")
+            tot = dict(n=0, status=0, inner=0, outer=0, penalty=0)
+            for (label, P), n in zip(vectors, counts):
+                u, _, res, _ = oracle.solve_batch(ocfg, P)
+                sl = slice(o, o + n); o += n
+                st_o, st_r = np.asarray(res["status"]), d["exit_status"][sl].astype(int)
+                both = (st_o == 0) & (st_r == 0)
+                du = np.max(np.abs(u - d["solution"][sl]), axis=1)
+                inner_eq = np.asarray(res["inner_iters"]) == d["num_inner_iterations"][sl].astype(int)
+                outer_eq = np.asarray(res["outer_iters"]) == d["num_outer_iterations"][sl].astype(int)
+                pen_r = np.asarray(d["penalty"][sl], dtype=float)
+                pen_eq = np.isclose(np.asarray(res["penalty"]), pen_r, rtol=1e-9) | ~np.isfinite(pen_r) | (pen_r == 0.0)
+                first = int(np.argmin(inner_eq)) if not inner_eq.all() else -1
+                tot["n"] += n; tot["status"] += int(np.sum(st_o == st_r)); tot["inner"] += int(inner_eq.sum())
+                tot["outer"] += int(outer_eq.sum()); tot["penalty"] += int(pen_eq.sum())
+                print(f"  {label:28s} n {n:4d}  same status {np.mean(st_o == st_r):.3f}  converged on both {int(both.sum()):4d}  "
+                      f"max|du| there {du[both].max() if both.any() else float('nan'):.3e}  same outer count {outer_eq.mean():.3f}  "
+                      f"same inner count {inner_eq.mean():.3f}  same final penalty {pen_eq.mean():.3f}"
+                      + (f"  first different call {first}: inner {int(res['inner_iters'][first])} vs "
+                         f"{int(d['num_inner_iterations'][sl][first])}" if first >= 0 else ""))
+            scores[(fallback, stall)] = tot
+    print("== summary over all calls (fraction equal to the recording)")
+    for (fallback, stall), t in scores.items():
+        print(f"   {fallback:10s} x {stall:6s}: status {t['status'] / t['n']:.3f}  outer count {t['outer'] / t['n']:.3f}  inner count "
+              f"{t['inner'] / t['n']:.3f}  final penalty {t['penalty'] / t['n']:.3f}")
+    best = max(scores, key=lambda k: (scores[k]["inner"] + scores[k]["outer"] + scores[k]["penalty"], scores[k]["status"]))
+    print(f"== reading whose iteration counts and penalties match the recording best: solver_linesearch_fallback={best[0]}, "
+          f"solver_penalty_stall={best[1]}")
 
 
 def main():

@@ -223,7 +223,7 @@ def show(derived_path, bench_path=None):
 if __name__ == "__main__":
     cmd = sys.argv[1] if len(sys.argv) > 1 else "show"
     if cmd == "rebuild":
-        raw = os.path.join(ROOT, "profiles", "raw_r03")
+        raw = os.path.join(ROOT, "profiles", "raw_r05")
         out = os.path.join(ROOT, "profiles", "r05_roofline_bench.json")
         a = sys.argv[2:]
         while a:

@@ -32,6 +32,10 @@ SOLVER_DEFAULTS: Dict[str, Any] = dict(
     # 'last_trial' = the tau = 2^-10 trial point becomes the iterate (effective behaviour of the published engine),
     # 'half_step'  = tau = 0, the point u - gamma*fpr is evaluated and taken.  DESIGN.md section 3.
     solver_linesearch_fallback="last_trial",
+    # When the ALM / PM loop keeps the penalty instead of multiplying it by solver_penalty_update_factor [OpEn; same caveat]:
+    # 'either' = first outer iteration, or ||y+ - y|| OR ||F2|| shrank by solver_sufficient_decrease (the published engine's
+    #            is_penalty_stall_criterion as recalled), 'both' = only when both shrank.  DESIGN.md section 3.
+    solver_penalty_stall="either",
 )
 
 REQUIRED_KEYS = ("ts", "N_hor", "nu", "ns", "nq", "Nother", "Nstcobs", "nstcobs", "Ndynobs", "ndynobs",
@@ -108,7 +112,8 @@ class MpcConfig:
             max_inner=int(self.solver_max_inner_iterations), max_outer=int(self.solver_max_outer_iterations),
             lbfgs_mem=int(self.solver_lbfgs_memory), device=int(device),
             max_duration_us=float(self.solver_max_duration_micros),
-            ls_fallback=1 if self.solver_linesearch_fallback == "half_step" else 0)
+            ls_fallback=1 if self.solver_linesearch_fallback == "half_step" else 0,
+            stall_rule=1 if self.solver_penalty_stall == "both" else 0)
 
 
 # The reference's class name (src/util/mpc_config.py:8): same constructor, same attribute semantics.

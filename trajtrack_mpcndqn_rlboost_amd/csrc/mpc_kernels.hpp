@@ -110,6 +110,7 @@ struct KParams {
     int N, Nother, Nstcobs, Ndynobs, np, mem;
     int max_inner, max_outer;
     int ls_fallback;  // line search without acceptance after 10 halvings: 0 = keep the last trial point, 1 = tau = 0
+    int stall_rule;   // when the penalty is kept: 0 = EITHER infeasibility shrank by theta (the published engine), 1 = BOTH did
     double ts, inv_ts;
     double vmin, vmax, wmax, amin, amax, aamax;
     double W2, social, fleetw;
@@ -2155,11 +2156,18 @@ __device__ __forceinline__ bool alm_exit(const Ctx& cx, const KParams& kp, int a
     const bool crit3 = akkt_tol <= kp.tol + KC(K_EPS);
     return crit1 && crit2 && crit3;
 }
-// the penalty stays when this is the first outer iteration or both infeasibilities shrank by the factor theta
+// The penalty stays ("stall criterion") in the first outer iteration and when the infeasibility shrank by the factor theta.  Two
+// readings [OpEn; cannot be checked against the crate here, DESIGN.md section 3], option MPCGPU_OPT_PENALTY_STALL:
+//   stall_rule = 0 "either" (default): ||y+ - y|| OR ||F2|| shrank -- `is_penalty_stall_criterion` of the published engine as
+//       recalled: iteration == 0 || (n1 > 0 && dy+ <= theta dy + eps) || (n2 > 0 && ||F2+|| <= theta ||F2|| + eps).  With inactive
+//       acceleration constraints y+ = y = 0, so 0 <= theta * 0 + eps holds and the penalty keeps its initial value 10.
+//   stall_rule = 1 "both": both shrank (rounds 1-5 of this build).
+// n1 = 2 N_hor > 0 and n2 = Ndynobs > 0 for every configuration the library accepts.
 __device__ __forceinline__ bool alm_stalled(const Ctx& cx, const KParams& kp, int alm_iteration, double dy_norm_plus, double dy_norm,
                                             double f2_norm_plus, double f2_norm) {
-    return alm_iteration == 0 || (dy_norm_plus <= kp.suff_decrease * dy_norm + KC(K_EPS) &&
-                                  f2_norm_plus <= kp.suff_decrease * f2_norm + KC(K_EPS));
+    const bool alm_shrank = dy_norm_plus <= kp.suff_decrease * dy_norm + KC(K_EPS);
+    const bool pm_shrank = f2_norm_plus <= kp.suff_decrease * f2_norm + KC(K_EPS);
+    return alm_iteration == 0 || (kp.stall_rule == 1 ? (alm_shrank && pm_shrank) : (alm_shrank || pm_shrank));
 }
 
 // The whole ALM / PANOC solve of problem P::problem() on the lanes P gives it.  `lds` is the workgroup's dynamic LDS.

@@ -66,6 +66,7 @@ struct Handle {
     hipStream_t side = nullptr;                      // stream of the concurrent continuation
     hipEvent_t ev_fork = nullptr, ev_join = nullptr; // launch stream -> side (records written), side -> launch stream (promoted problems solved)
     bool last_concurrent = false;
+    bool in_call = false;    // inside solve_common right now (guarded by g_handles_mu, see another_launch_in_flight)
     int trace_cap = 0;  // -DMPC_TRACE builds: PANOC steps recorded per problem (0 = tracing off)
     // mpcgpu_reserve_shape: upper bounds of active rows promised by the caller -> no count read-back before the launch
     bool capturing = false;  // the launch stream of the current call is being captured into a hipGraph: no event records
@@ -76,18 +77,33 @@ struct Handle {
     std::unordered_map<const void*, int> lds_attr;  // kernel -> largest dynamic-LDS size opted into (hipFuncSetAttribute once, not per launch)
 };
 
-// Handles of this process (mpcgpu_create / mpcgpu_destroy): a solve call looks at the others' end-of-call events to see whether
-// another launch is in flight on its device (the concurrent continuation is for ONE launch at a time, see solve_common).
+// Handles of this process (mpcgpu_create / mpcgpu_destroy): a solve call looks at the others to see whether another launch is in
+// flight on its device (the concurrent continuation is for ONE launch at a time, see solve_common).  "In flight" = the other
+// handle is INSIDE a solve call right now (`in_call`, set and cleared under the mutex: two threads that enter their calls together
+// both see the other one and both keep the continuation behind their launch -- never both beside it), or its end-of-call event
+// has not completed yet.  Other PROCESSES on the same GPU and graph replays of another handle are invisible here: such users set
+// MPCGPU_OPT_TAIL_CONCURRENT = 0 (include/mpcgpu.h); the cost of not doing so is time (a starved side stream), never results.
 std::mutex g_handles_mu;
 std::vector<Handle*> g_handles;
 
+struct InCall {   // marks the handle as inside solve_common for the lifetime of the object
+    Handle* h;
+    explicit InCall(Handle* h_) : h(h_) { std::lock_guard<std::mutex> lock(g_handles_mu); h->in_call = true; }
+    ~InCall() { std::lock_guard<std::mutex> lock(g_handles_mu); h->in_call = false; }
+    InCall(const InCall&) = delete;
+    InCall& operator=(const InCall&) = delete;
+};
+
 bool another_launch_in_flight(const Handle* h) {
     std::lock_guard<std::mutex> lock(g_handles_mu);
-    for (const Handle* o : g_handles)
-        if (o != h && o->device == h->device && o->ev[3] && hipEventQuery(o->ev[3]) == hipErrorNotReady) {
+    for (const Handle* o : g_handles) {
+        if (o == h || o->device != h->device) continue;
+        if (o->in_call) return true;
+        if (o->ev[3] && hipEventQuery(o->ev[3]) == hipErrorNotReady) {
             (void)hipGetLastError();   // "not ready" is an answer, not an error to carry along
             return true;
         }
+    }
     return false;
 }
 
@@ -183,6 +199,7 @@ void fill_static_params(Handle* h) {
     k.Nother = c.Nother; k.Nstcobs = c.Nstcobs; k.Ndynobs = c.Ndynobs; k.mem = c.lbfgs_mem;
     k.max_inner = c.max_inner; k.max_outer = c.max_outer;
     k.ls_fallback = 0;
+    k.stall_rule = 0;
     k.ts = c.ts; k.inv_ts = 1.0 / c.ts;
     k.vmin = c.lin_vel_min; k.vmax = c.lin_vel_max; k.wmax = c.ang_vel_max;
     k.amin = c.lin_acc_min; k.amax = c.lin_acc_max; k.aamax = c.ang_acc_max;
@@ -464,6 +481,7 @@ namespace {
 int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker* trk, const double* refs, const double* u0,
                      const double* y0, const double* c0, double* u, double* cost, int32_t* status, int32_t* inner_it,
                      int32_t* outer_it, double* fpr, double* f2norm, double* y_out, double* ms, hipStream_t s) {
+    InCall in_call_mark(h);
     h->capturing = stream_is_capturing(s);
     // The evaluation counts the previous call left in `evals` order this launch (MPCGPU_OPT_ORDER) only when that call was
     // enqueued on the SAME stream: another stream gives no ordering between its solve kernel and the kernels that read the counts.
@@ -1081,6 +1099,30 @@ int32_t mpcgpu_last_timing(void* handle, double* prep_ms, double* solve_ms) {
     return 0;
 }
 
+}  // extern "C"
+namespace {
+// A solve that was CAPTURED into a hipGraph leaves no completion event: its replays are ordered by the stream the graph is launched
+// on, which only the caller knows.  Named stream: that stream alone is waited for (never the whole device: that would stall every
+// other stream and fail outright while any of them is being captured).  MPCGPU_STREAM_OWN when the capture happened on ANOTHER stream
+// names the wrong one -- waiting for it would hand back stale counters silently: the whole device is drained instead, which fails
+// with a clear message while a capture is running anywhere on it.
+int wait_for_captured_solve(Handle* h, void* stream_arg, hipStream_t s, const char* who) {
+    if (stream_arg == MPCGPU_STREAM_OWN && h->last_stream != h->stream) {
+        hipError_t e = hipDeviceSynchronize();
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(h, -6, "%s: the last solve was captured into a hipGraph on a stream of the caller's; pass the stream the graph is "
+                               "launched on (draining the device instead failed: %s)", who, hipGetErrorString(e));
+        }
+        return 0;
+    }
+    if (stream_is_capturing(s)) return fail(h, -6, "%s inside a stream capture: the counters are read on the host", who);
+    HIP_OK(h, hipStreamSynchronize(s));
+    return 0;
+}
+}  // namespace
+extern "C" {
+
 int32_t mpcgpu_last_tail_timing(void* handle, double* main_ms, double* tail_ms) {
     Handle* h = (Handle*)handle;
     if (!h) return -1;
@@ -1114,8 +1156,7 @@ int32_t mpcgpu_last_eval_counts(void* handle, int32_t B, int32_t* n_psi, int32_t
         HIP_OK(h, hipEventSynchronize(h->ev[3]));
         if (s != h->last_stream) HIP_OK(h, hipStreamSynchronize(s));
     } else {
-        if (stream_is_capturing(s)) return fail(h, -6, "mpcgpu_last_eval_counts inside a stream capture: the counters are read on the host");
-        HIP_OK(h, hipStreamSynchronize(s));
+        if (int r = wait_for_captured_solve(h, stream, s, "mpcgpu_last_eval_counts")) return r;
     }
     int32_t* tmp = new (std::nothrow) int32_t[(size_t)B * 2];
     if (!tmp) return fail(h, -3, "out of host memory");
@@ -1168,8 +1209,10 @@ int32_t mpcgpu_reserve_batch(void* handle, int32_t B) {
     if (int r = ensure(h, h->bins, ORD_BINS * sizeof(int))) return r;
     if (int r = ensure(h, h->nlist, (size_t)B * sizeof(int32_t))) return r;
     {   // tail promotion: the list of promoted problems, and the continuation kernel's LDS size when the carve is known (reservation)
-        const int K = h->yield_opt > 4 * h->num_cus ? h->yield_opt : 4 * h->num_cus;
-        if (int r = ensure(h, h->ylist, (size_t)K * sizeof(int32_t))) return r;
+        // (solve_common's K never exceeds its batch, whatever MPCGPU_OPT_TAIL_PROMOTION / MPCGPU_OPT_TAIL_WAVES / the team width of
+        // the build make of it: one entry per problem of the promised batch covers every rule -- 4 bytes each)
+        const int K = h->yield_opt > B ? h->yield_opt : B;
+        if (int r = ensure(h, h->ylist, (size_t)(K > 0 ? K : 1) * sizeof(int32_t))) return r;
         if (h->reserved && h->yield_opt != 0) {
             for (int tw : {TEAM_WAVES, 2}) {
                 KParams kt = h->kp;
@@ -1209,6 +1252,10 @@ int32_t mpcgpu_set_option(void* handle, int32_t option, double value) {
         case MPCGPU_OPT_LINESEARCH_FALLBACK:
             if (value != 0.0 && value != 1.0) return fail(h, -1, "linesearch fallback must be 0 (last trial) or 1 (tau = 0), got %g", value);
             h->kp.ls_fallback = (int)value;
+            return 0;
+        case MPCGPU_OPT_PENALTY_STALL:
+            if (value != 0.0 && value != 1.0) return fail(h, -1, "penalty stall rule must be 0 (either infeasibility shrank) or 1 (both), got %g", value);
+            h->kp.stall_rule = (int)value;
             return 0;
         case MPCGPU_OPT_TEAM_BATCH:
             if (value < -1.0 || value != (double)(int)value) return fail(h, -1, "team batch must be -1 (automatic) or a batch size >= 0, got %g", value);
@@ -1302,7 +1349,8 @@ int32_t mpcgpu_last_tail_promotion(void* handle, int32_t* promoted, void* stream
         if (h->last_yield_cap > 0 && h->counts.ptr) {
             HIP_OK(h, hipSetDevice(h->device));
             hipStream_t s = pick_stream(h, stream);
-            HIP_OK(h, hipStreamSynchronize(s));
+            if (h->last_captured) { if (int r = wait_for_captured_solve(h, stream, s, "mpcgpu_last_tail_promotion")) return r; }
+            else HIP_OK(h, hipStreamSynchronize(s));
             int n = 0;
             HIP_OK(h, hipMemcpy(&n, (const int*)h->counts.ptr + CNT_YIELDED, sizeof(int), hipMemcpyDeviceToHost));
             *promoted = n < h->last_yield_cap ? n : h->last_yield_cap;

@@ -22,7 +22,7 @@ _LIB = os.environ.get("MPCGPU_LIB", os.path.join(_PKG, "libmpcgpu.so"))  # overr
 
 STATUS_NAMES = ("Converged", "NotConvergedIterations", "NotConvergedOutOfTime", "NotFiniteComputation",
                 "ShapeExceeded")
-ABI_VERSION = 7
+ABI_VERSION = 8
 _STREAM_OWN = C.c_void_p(-1)      # MPCGPU_STREAM_OWN: the handle's own non-blocking stream
 OPT_LINESEARCH_FALLBACK = 1       # MPCGPU_OPT_LINESEARCH_FALLBACK
 OPT_PAIRING = 2                   # MPCGPU_OPT_PAIRING
@@ -33,6 +33,7 @@ OPT_TAIL_PROMOTION = 6            # MPCGPU_OPT_TAIL_PROMOTION
 OPT_TAIL_POLL = 7                 # MPCGPU_OPT_TAIL_POLL
 OPT_TAIL_WAVES = 8                # MPCGPU_OPT_TAIL_WAVES
 OPT_TAIL_CONCURRENT = 9           # MPCGPU_OPT_TAIL_CONCURRENT
+OPT_PENALTY_STALL = 10            # MPCGPU_OPT_PENALTY_STALL
 
 
 def _stream_arg(stream):
@@ -260,6 +261,11 @@ class BatchSolver:
         if fb not in ("last_trial", "half_step"):
             raise MpcGpuError(f"solver_linesearch_fallback must be 'last_trial' or 'half_step', got {fb!r}")
         self._check(self._L.mpcgpu_set_option(self._h, OPT_LINESEARCH_FALLBACK, 1.0 if fb == "half_step" else 0.0),
+                    "mpcgpu_set_option")
+        stall = getattr(self.config, "solver_penalty_stall", "either")
+        if stall not in ("either", "both"):
+            raise MpcGpuError(f"solver_penalty_stall must be 'either' or 'both', got {stall!r}")
+        self._check(self._L.mpcgpu_set_option(self._h, OPT_PENALTY_STALL, 1.0 if stall == "both" else 0.0),
                     "mpcgpu_set_option")
         if pairing is None and os.environ.get("MPCGPU_PAIRING"):
             pairing = int(os.environ["MPCGPU_PAIRING"])
