@@ -49,6 +49,14 @@ Rank 0 prints ONE JSON line (contract in the task description) with extra object
   config.closed_loop.realtime_robots_per_gpu -- the largest fleet (multiple of 512 robots) whose WORST tick of that run stays within
                    the sampling time ts = 0.2 s of the yaml, cold and warm start (`realtime`: the sizes tried, the per-tick times).
   config.metric_batch -- the 8192-robot batch SURVEY.md 8(d) words the metric at, plain launches as given (copied from batch_sweep).
+  converged_solves_per_s, converged_fraction (top level, next to `value`) -- what `value` is made of: the headline family is the one
+                   SURVEY.md 8(d) prescribes and nearly all of its solves end at the iteration caps; these two say so without a look
+                   into `config` (the same figures of the convergent families are in config.convergent / config.avoidance).
+  config.penalty_stall -- the reading of the ALM penalty-stall rule this run solved with (yaml key solver_penalty_stall; DESIGN.md
+                   section 3), and `config.other_stall_reading`: two launches of the headline batch under the other reading.
+  config.host_boundary -- `mpcgpu_solve_batch` (HOST pointers -- the call the reference's plugin makes, trajectory_generator.py:318) at
+                   the metric batch 8192, from pageable and from page-locked memory, and one robot per call: solves/s and the share of
+                   the call that is not the solve kernels (copies + synchronisation).
   psi_evals_per_s -- psi evaluations per second of the headline leg: the workload-independent rate (families with other iteration
                    counts compare on it).
   The side legs (convergent, avoidance, ordered, batch_sweep, closed_loop, counter passes, cpu_baseline) run with ONE rank only
@@ -57,7 +65,9 @@ Rank 0 prints ONE JSON line (contract in the task description) with extra object
                    sample.  Its answers double as the checker of THIS run: `cpu_baseline.parity_on_sample` compares the control
                    sequences the timed launches wrote for the same problems (converged pairs: max |du| against the 1e-3 tolerance;
                    agreement on which problems converge; the cap-limited rest is reported, not judged); `parity_on_families` does the same,
-                   untimed, for the first 512 problems of the convergent side legs, where half of the solves converge.
+                   untimed, for the first 1024 problems of the convergent side legs, where half of the solves converge.  The headline
+                   family alone yields a handful of converged pairs, so `parity_on_sample.converged_pairs_total` adds the families' pairs
+                   (>= 256) and `feeds` says which sample contributes how many.
 """
 from __future__ import annotations
 
@@ -79,7 +89,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VECTOR_PEAK_TF = 78.6   # MI355X vector FP64: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
 ROOFLINE_JSON = os.path.join(ROOT, "profiles", "r05_roofline_bench.json")
 SWEEP_BATCHES = (32768, 8192)   # reference batches reported next to the headline (round 1's bench batch; SURVEY.md 8(d)'s metric batch)
-PARITY_SAMPLE = 512   # problems per convergent side-leg family handed to the oracle in the cpu_baseline leg (seconds of CPU)
+PARITY_SAMPLE = 1024  # problems per convergent side-leg family handed to the oracle in the cpu_baseline leg (seconds of CPU)
 
 
 def shard(total: int, rank: int, world: int):
@@ -103,6 +113,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-pmc", action="store_true", help="do not re-measure the counter-based roofline fields in this run")
     ap.add_argument("--no-closed-loop", action="store_true", help="skip the closed-loop leg")
     ap.add_argument("--no-capacity", action="store_true", help="skip the real-time capacity search of the closed-loop leg")
+    ap.add_argument("--no-host-boundary", action="store_true", help="skip the host-pointer leg (mpcgpu_solve_batch)")
+    ap.add_argument("--penalty-stall", choices=("either", "both"), default=None,
+                    help="reading of the ALM penalty-stall rule (default: the yaml / library default)")
     ap.add_argument("--side-batch", type=int, default=32768, help="problems per GPU of the convergent / avoidance legs")
     ap.add_argument("--full", action="store_true", help="run the side legs on every rank of a multi-GPU run as well")
     ap.add_argument("--p-file", default=None, help=argparse.SUPPRESS)   # counter passes: the parent's parameter vectors (.npy)
@@ -155,7 +168,7 @@ def pmc_in_run(args, p_host):
                        "command": "bench.py's own counter passes (pmc_in_run)"}, fh)
         child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--cpu-seconds", "0",
                  "--no-convergent", "--no-sweep", "--no-pmc", "--no-closed-loop", "--batch", str(args.batch), "--n-dyn", str(args.n_dyn),
-                 "--horizon", str(args.horizon), "--p-file", pfile]
+                 "--horizon", str(args.horizon), "--p-file", pfile] + (["--penalty-stall", args.penalty_stall] if args.penalty_stall else [])
         env = dict(os.environ, TMPDIR="/tmp")
         env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
         t0 = time.perf_counter()
@@ -252,17 +265,18 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     red_dev = dev if (backend == "nccl" and not stub) else torch.device("cpu")
 
-    cfg = MpcConfig(N_hor=args.horizon)
+    cfg_kw = {} if args.penalty_stall is None else {"solver_penalty_stall": args.penalty_stall}
+    cfg = MpcConfig(N_hor=args.horizon, **cfg_kw)
     N, B = cfg.N_hor, args.batch
 
-    def new_solver(order="as_given"):
+    def new_solver(order="as_given", config=None):
         """`order`: MPCGPU_OPT_ORDER.  Every leg that feeds `value` starts the problems in the order given; the library's default
         (longest first by the previous call's evaluation counts) is measured in legs of its own (`ordered`): a bench step repeats
         the SAME batch, so those hints are perfect -- an upper bound of what a receding-horizon loop gets from its last tick."""
         if stub:
-            return StubSolver(cfg)
+            return StubSolver(config or cfg)
         from trajtrack_mpcndqn_rlboost_amd import BatchSolver
-        return BatchSolver(cfg, device=dev_index, order=order)
+        return BatchSolver(config or cfg, device=dev_index, order=order)
 
     def new_out(b):
         return dict(u=torch.empty(b, 2 * N, dtype=torch.float64, device=dev),
@@ -459,6 +473,74 @@ def main():
                                             "(reserved shape: no read-back, no host synchronisation inside the timed region)"}
             sweep.append(item)
 
+    # the headline batch under the OTHER reading of the penalty-stall rule: two launches, same problems
+    other_reading = None
+    if side and not args.no_sweep and not args.p_file:
+        other = "both" if getattr(cfg, "solver_penalty_stall", "either") == "either" else "either"
+        cfg_o = MpcConfig(N_hor=args.horizon, solver_penalty_stall=other)
+        sv_o = new_solver(config=cfg_o)
+        ol = timed_leg(p, 2, 1, sv_o, out)
+        o_el, _ = over_ranks(ol["elapsed"])
+        other_reading = {"penalty_stall": other, "value": world * B * 2 / o_el, "unit": "solves/s", "steps": 2, "ms_per_step": 1e3 * o_el / 2,
+                         "kernel_ms": ol["kernel_ms"] + ol["tail_ms"], "status_histogram": np.bincount(ol["status"], minlength=3).tolist(),
+                         "converged_fraction": float((ol["status"] == 0).mean()), "mean_inner_iterations": float(ol["inner"].mean()),
+                         "mean_psi_evaluations": float(ol["n_psi"].mean()),
+                         "psi_evals_per_s": world * float(ol["n_psi"].sum()) * 2 / o_el}
+        if hasattr(sv_o, "close"):
+            sv_o.close()
+
+    # The boundary the reference's plugin actually crosses: HOST pointers (solver.run(p) with Python lists, trajectory_generator.py:272-275,318)
+    # -> mpcgpu_solve_batch: copy in, compaction + solve, copy out, synchronous.  The metric batch from pageable and from page-locked
+    # memory, and one robot per call (the reference's own pattern).  `not_the_solve_kernels` = 1 - (compaction + solve kernel time by
+    # HIP events) / wall time of the call: copies, launches and the synchronisation.
+    host_leg = None
+    if side and not args.no_host_boundary and not stub and not args.p_file:
+        hb = min(8192, B)
+        sv_h = new_solver()
+        p_page = p[:hb].cpu().numpy().copy()
+        pin_t = torch.empty((hb, cfg.num_params), dtype=torch.float64, pin_memory=True)
+        pin_t.copy_(p[:hb]); torch.cuda.synchronize()
+
+        def host_out(n, pinned):
+            mk = (lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True).numpy()) if pinned else \
+                 (lambda shape, dt: np.empty(shape, dtype={torch.float64: np.float64, torch.int32: np.int32}[dt]))
+            return dict(u=mk((n, 2 * N), torch.float64), cost=mk((n,), torch.float64), status=mk((n,), torch.int32),
+                        inner_it=mk((n,), torch.int32), outer_it=mk((n,), torch.int32))
+        host_leg = {"what": "mpcgpu_solve_batch (HOST pointers; copies in, compaction, solve, copies out, synchronous) on the first problems of the "
+                            "headline batch; bytes over PCIe per solve: " + str(8 * cfg.num_params + 8 * 2 * N + 8 + 4 + 4 + 4),
+                    "batch": hb}
+        for kind, pp in (("pageable", p_page), ("pinned", pin_t.numpy())):
+            oo = host_out(hb, kind == "pinned")
+            sv_h.solve_into(pp, oo)                                   # warm-up: buffers, shape
+            walls, kern = [], []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                sv_h.solve_into(pp, oo)
+                walls.append(time.perf_counter() - t0)
+                t = sv_h.last_timing()
+                kern.append(1e-3 * (t["prep_ms"] + t["solve_ms"]))
+            w, k = float(np.mean(walls)), float(np.mean(kern))
+            host_leg[kind] = {"value": hb / w, "unit": "solves/s", "ms_per_call": 1e3 * w, "kernel_ms": 1e3 * k,
+                              "not_the_solve_kernels": 1.0 - k / w, "status_histogram": np.bincount(oo["status"], minlength=3).tolist()}
+        one = host_out(1, False)
+        n_one = 48
+        walls, kern = [], []
+        sv_h.solve_into(p_page[:1], one)
+        for i in range(n_one):
+            t0 = time.perf_counter()
+            sv_h.solve_into(p_page[i:i + 1], one)
+            walls.append(time.perf_counter() - t0)
+            t = sv_h.last_timing()
+            kern.append(1e-3 * (t["prep_ms"] + t["solve_ms"]))
+        host_leg["one_robot_per_call"] = {"calls": n_one, "value": n_one / float(np.sum(walls)), "unit": "solves/s",
+                                          "ms_per_call_median": 1e3 * float(np.median(walls)), "ms_per_call_max": 1e3 * float(np.max(walls)),
+                                          "kernel_ms_median": 1e3 * float(np.median(kern)),
+                                          "not_the_solve_kernels": 1.0 - float(np.sum(kern)) / float(np.sum(walls)),
+                                          "what": "the reference's call pattern (src/interface_mpc.py:82-88: one solver.run per robot and tick): "
+                                                  "pageable host vectors, the latency kernel (four wavefronts per problem)"}
+        sv_h.close()
+        del pin_t
+
     closed = None
     if side and not args.no_closed_loop and not stub and not args.p_file and N == 20:
         from tools.closed_loop import device_closed_loop
@@ -486,7 +568,9 @@ def main():
     if rank == 0:
         status, inner = leg["status"], leg["inner"]
         n_psi, n_grad = leg["n_psi"], leg["n_grad"]
-        k_ms = leg["kernel_ms"]
+        # the whole solve of the batch on the launch stream: the throughput kernel AND what is left of the continuation behind it (the
+        # numerators below -- bytes, flops -- count every problem of the batch, the promoted ones included)
+        k_ms = leg["kernel_ms"] + leg["tail_ms"]
         algo_bytes = (8 * cfg.num_params + 8 * 2 * N + 8 * 2 * N + 40) * B
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9
         n_conv = int((status == 0).sum())
@@ -509,12 +593,16 @@ def main():
             # workload-independent rate: psi (+ grad psi) evaluations per second of this rank's shard x ranks (families with other
             # iteration counts compare on this, not on solves/s)
             "psi_evals_per_s": world * float(n_psi.sum()) * args.steps / elapsed,
+            # what `value` is made of (this scene family is cap-limited: SURVEY.md 8(d) prescribes it; config.convergent / avoidance have the others)
+            "converged_solves_per_s": world * n_conv * args.steps / elapsed,
+            "converged_fraction": n_conv / B,
             "config": {"workload": f"mpc_default.yaml N_hor={N}, {args.n_dyn} dynamic obstacles (r=1.6 m discs crossing "
                                    "the path, SURVEY.md 8(d)), 5 static boxes, cold start u0=0, "
                                    f"batch={B} robots per GPU; K plain launches on one stream, problems started in the order given "
                                    "(config.ordered: the library's default order; batch_sweep: the reference batches 32768 and "
                                    "8192, plain / ordered / pipelined)",
                        "batch_per_gpu": B, "N_hor": N, "n_dyn": args.n_dyn, "parallelism": f"shard{world}",
+                       "penalty_stall": getattr(cfg, "solver_penalty_stall", "either"),
                        "mean_inner_iterations": float(inner.mean()),
                        "mean_psi_evaluations": float(n_psi.mean()), "mean_grad_evaluations": float(n_grad.mean()),
                        "status_histogram": np.bincount(status, minlength=3).tolist(),
@@ -556,6 +644,10 @@ def main():
                 "mean_inner_iterations": float(al["inner"].mean()),
                 "mean_psi_evaluations": float(al["n_psi"].mean()),
                 "converged_solves_per_s": world * int((al["status"] == 0).sum()) * av["steps"] / av["elapsed"]}
+        if other_reading is not None:
+            line["config"]["other_stall_reading"] = other_reading
+        if host_leg is not None:
+            line["config"]["host_boundary"] = host_leg
         if closed is not None:
             line["config"]["closed_loop"] = closed
         if sweep:
@@ -580,9 +672,9 @@ def main():
             tf = flops / (k_ms * 1e-3) / 1e12
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc["traffic_bytes_per_launch"] if pmc else None,
-                    "kernel": "solve_kernel_pair", "kernel_ms": k_ms, "prep_kernel_ms": leg["prep_ms"],
+                    "kernel": "solve_kernel_pair", "kernel_ms": k_ms, "throughput_kernel_ms": leg["kernel_ms"], "prep_kernel_ms": leg["prep_ms"],
                     "tail_kernel": "solve_kernel_team (continuation of the tail promotion: the last problems of the launch; it starts on a side stream while "
-                                   "solve_kernel_pair drains -- tail_kernel_ms is the part of it AFTER that kernel has ended, by HIP events)",
+                                   "solve_kernel_pair drains -- tail_kernel_ms is the part of it AFTER that kernel has ended, by HIP events; kernel_ms = throughput_kernel_ms + tail_kernel_ms is what achieved / frac / flops divide by)",
                     "tail_kernel_ms": leg["tail_ms"],
                     "algorithmic_bytes_per_solve": algo_bytes // B,
                     "measured_in_run": {"achieved": True, "kernel_ms": True, "frac": True, "flops": True,

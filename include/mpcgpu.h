@@ -276,6 +276,13 @@ int32_t mpcgpu_last_ordered(void* handle);
  * problems actually moved to the latency kernel; reading it waits for `stream` (the stream the call was enqueued on). */
 int32_t mpcgpu_last_tail_promotion(void* handle, int32_t* promoted, void* stream);
 
+/* (ABI 8) Health of the concurrent continuation of the last solve call (MPCGPU_OPT_TAIL_CONCURRENT): returns 1 when that call ran its
+ * continuation beside the draining launch, 0 when behind it (or none).  `timeouts`: how many of its bounded waits ended by their
+ * wall-clock limit instead of by their condition (the gate's 60 s, a workgroup's 0.5 s for its list entry) -- 0 in a healthy run;
+ * a non-zero count means the side stream was starved (foreign work on the device) and the sweep launch finished those problems:
+ * the results are the same, the call took longer.  Reading it waits for `stream` like mpcgpu_last_tail_promotion. */
+int32_t mpcgpu_last_tail_timeouts(void* handle, int32_t* timeouts, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------------
  * Batched tracker harness on the device.  Replaces, for B robots per call and without a
  * host round trip, what the reference does per robot in Python around every solver.run:

@@ -1,0 +1,46 @@
+"""GPU (-m gpu): the concurrent continuation of the tail promotion (MPCGPU_OPT_TAIL_CONCURRENT: the latency kernel on a side stream of
+the handle's own, behind a gate, beside the draining throughput launch) against work the library cannot see -- torch kernels of the
+caller on another stream (what the hybrid / DQN tick runs next to the solve) and a second PROCESS on the same GPU.  Foreign work may
+cost time; it must never change a bit, hang a call, or leave a bounded wait to its time limit (mpcgpu_last_tail_timeouts).  The long
+form (200 calls per line) is tools/foreign_work_soak.py -> profiles/r06_foreign_work.txt."""
+import os
+import sys
+
+import pytest
+
+from conftest import make_cfg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("B", [4096, 8192])
+def test_solves_beside_a_stream_of_gemms_keep_their_bits_and_their_pace(B):
+    from foreign_work_soak import soak
+    cfg = make_cfg(20)
+    quiet = soak(cfg, B, 12, "quiet")
+    busy = soak(cfg, B, 30, "gemm")          # raises when any output of any call differs from the solve without tail promotion
+    print(f"\n[B = {B}] quiet: {quiet['ms_median']:.1f} ms per call (max {quiet['ms_max']:.1f}); beside GEMMs ({busy['gemms_launched']} launched): "
+          f"{busy['ms_median']:.1f} ms (p90 {busy['ms_p90']:.1f}, max {busy['ms_max']:.1f}); continuation beside the launch in "
+          f"{busy['beside_the_launch']} of {busy['calls']} calls; waits ended by their time limit: {busy['timeouts']}")
+    assert quiet["calls"] == 12 and busy["calls"] == 30
+    assert busy["gemms_launched"] > 0                                  # the other stream really was busy
+    assert quiet["timeouts"] == 0 and busy["timeouts"] == 0            # no gate / list-entry wait ran into its wall-clock limit
+    assert quiet["beside_the_launch"] == 12 and busy["beside_the_launch"] == 30   # the library cannot see the GEMMs: it keeps the default form
+    assert quiet["max_over_median"] < 2.0 and busy["max_over_median"] < 2.0       # no call falls out of line (a 2.2 s tick was seen once in round 5)
+
+
+def test_solves_beside_a_second_process_keep_their_bits():
+    """bench.py --steps 2 on 32768 problems runs as a second process (own context, own handle) while this one solves: time slicing
+    between two processes is the driver's; what is asserted is bits, termination, and that every call stays far below the waits' limits."""
+    from foreign_work_soak import soak
+    cfg = make_cfg(20)
+    r = soak(cfg, 8192, 60, "process")
+    print(f"\n[second process] {r['calls']} calls bitwise equal while it ran; per call median {r['ms_median']:.1f} ms, max {r['ms_max']:.1f}; "
+          f"waits ended by their time limit: {r['timeouts']}; other process: exit code {r['child_rc']}, {r['child_solves_per_s']} solves/s")
+    assert r["calls"] >= 8
+    assert r["child_rc"] == 0 and r["child_solves_per_s"] and r["child_solves_per_s"] > 1e3
+    assert r["ms_max"] < 2000.0          # nowhere near the 60 s gate limit; a starved entry wait (0.5 s) would show up in `timeouts`
+    assert r["timeouts"] == 0

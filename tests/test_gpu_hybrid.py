@@ -14,27 +14,36 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _setup(B):
+def _setup(B, stall=None):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     loop = importlib.import_module("hybrid_loop")
     from trajtrack_mpcndqn_rlboost_amd import MpcConfig
     from trajtrack_mpcndqn_rlboost_amd.dqn import QNetwork
     w = np.load(os.path.join(ROOT, "tests", "golden", "dqn_ray.npz"))
     q = QNetwork().load_arrays({k: w[k] for k in w.files if k.startswith("w")})
-    cfg = MpcConfig(os.path.join(ROOT, "config", "mpc_longiter.yaml"))
+    cfg = MpcConfig(os.path.join(ROOT, "config", "mpc_longiter.yaml"), **({} if stall is None else dict(solver_penalty_stall=stall)))
     rng = np.random.default_rng(3)
     return loop, cfg, q, [loop.scene(rng) for _ in range(B)]
 
 
-@pytest.mark.parametrize("mode", [1, 2])
-def test_mpc_and_hybrid_reach_the_goal_without_collision(mode):
+@pytest.mark.parametrize("mode,stall", [(1, "both"), (2, "both"), (2, "either"), (1, "either")])
+def test_mpc_and_hybrid_reach_the_goal_without_collision(mode, stall):
+    """Both readings of the ALM penalty-stall rule.  The DQN-boosted loop (mode 2, src/main.py) gets every robot
+    past the unexpected box under either of them.  Pure MPC (mode 1) does so only when the penalty on the hard constraints GROWS
+    ("both"); under "either" (the default: the published engine as recalled) the penalty stays at 10 while the acceleration constraints
+    are inactive, the box is a weak soft constraint and most robots cut through it (measured: 6 of 8 here, 22 of 32 in a larger run,
+    profiles/r06_stall_rule.txt) -- the situation the reference's DQN boost exists for."""
     hybrid = importlib.import_module("trajtrack_mpcndqn_rlboost_amd.hybrid")
-    loop, cfg, q, scenes = _setup(8)
+    loop, cfg, q, scenes = _setup(8, stall)
     run = hybrid.BatchedHybrid(cfg, scenes, q, decision_mode=mode)
     out = run.run(200)
+    print(f"\n[mode {mode}, {stall}] done {out['done'].mean():.3f} collided {out['collided'].mean():.3f} success {out['success'].mean():.3f}")
     # pure MPC (mode 1) can stay stuck behind the box for a whole run (profiles/archive/r01_hybrid_loop_B64.txt: 93 % success), and
     # which robot does depends on cap-limited solves, i.e. on rounding: the assertions are on rates, not on every robot
     assert out["done"].mean() >= (0.75 if mode == 1 else 1.0)
+    if mode == 1 and stall == "either":
+        assert (out["switch_ticks"] == 0).all()
+        return                                   # collisions are this reading's behaviour (docstring); nothing more to assert
     assert not out["collided"].any()
     assert out["success"].mean() >= 0.75
     ok = out["success"].astype(bool)

@@ -104,7 +104,9 @@ enum { CNT_KS = 0, CNT_KF = 1, CNT_KD = 2, CNT_VARSHAPE = 3, CNT_ROTATED = 4 /* 
        CNT_YIELDED = 9 /* length of the list of problems that left the throughput launch for the latency kernel */,
        CNT_LISTED = 10 /* entries of that list that are complete (record + list slot written): FINISHED + LISTED = every problem decided */,
        CNT_STARTED = 11 /* problems of the running throughput launch that have begun (gate of the concurrent continuation) */,
-       CNT_WORDS = 12 };
+       CNT_TIMEOUTS = 12 /* waits of the concurrent continuation that ended by their wall-clock limit (gate: 60 s; a workgroup waiting for its
+                            list entry: 0.5 s) instead of by their condition -- mpcgpu_last_tail_timeouts; the sweep launch finishes such entries */,
+       CNT_WORDS = 14 };
 
 struct KParams {
     int N, Nother, Nstcobs, Ndynobs, np, mem;

@@ -779,7 +779,7 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
         io.p = nullptr; io.perm = nullptr;
         if (concurrent) {
             // side stream: gate (opens at FINISHED >= yield_from and STARTED = B; 60 s limit), then one workgroup per list entry
-            hipLaunchKernelGGL(tail_gate_kernel, dim3(1), dim3(WAVE), 0, h->side, (const int*)io.counts, h->kp.yield_from, B, 6000000000LL);
+            hipLaunchKernelGGL(tail_gate_kernel, dim3(1), dim3(WAVE), 0, h->side, (int*)io.counts, h->kp.yield_from, B, 6000000000LL);
             kt_y.yield_persist = 1;
             LAUNCH_RESUME_N(yield_K, h->side)
             HIP_OK(h, hipGetLastError());
@@ -1357,6 +1357,22 @@ int32_t mpcgpu_last_tail_promotion(void* handle, int32_t* promoted, void* stream
         }
     }
     return h->last_yield_cap;
+}
+
+int32_t mpcgpu_last_tail_timeouts(void* handle, int32_t* timeouts, void* stream) {
+    Handle* h = (Handle*)handle;
+    if (!h || !timeouts) return -1;
+    *timeouts = 0;
+    if (h->last_yield_cap > 0 && h->counts.ptr) {
+        HIP_OK(h, hipSetDevice(h->device));
+        hipStream_t s = pick_stream(h, stream);
+        if (h->last_captured) { if (int r = wait_for_captured_solve(h, stream, s, "mpcgpu_last_tail_timeouts")) return r; }
+        else HIP_OK(h, hipStreamSynchronize(s));
+        int n = 0;
+        HIP_OK(h, hipMemcpy(&n, (const int*)h->counts.ptr + CNT_TIMEOUTS, sizeof(int), hipMemcpyDeviceToHost));
+        *timeouts = n;
+    }
+    return h->last_concurrent ? 1 : 0;
 }
 
 #ifdef MPC_PROFILE

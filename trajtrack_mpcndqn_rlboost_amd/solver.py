@@ -64,7 +64,7 @@ class _CConfig(C.Structure):
 EXPORTS = ("mpcgpu_abi_version", "mpcgpu_create", "mpcgpu_destroy", "mpcgpu_last_error", "mpcgpu_num_params",
            "mpcgpu_solve_batch", "mpcgpu_solve_batch_dev", "mpcgpu_cost_grad_batch", "mpcgpu_last_timing",
            "mpcgpu_last_eval_counts", "mpcgpu_last_shape", "mpcgpu_last_waves_per_simd", "mpcgpu_reserve_shape",
-           "mpcgpu_set_option", "mpcgpu_last_problems_per_wavefront", "mpcgpu_last_ordered", "mpcgpu_last_tail_promotion", "mpcgpu_last_tail_timing", "mpcgpu_last_latency_kernel", "mpcgpu_reserve_batch", "mpcgpu_last_table_kind", "mpcgpu_tracker_window_dev",
+           "mpcgpu_set_option", "mpcgpu_last_problems_per_wavefront", "mpcgpu_last_ordered", "mpcgpu_last_tail_promotion", "mpcgpu_last_tail_timeouts", "mpcgpu_last_tail_timing", "mpcgpu_last_latency_kernel", "mpcgpu_reserve_batch", "mpcgpu_last_table_kind", "mpcgpu_tracker_window_dev",
            "mpcgpu_tracker_step_dev", "mpcgpu_rl_reference_dev", "mpcgpu_hint_switch_dev", "mpcgpu_debug_read_workspace",
            "mpcgpu_workspace_stride", "mpcgpu_workspace_record", "mpcgpu_debug_prep", "mpcgpu_debug_tracker_assemble",
            "mpcgpu_debug_lbfgs_direction")
@@ -149,6 +149,9 @@ def load_library(path: Optional[str] = None):
     L.mpcgpu_last_problems_per_wavefront.restype = C.c_int32
     L.mpcgpu_last_ordered.argtypes = [vp]
     L.mpcgpu_last_ordered.restype = C.c_int32
+    if hasattr(L, "mpcgpu_last_tail_timeouts"):
+        L.mpcgpu_last_tail_timeouts.argtypes = [vp, ip, vp]
+        L.mpcgpu_last_tail_timeouts.restype = C.c_int32
     if hasattr(L, "mpcgpu_last_tail_promotion"):   # (absent only in an old build loaded for an A/B run, see MPCGPU_ALLOW_ABI)
         L.mpcgpu_last_tail_promotion.argtypes = [vp, ip, vp]
         L.mpcgpu_last_tail_promotion.restype = C.c_int32
@@ -313,6 +316,15 @@ class BatchSolver:
         cap = int(self._L.mpcgpu_last_tail_promotion(self._h, C.byref(n), _stream_arg(stream)))
         return cap, int(n.value)
 
+    def last_tail_timeouts(self, stream: Optional[int] = None):
+        """(the last solve ran its continuation beside the draining launch, number of its bounded waits that ended by their wall-clock
+        limit: 0 in a healthy run -- a starved side stream costs time, the sweep launch finishes what is left, same results)."""
+        n = C.c_int32()
+        conc = int(self._L.mpcgpu_last_tail_timeouts(self._h, C.byref(n), _stream_arg(stream)))
+        if conc < 0:
+            self._check(conc, "mpcgpu_last_tail_timeouts")
+        return bool(conc), int(n.value)
+
     def set_order(self, order: str):
         if order not in ("as_given", "longest_first"):
             raise MpcGpuError(f"order must be 'as_given' or 'longest_first', got {order!r}")
@@ -360,6 +372,23 @@ class BatchSolver:
                                         _ip(status), _ip(inner), _ip(outer), _dp(fpr), _dp(f2), _dp(y), _dp(ms))
         self._check(rc, "mpcgpu_solve_batch")
         return BatchResult(u, cost, status, inner, outer, fpr, f2, y, ms)
+
+    def solve_into(self, p: np.ndarray, out: dict, initial_guess=None):
+        """``mpcgpu_solve_batch`` (HOST pointers: what the reference's plugin boundary hands over, trajectory_generator.py:318) on
+        caller-owned float64 / int32 numpy arrays, nothing allocated here: ``p [B, np]``, ``out`` with ``u [B, 2N]``, ``cost [B]``,
+        ``status [B]`` (int32) and optionally ``inner_it``, ``outer_it`` (int32).  The arrays may be views of page-locked memory
+        (``torch.empty(..., pin_memory=True).numpy()``).  Synchronous: results are in place on return."""
+        B = int(p.shape[0])
+        if p.dtype != np.float64 or not p.flags.c_contiguous or p.shape != (B, self.np):
+            raise MpcGpuError(f"p must be a C-contiguous float64 [B, {self.np}] array, got {p.dtype} {p.shape}")
+        for name, dt, shape in (("u", np.float64, (B, self.n)), ("cost", np.float64, (B,)), ("status", np.int32, (B,))):
+            a = out[name]
+            if a.dtype != dt or a.shape != shape or not a.flags.c_contiguous:
+                raise MpcGpuError(f"out[{name!r}] must be a C-contiguous {np.dtype(dt).name} {shape} array")
+        u0 = None if initial_guess is None else np.ascontiguousarray(initial_guess, dtype=np.float64)
+        rc = self._L.mpcgpu_solve_batch(self._h, B, _dp(p), _dp(u0), None, None, _dp(out["u"]), _dp(out["cost"]), _ip(out["status"]),
+                                        _ip(out.get("inner_it")), _ip(out.get("outer_it")), None, None, None, None)
+        self._check(rc, "mpcgpu_solve_batch")
 
     def cost_grad(self, u, p, c=None, y=None):
         """Test hook: psi, f, grad psi, F1, F2 of every problem (GPU evaluation of the generated functions)."""
