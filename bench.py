@@ -31,7 +31,7 @@ Rank 0 prints ONE JSON line (contract in the task description) with extra object
                    when rocprofv3 is there (N = 1): after the timed legs, three `rocprofv3 --pmc` passes (SQ counters,
                    FETCH_SIZE, WRITE_SIZE: one pass each, never combined with a trace) over a child bench.py on the
                    same parameter vectors, rebuilt by tools/roofline.py -- `measured_in_run: true`.  Without the
-                   profiler (or with --no-pmc) the fields come from profiles/r05_roofline_bench.json -- the committed
+                   profiler (or with --no-pmc) the fields come from profiles/r06_roofline_bench.json -- the committed
                    passes on this very workload -- and are marked `measured_in_run: false` with the reason.
   config.convergent -- the same step on the "passing" scene family (same N, obstacle counts and batch; a
                    collision-free plan exists), where about half of the solves converge: the headline family is the
@@ -87,7 +87,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VECTOR_PEAK_TF = 78.6   # MI355X vector FP64: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
-ROOFLINE_JSON = os.path.join(ROOT, "profiles", "r05_roofline_bench.json")
+ROOFLINE_JSON = os.path.join(ROOT, "profiles", "r06_roofline_bench.json")
 SWEEP_BATCHES = (32768, 8192)   # reference batches reported next to the headline (round 1's bench batch; SURVEY.md 8(d)'s metric batch)
 PARITY_SAMPLE = 1024  # problems per convergent side-leg family handed to the oracle in the cpu_baseline leg (seconds of CPU)
 
@@ -778,7 +778,7 @@ def cpu_baseline(cfg, p_all, budget_s, gpu_u=None, gpu_status=None, family_sampl
         du = np.max(np.abs(np.asarray(u_c)[:n] - np.asarray(u_g)[:n]), axis=1)
         both = (st_c == 0) & (st_g == 0)
         far = both & (du > 1e-3)      # converged on both sides, yet apart: two local minima (a detour on either side of an obstacle;
-        near = both & ~far            # the oracle against its own 1-ulp twin shows the same: profiles/r05_fuzz_parity.txt)
+        near = both & ~far            # the oracle against its own 1-ulp twin shows the same: profiles/r06_fuzz_parity.txt)
         return {"problems": int(n), "converged_on_both_sides": int(both.sum()),
                 "max_abs_du_on_them": float(du[both].max()) if both.any() else None, "tolerance": 1e-3,
                 "pairs_beyond_tolerance": int(far.sum()), "max_abs_du_of_the_pairs_within": float(du[near].max()) if near.any() else None,

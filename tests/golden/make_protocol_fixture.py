@@ -84,5 +84,8 @@ if __name__ == "__main__":
         out["state"].append(mpc.state.copy()); out["pred"].append(np.array(pred))
     save = {k: np.array(v) for k, v in out.items()}
     save["path"] = np.array(path); save["box"] = np.array(box)
+    # the reading of the ALM penalty-stall rule the stand-in solved with (the package default: DESIGN.md section 3)
+    from trajtrack_mpcndqn_rlboost_amd.config import SOLVER_DEFAULTS
+    save["penalty_stall"] = np.array(SOLVER_DEFAULTS["solver_penalty_stall"])
     print("ticks", T, "converged", sum(s == "Converged" for s in out["status"]), "final state", mpc.state)
     np.savez_compressed(os.path.join(HERE, "protocol_trace.npz"), **save)

@@ -170,10 +170,11 @@ def test_hard_scenes_agree_within_intrinsic_sensitivity(solver20, cfg20):
     # (||F2|| of cap-limited solves spreads over three decades -- 1e-3 .. 4 -- and more so under the "either" stall rule, where the
     #  penalty stops growing for part of them: the MEDIAN of 192 such values is itself noisy; the distributions are compared in log space
     #  and against what the oracle's own 1-ulp twin shows)
-    lg = lambda x: np.log10(np.maximum(x, 1e-12))
-    f2_gpu, f2_self = abs(np.median(lg(res.f2_norm)) - np.median(lg(ro["f2_norm"]))), abs(np.median(lg(ro2["f2_norm"])) - np.median(lg(ro["f2_norm"])))
-    assert f2_gpu <= max(0.15, 3.0 * f2_self), (f2_gpu, f2_self)
-    assert abs(np.mean(lg(res.f2_norm)) - np.mean(lg(ro["f2_norm"]))) <= 0.15
+    lg = lambda x: np.sort(np.log10(np.maximum(x, 1e-12)))
+    w1 = float(np.mean(np.abs(lg(res.f2_norm) - lg(ro["f2_norm"]))))      # Wasserstein-1 distance of the two samples, in decades
+    print(f"\n||F2|| distributions (log10): GPU quartiles {np.quantile(lg(res.f2_norm), [0.25, 0.5, 0.75]).round(2).tolist()}, oracle "
+          f"{np.quantile(lg(ro['f2_norm']), [0.25, 0.5, 0.75]).round(2).tolist()}, distance {w1:.3f} decades")
+    assert w1 <= 0.15
     assert (res.status == ro["status"]).mean() >= 0.9
     assert abs(res.num_inner_iterations.mean() / ro["inner_iters"].mean() - 1.0) < 0.1
     # work counters: the oracle counts the same evaluations

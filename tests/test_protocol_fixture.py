@@ -30,10 +30,20 @@ def _closed_loop(mpc, fx, T):
     return np.array(states), np.array(actions)
 
 
-def test_own_harness_replays_the_reference_harness_run_bitwise():
+@pytest.fixture
+def recorded_reading(monkeypatch):
+    """The recording was made under ONE reading of the penalty-stall rule (stored with it): the replays solve under that one, whatever
+    reading the rest of the run uses (`pytest --penalty-stall`)."""
+    from trajtrack_mpcndqn_rlboost_amd import config as pkg_config
+    fx = load_golden("protocol_trace.npz")
+    monkeypatch.setitem(pkg_config.SOLVER_DEFAULTS, "solver_penalty_stall", str(fx["penalty_stall"]))
+    return fx
+
+
+def test_own_harness_replays_the_reference_harness_run_bitwise(recorded_reading):
     import trajtrack_mpcndqn_rlboost_amd.plugin as plugin
     from support.oracle_solver import OracleBatchSolver
-    fx = load_golden("protocol_trace.npz")
+    fx = recorded_reading
     cfg = MpcConfig()
     captured = []
 
@@ -60,9 +70,9 @@ def test_own_harness_replays_the_reference_harness_run_bitwise():
 
 
 @pytest.mark.gpu
-def test_real_library_behind_the_plugin_module_follows_the_recorded_closed_loop():
+def test_real_library_behind_the_plugin_module_follows_the_recorded_closed_loop(recorded_reading):
     """__import__('navi_default').solver() -- the reference's loading sequence -- with libmpcgpu.so behind it."""
-    fx = load_golden("protocol_trace.npz")
+    fx = recorded_reading
     path = os.path.join(ROOT, "mpc_solver", "navi_default")
     sys.path.append(path)
     try:

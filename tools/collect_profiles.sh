@@ -1,12 +1,12 @@
 #!/bin/bash
 # Collects, on the GPU box, the raw rocprofv3 outputs behind bench.py's roofline object -- every pass on the SAME
 # workload (bench.py defaults: N_hor = 20, 8 dynamic obstacles, B = 131072), one rocprofv3 run per pass (kernel trace and
-# counters are never combined; FETCH_SIZE and WRITE_SIZE need a pass each).  Copy the directory to profiles/raw_r05/ and
+# counters are never combined; FETCH_SIZE and WRITE_SIZE need a pass each).  Copy the directory to profiles/raw_r06/ and
 # run `python tools/roofline.py rebuild`.
-#   usage: tools/collect_profiles.sh [outdir = gpurun_out/raw_r05] [extra bench.py arguments]
+#   usage: tools/collect_profiles.sh [outdir = gpurun_out/raw_r06] [extra bench.py arguments]
 set -u
 REPO="$(cd "$(dirname "$0")/.." && pwd)"
-OUT="${1:-$REPO/gpurun_out/raw_r05}"; shift || true
+OUT="${1:-$REPO/gpurun_out/raw_r06}"; shift || true
 case "$OUT" in /*) ;; *) OUT="$REPO/$OUT";; esac
 mkdir -p "$OUT"
 export TMPDIR=/tmp

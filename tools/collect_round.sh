@@ -1,11 +1,13 @@
+# usage (GPU box): bash tools/collect_round.sh [round = r06]  -- every table of a round into gpurun_out/<round>/ (tools/publish_profiles.sh copies them to profiles/)
 set -u
-O=gpurun_out/r05
+R=${1:-r06}
+O=gpurun_out/$R
 mkdir -p $O
 # the tables below are those of rounds 1-5: problems started in the order given (bench.py sets the order of each of its legs itself);
 # the library's default order gets a table of its own at the end
 export MPCGPU_ORDER=as_given
 python bench.py --steps 5 --warmup 1 > $O/bench_line.json 2> $O/bench.err
-(echo "# tools/phase_prof.py on a -DMPC_PROFILE build of the final round-5 source (throughput kernel; shader-clock cycles per phase; 16 resident wavefronts per CU at N = 20, 12 at N = 40)"; MPCGPU_LIB=$PWD/build_ab/libmpcgpu_prof.so python tools/phase_prof.py 8192 20; MPCGPU_LIB=$PWD/build_ab/libmpcgpu_prof.so python tools/phase_prof.py 4096 40) > $O/phase_table.txt 2>&1
+(echo "# tools/phase_prof.py on a -DMPC_PROFILE build of the final source of this round (throughput kernel; shader-clock cycles per phase; 16 resident wavefronts per CU at N = 20, 12 at N = 40)"; MPCGPU_LIB=$PWD/build_ab/libmpcgpu_prof.so python tools/phase_prof.py 8192 20; MPCGPU_LIB=$PWD/build_ab/libmpcgpu_prof.so python tools/phase_prof.py 4096 40) > $O/phase_table.txt 2>&1
 (echo "# tools/team_sweep.py bench (kernel ms, best of 3)"; python tools/team_sweep.py bench; python tools/team_sweep.py passing) > $O/team_sweep.txt 2>&1
 (echo "# config 2: N_hor = 20, 4 dynamic obstacles, B = 1024 (tools/prof_solve.py 1024 3 4 20)"; python tools/prof_solve.py 1024 3 4 20; echo "# config 3: N_hor = 40, 8 dynamic obstacles, B = 4096 / 16384 (tools/prof_solve.py B 3 8 40)"; python tools/prof_solve.py 4096 3 8 40; python tools/prof_solve.py 16384 2 8 40) > $O/config2_config3.txt 2>&1
 (echo "# tools/prof_solve.py B 2 8 20: benchmark scene family, N_hor = 20, 8 dynamic obstacles, cold start, solve kernel ms"; for B in 8192 16384 32768 65536 131072; do python tools/prof_solve.py $B 2 8 20; done) > $O/batch_scaling.txt 2>&1
@@ -20,10 +22,14 @@ timeout 900 python -m pytest tests/test_gpu_hybrid.py -q -m gpu -s -k "configure
 python tools/scanner_replay.py 256 > $O/scanner_replay_B256.txt 2>&1
 python tools/train_dqn.py --envs 4096 --timesteps 401408 --graph --save $O/dqn_ckpt > $O/dqn_config5.txt 2>&1
 ls $O/dqn_ckpt >> $O/dqn_config5.txt; rm -rf $O/dqn_ckpt
-bash tools/collect_profiles.sh gpurun_out/raw_r05 > $O/collect.log 2>&1
-bash tools/pmc_stalls.sh 8192 gpurun_out/pmc_stalls_r05 > $O/pmc_stalls_B8192.txt 2>&1
+bash tools/collect_profiles.sh gpurun_out/raw_$R > $O/collect.log 2>&1
+bash tools/pmc_stalls.sh 8192 gpurun_out/pmc_stalls_$R > $O/pmc_stalls_B8192.txt 2>&1
 (echo "# dispatch order (MPCGPU_OPT_ORDER): tools/prof_solve.py B 4 8 N, kernel ms of four consecutive calls of one handle (the first has no hints)"; for a in "8192 4 8 20" "32768 4 8 20" "4096 4 8 40" "16384 4 8 40"; do for o in as_given longest_first; do echo "## $a  MPCGPU_ORDER=$o"; MPCGPU_ORDER=$o python tools/prof_solve.py $a 2>&1 | grep solve_ms | sed "s/inner.*//"; done; done) > $O/order_table.txt 2>&1
 (echo "# tail promotion off (K = 0) / on with the continuation on the side stream while the launch drains (K = -1: the library default)"; python tools/tail_ab.py 20 4096,8192,32768,131072 0,-1 2; python tools/tail_ab.py 40 4096,16384 0,-1 2; python tools/tail_ab.py 20 8192 0,-1 2 avoidance; python tools/tail_ab.py 20 8192 0,-1 2 passing; echo "# ... with the continuation as the launch BEHIND the throughput kernel (MPCGPU_TAIL_CONCURRENT=0: what a captured call records)"; MPCGPU_TAIL_CONCURRENT=0 python tools/tail_ab.py 20 4096,8192,32768 -1 2; MPCGPU_TAIL_CONCURRENT=0 python tools/tail_ab.py 40 4096,16384 -1 2) 2>&1 | grep -v amdgpu.ids > $O/tail_promotion_final.txt
 (python tools/closed_loop.py 8192 30 4 cold capacity) 2>&1 | grep -v amdgpu.ids > $O/realtime_capacity.txt
 (python tools/closed_loop.py 8192 30 4 cold streams) 2>&1 | grep -v amdgpu.ids > $O/closed_loop_streams.txt
+# round 6: the two readings of the penalty-stall rule on every workload; the concurrent continuation beside foreign work; the environment kernel
+python tools/stall_rule_report.py 2>&1 | grep -v amdgpu.ids > $O/stall_rule.txt
+python tools/foreign_work_soak.py --calls 200 2>&1 | grep -v amdgpu.ids > $O/foreign_work.txt
+python tools/bench_env.py 2>&1 | grep -v amdgpu.ids > $O/env_bench.txt
 tail -2 $O/bench.err; cat $O/bench_line.json | cut -c1-400

@@ -1,9 +1,9 @@
 #!/bin/bash
-# usage: tools/publish_profiles.sh [round = r05]  -- copies what tools/collect_round.sh merged into gpurun_out/<round>/ and gpurun_out/raw_<round>/
+# usage: tools/publish_profiles.sh [round = r06]  -- copies what tools/collect_round.sh merged into gpurun_out/<round>/ and gpurun_out/raw_<round>/
 # to profiles/ (tracked), rebuilds the roofline json from the raw CSVs and prints the figures the docs quote.
 set -e
 cd "$(dirname "$0")/.."
-R=${1:-r05}
+R=${1:-r06}
 for f in gpurun_out/$R/*.txt; do grep -v "amdgpu.ids" "$f" > profiles/${R}_$(basename "$f"); done
 cp gpurun_out/$R/bench_line.json profiles/${R}_bench_line.json
 rm -rf profiles/raw_$R; mkdir -p profiles/raw_$R

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Roofline numbers of the solve kernel, rebuilt from the raw rocprofv3 CSVs kept under profiles/.
 
-    python tools/roofline.py rebuild  [--raw profiles/raw_r05] [--out profiles/r05_roofline_bench.json]
-    python tools/roofline.py show     [profiles/r05_roofline_bench.json] [bench-line.json]
+    python tools/roofline.py rebuild  [--raw profiles/raw_r06] [--out profiles/r06_roofline_bench.json]
+    python tools/roofline.py show     [profiles/r06_roofline_bench.json] [bench-line.json]
 
 `rebuild` reads, from the raw directory (copies of what `tools/collect_profiles.sh` wrote on the GPU box):
     workload.json                 {"N_hor", "n_dyn", "batch_per_gpu"}: the bench.py arguments of every pass
@@ -223,8 +223,8 @@ def show(derived_path, bench_path=None):
 if __name__ == "__main__":
     cmd = sys.argv[1] if len(sys.argv) > 1 else "show"
     if cmd == "rebuild":
-        raw = os.path.join(ROOT, "profiles", "raw_r05")
-        out = os.path.join(ROOT, "profiles", "r05_roofline_bench.json")
+        raw = os.path.join(ROOT, "profiles", "raw_r06")
+        out = os.path.join(ROOT, "profiles", "r06_roofline_bench.json")
         a = sys.argv[2:]
         while a:
             if a[0] == "--raw": raw = a[1]
@@ -233,5 +233,5 @@ if __name__ == "__main__":
         d = rebuild(raw, out)
         print(json.dumps({k: v for k, v in d.items() if k != "raw_per_launch"}, indent=1))
     else:
-        show(sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r05_roofline_bench.json"),
+        show(sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r06_roofline_bench.json"),
              sys.argv[3] if len(sys.argv) > 3 else None)

@@ -28,6 +28,14 @@
 #define MPC_PRIO_CHAIN() __builtin_amdgcn_s_setprio(2)
 #define MPC_PRIO_ITEMS() __builtin_amdgcn_s_setprio(0)
 #define MPC_ITEM_LOOP _Pragma("unroll 1")  // item loops: keep the loads of one iteration in flight, not of all (other policies: +-1 %, round 2)
+// Round 6: item phase B (the weighted gradients of the hard dynamic-obstacle constraint) re-derived every (row, step) item of phase A --
+// table reads, ellipse-frame coordinates, the indicator -- to form  W_i * d(Ih)/d(position).  With MPC_CACHE_B the unweighted derivative
+// of the first MPC_CACHE_B_TRIPS trips (rows c_isub, c_isub + LPS, ...: nine rows at N_hor = 20) stays in registers from phase A (zero
+// outside the ellipse) and phase B is one table read and two fused multiply-adds per trip; rows beyond them are re-derived as before.
+// The same expression values in the same order: same bits.  Compiled horizons with a uniform lane split only (N_hor = 20).
+#ifndef MPC_CACHE_B
+#define MPC_CACHE_B 1
+#endif
 
 namespace mpcgpu {
 
@@ -1107,6 +1115,9 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     // (+1 %, measured) and the rows are walked as in rounds 1-3.
     constexpr bool HM = !UNIFORM;
     unsigned hmask = 0u;
+    // MPC_CACHE_B: d(Ih)/d(position) of this lane's first three rows, zero outside the hard ellipse (see the knob's comment)
+    constexpr bool CB = MPC_CACHE_B != 0 && UNIFORM && !P::DUO && NT != 0;
+    double cbx0 = 0.0, cby0 = 0.0, cbx1 = 0.0, cby1 = 0.0, cbx2 = 0.0, cby2 = 0.0;
     const int minLPS = UNIFORM ? PW / N : (PW - N) / N + 1;
     // BALANCED WALK (round 4, N_hor = 40).  Steps 0 .. NL2-1 have two item lanes, the NS1 steps behind them ONE: walking the rows
     // step by step, those lanes make Kd trips while the others are done after Kd / 2 -- and the wavefront waits for them.  Here
@@ -1279,30 +1290,59 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
                 if (P::any(inside)) hmask |= 1u << t;
             }
         } else {
+        // one (row, step) item of phase A; (tx, ty) receive d(Ih)/d(px, py) when the position is inside the hard ellipse (CB)
+        auto dyn_a1 = [&](int i, double& tx, double& ty) -> bool {
+            const DynItem d = dyn_item<SC, AXIS, LIN>(cx, i, k, N, px, py);
+            const double a2 = d.a * d.a, b2 = d.b * d.b;
+            const double Ih = 1.0 - a2 * d.ihx - b2 * d.ihy;
+            if (Ih > 0.0) {
+                lds_add(cx.H + i, Ih);      // D_i = sum_k max(0, Ih(i, k)): accumulated where the terms arise
+                if (CB && want_grad) {      // the factors phase B multiplies the row weight W_i with
+                    if (AXIS) {
+                        tx = -2.0 * d.a * d.ihx;
+                        ty = 2.0 * d.b * d.ihy;
+                    } else {
+                        tx = -2.0 * d.a * d.ca * d.ihx - 2.0 * d.b * d.sa * d.ihy;
+                        ty = -2.0 * d.a * d.sa * d.ihx + 2.0 * d.b * d.ca * d.ihy;
+                    }
+                }
+            }
+            const double Is = 1.0 - a2 * d.isx - b2 * d.isy;
+            if (Is > 0.0) {
+                cost_l += d.wgt * Is * Is;
+                const double wI = 2.0 * d.wgt * Is;
+                if (AXIS) {   // the general terms with cos = 1, sin = 0: the products by 1 are exact, those by 0 vanish
+                    gx += wI * (-2.0 * d.a * d.isx);
+                    gy += wI * (2.0 * d.b * d.isy);
+                } else {
+                    gx += wI * (-2.0 * d.a * d.ca * d.isx - 2.0 * d.b * d.sa * d.isy);
+                    gy += wI * (-2.0 * d.a * d.sa * d.isx + 2.0 * d.b * d.ca * d.isy);
+                }
+            }
+            return Ih > 0.0;
+        };
+        if (CB) {
+            int i = c_isub;
+            if (i < cx.Kd) anyh |= dyn_a1(i, cbx0, cby0);
+            i += LPS;
+            if (i < cx.Kd) anyh |= dyn_a1(i, cbx1, cby1);
+            i += LPS;
+            if (i < cx.Kd) anyh |= dyn_a1(i, cbx2, cby2);
+            i += LPS;
+            double ux, uy;      // rows beyond the cached trips: phase B re-derives them
+            MPC_ITEM_LOOP
+            for (; i < cx.Kd; i += LPS) anyh |= dyn_a1(i, ux, uy);
+        } else {
         MPC_ITEM_LOOP
         for (int t = 0, i = c_isub; HM ? t < ntrip : i < cx.Kd; ++t, i += LPS) {
             bool inside = false;
             if (!HM || i < cx.Kd) {
-                const DynItem d = dyn_item<SC, AXIS, LIN>(cx, i, k, N, px, py);
-                const double a2 = d.a * d.a, b2 = d.b * d.b;
-                const double Ih = 1.0 - a2 * d.ihx - b2 * d.ihy;
-                inside = Ih > 0.0;
+                double ux, uy;
+                inside = dyn_a1(i, ux, uy);
                 anyh |= inside;
-                if (Ih > 0.0) lds_add(cx.H + i, Ih);      // D_i = sum_k max(0, Ih(i, k)): accumulated where the terms arise
-                const double Is = 1.0 - a2 * d.isx - b2 * d.isy;
-                if (Is > 0.0) {
-                    cost_l += d.wgt * Is * Is;
-                    const double wI = 2.0 * d.wgt * Is;
-                    if (AXIS) {   // the general terms with cos = 1, sin = 0: the products by 1 are exact, those by 0 vanish
-                        gx += wI * (-2.0 * d.a * d.isx);
-                        gy += wI * (2.0 * d.b * d.isy);
-                    } else {
-                        gx += wI * (-2.0 * d.a * d.ca * d.isx - 2.0 * d.b * d.sa * d.isy);
-                        gy += wI * (-2.0 * d.a * d.sa * d.isx + 2.0 * d.b * d.ca * d.isy);
-                    }
-                }
             }
             if (HM && P::any(inside)) hmask |= 1u << t;
+        }
         }
         }
     }
@@ -1391,6 +1431,30 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
                     int i, kk; double qx, qy;
                     const bool foreign = trip_item(t, k, px, py, i, kk, qx, qy);
                     if (i < cx.Kd) dyn_b(i, kk, qx, qy, foreign);
+                }
+            } else if (any_h && CB) {
+                // the cached trips: W_i times the factor phase A left (zero where the position is outside the ellipse: gx + W_i * 0 = gx)
+                int i = c_isub;
+                if (i < cx.Kd) { const double wi = cx.W[i]; gx += wi * cbx0; gy += wi * cby0; }
+                i += LPS;
+                if (i < cx.Kd) { const double wi = cx.W[i]; gx += wi * cbx1; gy += wi * cby1; }
+                i += LPS;
+                if (i < cx.Kd) { const double wi = cx.W[i]; gx += wi * cbx2; gy += wi * cby2; }
+                i += LPS;
+                MPC_ITEM_LOOP
+                for (; i < cx.Kd; i += LPS) {
+                    const DynItem d = dyn_item<SC, AXIS, LIN>(cx, i, k, N, px, py);
+                    const double Ih = 1.0 - d.a * d.a * d.ihx - d.b * d.b * d.ihy;
+                    if (Ih > 0.0) {
+                        const double wi = cx.W[i];
+                        if (AXIS) {
+                            gx += wi * (-2.0 * d.a * d.ihx);
+                            gy += wi * (2.0 * d.b * d.ihy);
+                        } else {
+                            gx += wi * (-2.0 * d.a * d.ca * d.ihx - 2.0 * d.b * d.sa * d.ihy);
+                            gy += wi * (-2.0 * d.a * d.sa * d.ihx + 2.0 * d.b * d.ca * d.ihy);
+                        }
+                    }
                 }
             } else if (any_h) {
                 MPC_ITEM_LOOP
