@@ -794,6 +794,16 @@ def cpu_baseline(cfg, p_all, budget_s, gpu_u=None, gpu_status=None, family_sampl
     for fam, smp in (family_samples or {}).items():
         u_f, _, res_f, _ = oracle.solve_batch(ocfg, smp["p"], nthreads=cores)
         families[fam] = compare(u_f, res_f["status"], smp["u"], smp["status"])
+    if parity is not None:
+        # The headline family is cap-limited: a handful of converged pairs.  The tolerance is carried by the convergent families at the same
+        # horizon and obstacle counts (the first problems of the timed side legs): their pairs are added here, and `feeds` says who gave what.
+        feeds = {"headline_sample": parity["converged_on_both_sides"], **{f: v["converged_on_both_sides"] for f, v in families.items()}}
+        allp = [parity] + list(families.values())
+        within = [v["max_abs_du_of_the_pairs_within"] for v in allp if v["max_abs_du_of_the_pairs_within"] is not None]
+        parity["converged_pairs_total"] = int(sum(feeds.values()))
+        parity["feeds"] = feeds
+        parity["pairs_beyond_tolerance_total"] = int(sum(v["pairs_beyond_tolerance"] for v in allp))
+        parity["max_abs_du_of_the_pairs_within_total"] = max(within) if within else None
     return {"value": S / dt, "unit": "solves/s", "cores": used, "kind": "port", "parity_on_sample": parity, "parity_on_families": families or None,
             "per_core_solves_per_s": S / dt / used,
             "host": {"logical_cpus": hc["logical_cpus"], "sched_affinity": hc["affinity"],

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 def test_bench_line_contract_and_in_run_counters():
     B = 4096
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", str(B), "--steps", "2", "--warmup", "1",
-                        "--cpu-seconds", "2", "--no-convergent", "--no-sweep", "--no-closed-loop"], cwd=ROOT, stdout=subprocess.PIPE,
+                        "--cpu-seconds", "2", "--no-sweep", "--no-closed-loop"], cwd=ROOT, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
@@ -41,6 +41,18 @@ def test_bench_line_contract_and_in_run_counters():
     assert par["problems"] >= cb["cores"] and par["tolerance"] == 1e-3 and par["same_converged_or_not"] >= 0.95
     if par["converged_on_both_sides"]:
         assert par["max_abs_du_on_them"] < 1e-3
+    # ... and the tolerance rests on >= 256 converged pairs: the convergent families' samples (same horizon, same obstacle counts) feed it
+    assert par["converged_pairs_total"] >= 256 and set(par["feeds"]) == {"headline_sample", "passing", "avoidance"}
+    assert par["converged_pairs_total"] == sum(par["feeds"].values())
+    assert par["pairs_beyond_tolerance_total"] <= 2                        # two local minima of a nonconvex problem: rare, reported
+    assert par["max_abs_du_of_the_pairs_within_total"] < 1e-3
+    # what `value` is made of, at the top level; the reading of the stall rule; the host-pointer boundary
+    assert d["converged_fraction"] == d["config"]["converged_fraction"] and 0.0 <= d["converged_fraction"] <= 1.0
+    assert abs(d["converged_solves_per_s"] - d["converged_fraction"] * d["value"]) < 1e-6 * d["value"] + 1e-9
+    assert d["config"]["penalty_stall"] in ("either", "both")
+    hb = d["config"]["host_boundary"]
+    assert hb["pageable"]["value"] > 0 and hb["pinned"]["value"] > 0 and 0.0 <= hb["pinned"]["not_the_solve_kernels"] < 0.5
+    assert hb["one_robot_per_call"]["calls"] >= 16 and hb["one_robot_per_call"]["ms_per_call_median"] > 0
     if ro["measured_in_run"]["traffic"]:
         assert shutil.which("rocprofv3") and ro["measured_in_run"]["secondary"]
         assert ro["traffic"] > 21944 * B                                   # the kernel's own cold state on top of the inputs
