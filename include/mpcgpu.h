@@ -192,8 +192,10 @@ int32_t mpcgpu_reserve_batch(void* handle, int32_t B);
  *     their results differ by floating-point summation order only.
  *   MPCGPU_OPT_TEAM_BATCH  largest batch that is solved by the LATENCY kernel (csrc/mpc_team.hpp: one problem per workgroup of
  *       four wavefronts that evaluate the Lipschitz test and the line-search trials of a PANOC step side by side; compaction
- *       fused; LDS carve from the configured maxima, nothing read back before the launch).  -1 (default): 4 x the number of
- *       compute units (the measured break-even against the throughput kernel is 1000-1500 problems); 0 switches it off.  Every horizon
+ *       fused; LDS carve from the configured maxima, nothing read back before the launch).  -1 (default, ABI 8): 2 x the number of
+ *       compute units = the four-wavefront form; a larger value (up to 4 x the number of compute units, the default of ABI <= 7) adds the
+ *       mid-range form with two wavefronts per problem (profiles/r06_team_sweep.txt: under the default penalty-stall reading the
+ *       throughput kernel with its tail promotion is the faster one from 640 problems up); 0 switches it off.  Every horizon
  *       whose carve fits the 160 KiB of a compute unit; results are bitwise those of the throughput kernel.
  *   MPCGPU_OPT_ORDER  (ABI 5) in which order the throughput kernel starts the problems of a batch that is larger than what is
  *       resident at once (12 - 16 problems per compute unit, by the registers and the LDS carve of the kernel the batch runs on).

@@ -56,7 +56,7 @@ class _Lbfgs:
 
 
 def solve(cfg: OracleConfig, p, u0=None, y0=None, c0=None):
-    """Returns dict(u, y, cost, status, inner_iters, outer_iters)."""
+    """Returns dict(u, y, cost, status, inner_iters, outer_iters, penalty)."""
     N = cfg.N
     n = 2 * N
     lo = np.tile([cfg.lin_vel_min, -cfg.ang_vel_max], N)
@@ -157,4 +157,4 @@ def solve(cfg: OracleConfig, p, u0=None, y0=None, c0=None):
     if outer == cfg.max_outer:
         status = 1
     return dict(u=u, y=y_plus, cost=cost_grad(cfg, u, p, 0.0, y)["f"], status=status, inner_iters=inner_total,
-                outer_iters=outer)
+                outer_iters=outer, penalty=c)

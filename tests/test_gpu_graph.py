@@ -107,12 +107,12 @@ def test_small_batches_capture_without_a_reservation(B):
     dev = torch.device("cuda", 0)
     sc = scenes.make_batch(cfg, B, n_dyn=6, seed=15, dyn_clearance=0.1, box_clearance=0.3)
     p = torch.from_numpy(sc["p"]).to(dev)
-    ref_solver = BatchSolver(cfg)
+    ref_solver = BatchSolver(cfg, latency_batch=1024)      # the whole latency range, mid-range form included (the default ends at 512)
     ref = _out(B, 40, dev)
     ref_solver.solve_device(p, ref, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert ref_solver.last_shape()["latency_kernel"]
-    bs = BatchSolver(cfg)
+    bs = BatchSolver(cfg, latency_batch=1024)
     bs.reserve_batch(B)
     out = _out(B, 40, dev)
     bs.solve_device(p, out, stream=torch.cuda.current_stream().cuda_stream)     # one eager call: LDS opt-in of the kernel

@@ -102,7 +102,7 @@ def test_selection_rule_and_single_problem_call():
     sc = scenes.make_batch(cfg, 2048, n_dyn=4, seed=3, dyn_clearance=0.1, box_clearance=0.3)
     bs = BatchSolver(cfg)
     big = bs.solve(sc["p"])
-    assert not bs.last_shape()["latency_kernel"]                  # 2048 > 4 x 256 compute units
+    assert not bs.last_shape()["latency_kernel"]                  # 2048 > 2 x 256 compute units
     one = bs.solve(sc["p"][17])
     assert bs.last_shape()["latency_kernel"]
     assert np.array_equal(one.solution[0], big.solution[17]) and one.status[0] == big.status[17]
@@ -162,7 +162,7 @@ def test_mid_batches_run_two_wavefronts_per_problem_bitwise_equal_too(N, B, caps
     whole batch is resident at once.  Same device functions: every output is bitwise that of the throughput kernel."""
     cfg = make_cfg(N, solver_max_inner_iterations=caps[0], solver_max_outer_iterations=caps[1])
     sc = scenes.make_batch(cfg, B, n_dyn=4, seed=123, dyn_clearance=0.1, box_clearance=0.3)
-    fast, seq = BatchSolver(cfg), BatchSolver(cfg, latency_batch=0)
+    fast, seq = BatchSolver(cfg, latency_batch=1024), BatchSolver(cfg, latency_batch=0)     # (MPCGPU_OPT_TEAM_BATCH = 1024: the mid-range form)
     a, b = fast.solve(sc["p"]), seq.solve(sc["p"])
     took = fast._L.mpcgpu_last_latency_kernel(fast._h)
     # N_hor = 20: four two-wavefront workgroups fit a compute unit; N_hor = 40: they do not, the throughput kernel runs
@@ -205,7 +205,7 @@ def test_latency_kernel_decision_trace_is_bitwise_the_throughput_kernel_trace(B)
     cfg = make_cfg(20, solver_max_inner_iterations=40, solver_max_outer_iterations=4)
     sc = scenes.make_batch(cfg, B, n_dyn=8, seed=55)
     out = []
-    for kw in ({}, dict(latency_batch=0)):
+    for kw in (dict(latency_batch=1024), dict(latency_batch=0)):
         bs = BatchSolver(cfg, library=variant_path("trace"), **kw)
         bs.set_trace(160)
         res = bs.solve(sc["p"], np.tile([0.6, 0.1], (B, 20)))

@@ -113,15 +113,18 @@ def test_iteration_caps_and_status_codes():
     assert np.all(res["inner_iters"] <= 2 * 3)
 
 
-@pytest.mark.parametrize("max_inner,max_outer,tol", [(3, 1, 1e-9), (8, 2, 1e-7), (12, 3, 1e-4), (20, 1, 1e-4)])
-def test_c_oracle_follows_the_independent_numpy_restatement(max_inner, max_outer, tol):
+@pytest.mark.parametrize("max_inner,max_outer,tol,stall", [(3, 1, 1e-9, "either"), (8, 2, 1e-7, "either"), (12, 3, 1e-4, "either"),
+                                                           (20, 1, 1e-4, "either"), (12, 3, 1e-4, "both"), (6, 5, 1e-4, "either"),
+                                                           (6, 5, 1e-4, "both")])
+def test_c_oracle_follows_the_independent_numpy_restatement(max_inner, max_outer, tol, stall):
     """The solver iteration cannot be pinned against OpEn itself, so it is written twice -- in C (the oracle) and in
     numpy from the algorithm statement of DESIGN.md section 3 -- and the two must agree step for step (rounding
     differences grow with the iteration count, hence the budgets)."""
     from oracle import panoc_numpy
     from trajtrack_mpcndqn_rlboost_amd import scenes
-    cfg = make_cfg(20, solver_max_inner_iterations=max_inner, solver_max_outer_iterations=max_outer)
+    cfg = make_cfg(20, solver_max_inner_iterations=max_inner, solver_max_outer_iterations=max_outer, solver_penalty_stall=stall)
     ocfg = oracle_cfg(cfg)
+    assert ocfg.stall_rule == (1 if stall == "both" else 0)
     sc = scenes.make_batch(cfg, 6, n_dyn=4, n_other=1, seed=17)
     u0 = np.tile([0.5, 0.05], (6, 20))
     u, y, res, _ = oracle.solve_batch(ocfg, sc["p"], u0, nthreads=2)
@@ -129,6 +132,7 @@ def test_c_oracle_follows_the_independent_numpy_restatement(max_inner, max_outer
         r = panoc_numpy.solve(ocfg, sc["p"][i], u0[i])
         assert r["inner_iters"] == res["inner_iters"][i] and r["outer_iters"] == res["outer_iters"][i]
         assert r["status"] == res["status"][i]
+        assert r["penalty"] == res["penalty"][i]          # the path of the penalty: the witness of the stall rule (10 * 5^k)
         assert np.max(np.abs(r["u"] - u[i])) < tol
         assert np.max(np.abs(r["y"] - y[i])) < 1e3 * tol * max(1.0, np.max(np.abs(y[i])))
         assert abs(r["cost"] - res["cost"][i]) < 10 * tol * max(1.0, abs(res["cost"][i]))

@@ -24,12 +24,12 @@ HBM_PEAK_GBS = 8000.0
 
 
 def measured_traffic(B):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r04_env_hbm_traffic.json), when they were
-    collected on this batch size."""
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r06_env_roofline.json, made by tools/env_counters.sh on
+    this round's build), when they were collected on this batch size."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r04_env_hbm_traffic.json")) as fh:
+        with open(os.path.join(ROOT, "profiles", "r06_env_roofline.json")) as fh:
             d = json.load(fh)
-        return d["env_step_kernel_bytes_per_launch"] if d["workload"]["batch_per_gpu"] == B else None
+        return d["traffic_bytes_per_launch"] if d["batch"] == B else None
     except (OSError, KeyError, ValueError):
         return None
 

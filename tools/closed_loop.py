@@ -191,7 +191,7 @@ def device_closed_loop_streams(cfg, B=8192, streams=2, ticks=30, warmup_ticks=5,
     return res
 
 
-def realtime_capacity(cfg, warm=False, order="longest_first", lo=2048, hi=8192, step=512, ticks=30, warmup_ticks=5, n_dyn=4, device=0,
+def realtime_capacity(cfg, warm=False, order="longest_first", lo=2048, hi=12288, step=512, ticks=30, warmup_ticks=5, n_dyn=4, device=0,
                       limit_ms=None, streams=1):
     """The largest fleet per GPU (a multiple of `step`) whose WORST control tick of the scene-1 run stays within the sampling
     time `ts` of the yaml (config/mpc_default.yaml: 0.2 s) -- what the reference prints per step as its solve time

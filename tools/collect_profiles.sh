@@ -11,7 +11,7 @@ case "$OUT" in /*) ;; *) OUT="$REPO/$OUT";; esac
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-ARGS="$REPO/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-convergent --no-sweep --no-closed-loop --no-pmc $*"
+ARGS="$REPO/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-convergent --no-sweep --no-closed-loop --no-host-boundary --no-pmc $*"
 python3 - "$OUT" $ARGS <<'PY'
 import json, sys
 sys.path.insert(0, sys.argv[2].rsplit("/", 1)[0])

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Where the latency kernel stops paying: kernel time of the same batch with the latency kernel (one problem per workgroup of
-four wavefronts) and with the throughput kernel (one problem per wavefront), by batch size.  usage: team_sweep.py [family]"""
+four wavefronts) and with the throughput kernel (one problem per wavefront), by batch size.
+usage: team_sweep.py [family = passing] [penalty stall reading = the default] [horizon = 20]"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,10 +9,12 @@ sys.path.insert(0, ROOT)
 from trajtrack_mpcndqn_rlboost_amd import MpcConfig, BatchSolver, scenes
 fam = sys.argv[1] if len(sys.argv) > 1 else "passing"
 kw = dict(dyn_clearance=0.1, box_clearance=0.3) if fam == "passing" else {}
-cfg = MpcConfig()
+stall = sys.argv[2] if len(sys.argv) > 2 else None
+N = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+cfg = MpcConfig(N_hor=N, **({} if stall in (None, "default") else dict(solver_penalty_stall=stall)))
 team, solo = BatchSolver(cfg, latency_batch=1 << 20), BatchSolver(cfg, latency_batch=0)
-print(f"{fam} family, N_hor = 20, 8 dynamic obstacles; kernel ms (best of 3)")
-for B in (64, 256, 512, 768, 1024, 1536, 2048, 4096):
+print(f"{fam} family, N_hor = {N}, 8 dynamic obstacles, penalty stall rule {cfg.solver_penalty_stall}; kernel ms (best of 3)")
+for B in (64, 256, 512, 640, 768, 896, 1024, 1536, 2048, 4096):
     p = scenes.make_batch(cfg, B, n_dyn=8, seed=1236, **kw)["p"]
     t = {}
     for name, bs in (("latency", team), ("throughput", solo)):

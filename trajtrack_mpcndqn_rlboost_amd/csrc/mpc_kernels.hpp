@@ -36,6 +36,11 @@
 #ifndef MPC_CACHE_B
 #define MPC_CACHE_B 1
 #endif
+// ... the same for the balanced walk of N_hor = 40: the first four trips of a lane's OWN rows (the foreign items and later trips are
+// re-derived).  An experiment knob: 0 unless measured faster (the 168-register kernel has no register to spare).
+#ifndef MPC_CACHE_B40
+#define MPC_CACHE_B40 0
+#endif
 
 namespace mpcgpu {
 
@@ -1117,7 +1122,8 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
     unsigned hmask = 0u;
     // MPC_CACHE_B: d(Ih)/d(position) of this lane's first three rows, zero outside the hard ellipse (see the knob's comment)
     constexpr bool CB = MPC_CACHE_B != 0 && UNIFORM && !P::DUO && NT != 0;
-    double cbx0 = 0.0, cby0 = 0.0, cbx1 = 0.0, cby1 = 0.0, cbx2 = 0.0, cby2 = 0.0;
+    constexpr bool CB40 = MPC_CACHE_B40 != 0 && NT != 0 && !UNIFORM && !P::DUO && balanced_shape(NT ? NT : 2, MemOf<NT>::value ? MemOf<NT>::value : 1);
+    double cbx0 = 0.0, cby0 = 0.0, cbx1 = 0.0, cby1 = 0.0, cbx2 = 0.0, cby2 = 0.0, cbx3 = 0.0, cby3 = 0.0;
     const int minLPS = UNIFORM ? PW / N : (PW - N) / N + 1;
     // BALANCED WALK (round 4, N_hor = 40).  Steps 0 .. NL2-1 have two item lanes, the NS1 steps behind them ONE: walking the rows
     // step by step, those lanes make Kd trips while the others are done after Kd / 2 -- and the wavefront waits for them.  Here
@@ -1241,11 +1247,17 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
         // one body for both walks: HM: t = 0 .. ntrip-1 for every lane, row c_isub + t LPS if it exists; else i = c_isub, c_isub + LPS ...
         if (BAL) {
             // one (row, step) item of phase A; `foreign`: the step is not this lane's own -- its gradient goes to the step's accumulator
-            auto dyn_a = [&](int i, int kk, double qx, double qy, bool foreign) -> bool {
+            auto dyn_a = [&](int i, int kk, double qx, double qy, bool foreign, double& tx, double& ty) -> bool {
                 const DynItem d = dyn_item<SC, AXIS, LIN>(cx, i, kk, N, qx, qy);
                 const double a2 = d.a * d.a, b2 = d.b * d.b;
                 const double Ih = 1.0 - a2 * d.ihx - b2 * d.ihy;
-                if (Ih > 0.0) lds_add(cx.H + i, Ih);
+                if (Ih > 0.0) {
+                    lds_add(cx.H + i, Ih);
+                    if (CB40 && want_grad) {   // the factors phase B multiplies the row weight with (own rows of the first trips)
+                        if (AXIS) { tx = -2.0 * d.a * d.ihx; ty = 2.0 * d.b * d.ihy; }
+                        else { tx = -2.0 * d.a * d.ca * d.ihx - 2.0 * d.b * d.sa * d.ihy; ty = -2.0 * d.a * d.sa * d.ihx + 2.0 * d.b * d.ca * d.ihy; }
+                    }
+                }
                 const double Is = 1.0 - a2 * d.isx - b2 * d.isy;
                 if (Is > 0.0) {
                     cost_l += d.wgt * Is * Is;
@@ -1272,20 +1284,29 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
                 return Ih > 0.0;
             };
             // trips 0 .. balT2-1: every lane walks rows of its own step (the row walk, unchanged) ...
-            MPC_ITEM_LOOP
-            for (int t = 0, i = c_isub; t < cx.balT2; ++t, i += LPS) {
+            double ux, uy;   // factors nobody keeps
+            auto own_trip = [&](int t, int i, double& tx, double& ty) {
                 bool inside = false;
-                if (i < cx.Kd) inside = dyn_a(i, k, px, py, false);
+                if (i < cx.Kd) inside = dyn_a(i, k, px, py, false, tx, ty);
                 anyh |= inside;
                 if (P::any(inside)) hmask |= 1u << t;
+            };
+            int t_own = 0, i_own = c_isub;
+            if (CB40) {
+                if (t_own < cx.balT2) { own_trip(t_own, i_own, cbx0, cby0); ++t_own; i_own += LPS; }
+                if (t_own < cx.balT2) { own_trip(t_own, i_own, cbx1, cby1); ++t_own; i_own += LPS; }
+                if (t_own < cx.balT2) { own_trip(t_own, i_own, cbx2, cby2); ++t_own; i_own += LPS; }
+                if (t_own < cx.balT2) { own_trip(t_own, i_own, cbx3, cby3); ++t_own; i_own += LPS; }
             }
+            MPC_ITEM_LOOP
+            for (; t_own < cx.balT2; ++t_own, i_own += LPS) own_trip(t_own, i_own, ux, uy);
             // ... trips balT2 .. balT-1: the single-lane steps go on with their rows, the other lanes take foreign items
             MPC_ITEM_LOOP
             for (int t = cx.balT2; t < ntrip; ++t) {
                 bool inside = false;
                 int i, kk; double qx, qy;
                 const bool foreign = trip_item(t, k, px, py, i, kk, qx, qy);
-                if (i < cx.Kd) inside = dyn_a(i, kk, qx, qy, foreign);
+                if (i < cx.Kd) inside = dyn_a(i, kk, qx, qy, foreign, ux, uy);
                 anyh |= inside;
                 if (P::any(inside)) hmask |= 1u << t;
             }
@@ -1420,10 +1441,20 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
                         }
                     }
                 };
+                int t_own = 0, i_own = c_isub;
+                if (CB40) {   // the cached trips: W_i times the factor phase A left (zero outside the ellipse)
+                    auto cached = [&](double tx, double ty) {
+                        if (t_own < cx.balT2) {
+                            if (((hmask >> t_own) & 1u) && i_own < cx.Kd) { const double wi = cx.W[i_own]; gx += wi * tx; gy += wi * ty; }
+                            ++t_own; i_own += LPS;
+                        }
+                    };
+                    cached(cbx0, cby0); cached(cbx1, cby1); cached(cbx2, cby2); cached(cbx3, cby3);
+                }
                 MPC_ITEM_LOOP
-                for (int t = 0, i = c_isub; t < cx.balT2; ++t, i += LPS) {
-                    if (!((hmask >> t) & 1u) || i >= cx.Kd) continue;          // no lane of this trip is inside a hard ellipse
-                    dyn_b(i, k, px, py, false);
+                for (; t_own < cx.balT2; ++t_own, i_own += LPS) {
+                    if (!((hmask >> t_own) & 1u) || i_own >= cx.Kd) continue;          // no lane of this trip is inside a hard ellipse
+                    dyn_b(i_own, k, px, py, false);
                 }
                 MPC_ITEM_LOOP
                 for (int t = cx.balT2; t < ntrip; ++t) {

@@ -491,7 +491,11 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
     BatchPtrs io{};
     // Small batches take the latency kernel: one problem per workgroup of four wavefronts, compaction fused, carve from the
     // configured maxima -- one launch, nothing read back.  Results are bitwise those of the throughput kernel.
-    const int team_cap = h->team_max_batch >= 0 ? h->team_max_batch : 4 * h->num_cus;  // measured break-even: 1000-1500 problems (tools/team_sweep.py)
+    // Default (round 6): up to TWO problems per compute unit -- the four-wavefront form.  The mid-range form (two wavefronts per problem up to four
+    // problems per compute unit; MPCGPU_OPT_TEAM_BATCH = 1024 selects it) was the default of rounds 3-5, measured under the "both" reading of the
+    // stall rule; under the default reading of this round the throughput kernel with its whole-batch tail promotion is 1-13 % faster from 640 to 1024
+    // problems on every family (profiles/r06_team_sweep.txt: a problem whose line search runs all ten halvings costs six passes on two wavefronts)
+    const int team_cap = h->team_max_batch >= 0 ? h->team_max_batch : 2 * h->num_cus;
     h->last_team = 0;
     h->last_yield_cap = 0;
     h->tail_timed = false;
@@ -1230,7 +1234,7 @@ int32_t mpcgpu_reserve_batch(void* handle, int32_t B) {
     }
     // A batch of the latency range is captured in its one-launch form (tables for the configured maxima: more than 64 KiB of
     // dynamic LDS for the yaml's slot counts), whatever form an eager call of the same size takes: opt that kernel in now.
-    const int team_cap = h->team_max_batch >= 0 ? h->team_max_batch : 4 * h->num_cus;
+    const int team_cap = h->team_max_batch >= 0 ? h->team_max_batch : 2 * h->num_cus;
     if (B <= team_cap && !use_duo(h) && !h->reserved) {
         KParams kt = h->kp;
         fill_team_layout(kt, TEAM_WAVES, h->cfg.Nstcobs, h->cfg.Nother, h->cfg.Ndynobs);
