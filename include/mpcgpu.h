@@ -246,10 +246,16 @@ int32_t mpcgpu_reserve_batch(void* handle, int32_t B);
  *       that share the GPU, graph replays of another handle, or foreign kernels of the caller on other streams: those cost time only
  *       (the lowest-priority side stream waits; every wait is bounded and a sweep launch behind the throughput kernel finishes what is
  *       left) -- tests/test_gpu_foreign_work.py -- and a process that shares its GPU that way sets this option to 0.
+ *   MPCGPU_OPT_TAIL_GRADUAL  (ABI 8) EXPERIMENT, default 0 = off.  G > 0: with the concurrent continuation a problem may also leave the
+ *       throughput launch -- at the start of an inner problem, once every problem of the launch has begun -- while (promoted + 1) * G <=
+ *       finished and less than half of the list is taken, i.e. long before the last K problems.  Bitwise the same results
+ *       (tests/test_gpu_yield.py) -- and measured SLOWER or equal on every batch and family (G = 4 / 8 / 16: up to +11 / +13 / +7 %,
+ *       profiles/r06_tail_gradual_ab.txt): four wavefronts per promoted problem cost 2.5 x the issue slots of one for 1.6 x its speed,
+ *       which pays only on a draining GPU.
  */
 enum { MPCGPU_OPT_LINESEARCH_FALLBACK = 1, MPCGPU_OPT_PAIRING = 2, MPCGPU_OPT_TEAM_BATCH = 3, MPCGPU_OPT_ORDER = 4,
        MPCGPU_OPT_LINEAR_TABLES = 5, MPCGPU_OPT_TAIL_PROMOTION = 6, MPCGPU_OPT_TAIL_POLL = 7, MPCGPU_OPT_TAIL_WAVES = 8,
-       MPCGPU_OPT_TAIL_CONCURRENT = 9, MPCGPU_OPT_PENALTY_STALL = 10 };
+       MPCGPU_OPT_TAIL_CONCURRENT = 9, MPCGPU_OPT_PENALTY_STALL = 10, MPCGPU_OPT_TAIL_GRADUAL = 11 };
 int32_t mpcgpu_set_option(void* handle, int32_t option, double value);
 
 /* Register-allocation variant the last solve call was launched with: 3 (148 / 168 VGPRs) or 4 wavefronts per SIMD

@@ -206,6 +206,29 @@ def test_closed_loop_trajectories_do_not_depend_on_the_promotion():
             assert ref["status_histogram_per_tick"] == r["status_histogram_per_tick"]
 
 
+@pytest.mark.parametrize("N,B,fam", [(20, 4096, "passing"), (20, 6144, "avoidance"), (40, 3072, "passing")])
+def test_gradual_promotion_is_bitwise_neutral_too(N, B, fam):
+    """MPCGPU_OPT_TAIL_GRADUAL (round 6): with the continuation beside the launch, problems may leave -- at the start of an inner problem,
+    once every problem of the launch has begun -- while (promoted + 1) * G <= finished, long before the last K problems are reached.  When
+    a problem leaves never changes what it computes: every output bitwise that of a launch without promotion, the time-out counter 0."""
+    cfg = make_cfg(N)
+    sc = scenes.make_family(cfg, B, fam, n_dyn=8, seed=77 + N)
+    r0, e0, _, _, t0 = _solve(cfg, sc["p"], 0)
+    for G in (4, 16):
+        bs = BatchSolver(cfg, latency_batch=0, order="as_given")
+        bs.set_tail_gradual(G)
+        for _ in range(2):
+            r = bs.solve(sc["p"])
+            cap, moved = bs.last_tail_promotion()
+            conc, timeouts = bs.last_tail_timeouts()
+            _same(r0, r)
+            assert cap > 0 and moved > 0 and conc and timeouts == 0, (G, cap, moved, conc, timeouts)
+        e = bs.last_eval_counts(B)
+        assert np.array_equal(e0[0], e[0]) and np.array_equal(e0[1], e[1])
+        print(f"\nN_hor {N} B {B} {fam} G = {G}: {moved} of {cap} promoted, {bs.last_timing()['solve_ms']:.1f} ms (no promotion: {t0:.1f})")
+        bs.close()
+
+
 def test_random_batches_on_reused_handles_keep_their_bits():
     """tools/probes/concurrent_stress.py, a short run: random horizons, batch sizes, families, orders and starts, three calls per
     handle (list, counters and side stream reused) -- promotion with the continuation beside the draining launch against none."""

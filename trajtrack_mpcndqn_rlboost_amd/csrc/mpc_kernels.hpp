@@ -147,6 +147,11 @@ struct KParams {
     // concurrent continuation (mpc_team.hpp, CONCURRENT): 1 = the workgroups of the latency kernel wait for their list entries while
     // the throughput launch is still running; yield_total = problems of that launch (the list is final once FINISHED + LISTED reach it)
     int yield_persist, yield_total;
+    // gradual promotion (round 6, MPCGPU_OPT_TAIL_GRADUAL; only with the concurrent continuation): once every problem of the launch has
+    // begun, a problem may ALSO leave at the start of an inner problem while (promoted + 1) * yield_grad <= finished and fewer than half of
+    // the list is taken -- the teams fill the compute units the finished wavefronts free instead of waiting for the last yield_cap
+    // problems.  0 = off.
+    int yield_grad;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -2389,7 +2394,14 @@ __device__ __forceinline__ void solve_body(const KParams& kp, const BatchPtrs& i
             // (first look of this problem: it counts itself as started -- the gate of the concurrent continuation waits until every
             //  problem of the launch has, mpc_team.hpp tail_gate_kernel)
             if (num_outer == 1 && lane == 0) __hip_atomic_fetch_add(io.counts + CNT_STARTED, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__hip_atomic_load(io.counts + CNT_FINISHED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= kp.yield_from) {
+            const int fin_now = __hip_atomic_load(io.counts + CNT_FINISHED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool leave = fin_now >= kp.yield_from;
+            if (!leave && kp.yield_grad > 0) {   // gradual promotion: see KParams::yield_grad
+                const int begun = __hip_atomic_load(io.counts + CNT_STARTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int gone = __hip_atomic_load(io.counts + CNT_YIELDED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                leave = begun >= kp.yield_total && 2 * gone < kp.yield_cap && (long long)(gone + 1) * kp.yield_grad <= fin_now;
+            }
+            if (leave) {
                 if (lane == 0) yslot = __hip_atomic_fetch_add(io.counts + CNT_YIELDED, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 yslot = __builtin_amdgcn_readfirstlane(yslot);
                 if (yslot < kp.yield_cap) { yielded = true; break; }   // (the list cannot overflow: at most yield_cap problems are unfinished)

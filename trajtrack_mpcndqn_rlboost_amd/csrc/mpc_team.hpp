@@ -557,12 +557,14 @@ __global__ __launch_bounds__(WAVE * TW) MPC_TEAM_ATTR void solve_kernel_team(KPa
 // its last workgroups are still waiting when it starts to promote, and teams that fill the compute units must not wait for list
 // entries those very workgroups would write (seen once before this condition existed: a tick of 2.2 s = the wall-clock limit of
 // the wait in solve_kernel_team at the time).  One lane, asleep between looks; bounded by a wall-clock limit like every wait here.
-__global__ __launch_bounds__(WAVE) void tail_gate_kernel(int* counts, int yield_from, int total, long long max_ticks) {
+__global__ __launch_bounds__(WAVE) void tail_gate_kernel(int* counts, int yield_from, int total, long long max_ticks, int gradual) {
     if (threadIdx.x != 0) return;
     const long long t0 = wall_clock64();
     for (;;) {
         const int fin = __hip_atomic_load(counts + CNT_FINISHED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (fin >= yield_from && __hip_atomic_load(counts + CNT_STARTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= total) break;
+        const bool promoting = fin >= yield_from ||
+                               (gradual && __hip_atomic_load(counts + CNT_YIELDED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0);   // (gradual promotion: the first entry opens the gate)
+        if (promoting && __hip_atomic_load(counts + CNT_STARTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= total) break;
         if (fin + __hip_atomic_load(counts + CNT_LISTED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= total) break;   // the launch is over
         if (wall_clock64() - t0 >= max_ticks) { atomicAdd(counts + CNT_TIMEOUTS, 1); break; }
         __builtin_amdgcn_s_sleep(127);

@@ -30,6 +30,10 @@ struct DevBuf {
     size_t cap = 0;
 };
 
+#ifndef MPC_TAIL_GRADUAL_DEFAULT
+#define MPC_TAIL_GRADUAL_DEFAULT 0
+#endif
+
 struct Handle {
     mpcgpu_config cfg{};
     KParams kp{};
@@ -62,6 +66,7 @@ struct Handle {
     int yield_poll = 16; // ... builds with -DMPC_YIELD_STEP=1 only: the finished-counter is also polled every this many PANOC steps (power of two)
     int yield_waves = 0; // MPCGPU_OPT_TAIL_WAVES: wavefronts per promoted problem (0: four; two for an explicit capacity beyond four times the residency)
     int last_yield_cap = 0;  // capacity of the continuation launch of the last solve (0: none was enqueued)
+    int tail_gradual = MPC_TAIL_GRADUAL_DEFAULT;   // MPCGPU_OPT_TAIL_GRADUAL: finished problems per gradually promoted one (0 = off)
     int tail_concurrent = 1; // MPCGPU_OPT_TAIL_CONCURRENT: 1 = the continuation runs on `side` while the throughput launch drains (mpc_team.hpp CONCURRENT)
     hipStream_t side = nullptr;                      // stream of the concurrent continuation
     hipEvent_t ev_fork = nullptr, ev_join = nullptr; // launch stream -> side (records written), side -> launch stream (promoted problems solved)
@@ -187,6 +192,7 @@ constexpr bool LBFGS_IN_WORKSPACE = MPC_LBFGS_IN_WORKSPACE != 0;
 #ifndef MPC_TRY_FOUR_WAVES
 #define MPC_TRY_FOUR_WAVES 1
 #endif
+
 #ifndef MPC_FOUR_WAVES_FROM
 #define MPC_FOUR_WAVES_FROM (4 * MPC_MIN_WAVES)   // problems per compute unit from which the 128-VGPR build is taken (more than the other build holds at once)
 #endif
@@ -233,7 +239,7 @@ void fill_static_params(Handle* h) {
     // tail promotion (mpc_kernels.hpp YIELD): the iteration state a problem leaves behind when it moves to the latency kernel
     k.ws_yield = o; o += YS_SCALARS + N * YS_VECW + even(c.lbfgs_mem) + gg_doubles_c(N, c.lbfgs_mem, gram_shape(N, c.lbfgs_mem));
     k.ws_stride = (o + 15) & ~15;
-    k.yield_from = 0; k.yield_cap = 0; k.yield_mask = 15; k.yield_persist = 0; k.yield_total = 0;
+    k.yield_from = 0; k.yield_cap = 0; k.yield_mask = 15; k.yield_persist = 0; k.yield_total = 0; k.yield_grad = 0;
 }
 
 // sizes of the fixed regions: mpc_kernels.hpp (part_doubles_c, stash_doubles_c, fixed_lds) -- shared with the kernels
@@ -501,6 +507,7 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
     h->tail_timed = false;
     h->last_concurrent = false;
     h->kp.yield_from = 0;
+    h->kp.yield_grad = 0;
     bool prepared = false;
 #ifdef MPC_TRACE
     if (h->trace_cap > 0) {     // trace builds (tests): one record per PANOC step, from whichever kernel runs
@@ -715,6 +722,8 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
     // holds -- 3.37e4 -> 2.91e4 solves/s measured).
     const bool concurrent = yield_K > 0 && h->tail_concurrent && !h->capturing && yield_K <= resident && !another_launch_in_flight(h);
     if (concurrent) {
+        h->kp.yield_grad = h->tail_gradual;                  // gradual promotion needs the teams beside the launch
+        h->kp.yield_total = B;
         HIP_OK(h, hipEventRecord(h->ev_fork, s));            // the records (compaction) and the empty list are in place
         HIP_OK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
     }
@@ -783,7 +792,7 @@ int32_t solve_common(Handle* h, int32_t B, const double* p, const mpcgpu_tracker
         io.p = nullptr; io.perm = nullptr;
         if (concurrent) {
             // side stream: gate (opens at FINISHED >= yield_from and STARTED = B; 60 s limit), then one workgroup per list entry
-            hipLaunchKernelGGL(tail_gate_kernel, dim3(1), dim3(WAVE), 0, h->side, (int*)io.counts, h->kp.yield_from, B, 6000000000LL);
+            hipLaunchKernelGGL(tail_gate_kernel, dim3(1), dim3(WAVE), 0, h->side, (int*)io.counts, h->kp.yield_from, B, 6000000000LL, h->kp.yield_grad);
             kt_y.yield_persist = 1;
             LAUNCH_RESUME_N(yield_K, h->side)
             HIP_OK(h, hipGetLastError());
@@ -1289,6 +1298,10 @@ int32_t mpcgpu_set_option(void* handle, int32_t option, double value) {
         case MPCGPU_OPT_TAIL_CONCURRENT:
             if (value != 0.0 && value != 1.0) return fail(h, -1, "tail concurrent must be 0 or 1, got %g", value);
             h->tail_concurrent = (int)value;
+            return 0;
+        case MPCGPU_OPT_TAIL_GRADUAL:
+            if (value < 0.0 || value > 1024.0 || value != (double)(int)value) return fail(h, -1, "tail gradual must be 0 (off) or finished problems per promoted one (1..1024), got %g", value);
+            h->tail_gradual = (int)value;
             return 0;
         case MPCGPU_OPT_TAIL_POLL: {
             const int v = (int)value;

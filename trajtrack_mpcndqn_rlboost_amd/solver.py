@@ -34,6 +34,7 @@ OPT_TAIL_POLL = 7                 # MPCGPU_OPT_TAIL_POLL
 OPT_TAIL_WAVES = 8                # MPCGPU_OPT_TAIL_WAVES
 OPT_TAIL_CONCURRENT = 9           # MPCGPU_OPT_TAIL_CONCURRENT
 OPT_PENALTY_STALL = 10            # MPCGPU_OPT_PENALTY_STALL
+OPT_TAIL_GRADUAL = 11             # MPCGPU_OPT_TAIL_GRADUAL
 
 
 def _stream_arg(stream):
@@ -295,6 +296,8 @@ class BatchSolver:
             self.set_tail_promotion(tail_promotion)
         if os.environ.get("MPCGPU_TAIL_CONCURRENT"):
             self.set_tail_concurrent(int(os.environ["MPCGPU_TAIL_CONCURRENT"]) != 0)
+        if os.environ.get("MPCGPU_TAIL_GRADUAL"):
+            self.set_tail_gradual(int(os.environ["MPCGPU_TAIL_GRADUAL"]))
 
     def set_tail_promotion(self, problems: int, poll_steps: Optional[int] = None, waves: Optional[int] = None):
         """MPCGPU_OPT_TAIL_PROMOTION (-1 automatic, 0 off, K problems) and, for the A/B build that can leave inside an inner
@@ -309,6 +312,12 @@ class BatchSolver:
         """MPCGPU_OPT_TAIL_CONCURRENT: the continuation of the tail promotion runs on a stream of the handle's own while the
         throughput launch drains (True) or as the launch behind it (False).  Results do not depend on it (bitwise)."""
         self._check(self._L.mpcgpu_set_option(self._h, OPT_TAIL_CONCURRENT, 1.0 if on else 0.0), "mpcgpu_set_option")
+
+    def set_tail_gradual(self, finished_per_promoted: int):
+        """MPCGPU_OPT_TAIL_GRADUAL: with the concurrent continuation, a problem may also leave the throughput launch (at the start of an inner
+        problem, once every problem of the launch has begun) while (promoted + 1) * finished_per_promoted <= finished; 0 = off.  Results
+        do not depend on it (bitwise)."""
+        self._check(self._L.mpcgpu_set_option(self._h, OPT_TAIL_GRADUAL, float(finished_per_promoted)), "mpcgpu_set_option")
 
     def last_tail_promotion(self, stream: Optional[int] = None):
         """(capacity of the continuation launch of the last solve call, problems that actually moved to the latency kernel)."""
