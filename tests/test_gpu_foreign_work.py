@@ -46,5 +46,8 @@ def test_solves_beside_a_second_process_keep_their_bits():
           f"waits ended by their time limit: {r['timeouts']}; other process: exit code {r['child_rc']}, {r['child_solves_per_s']} solves/s")
     assert r["calls"] >= 8
     assert r["child_rc"] == 0 and r["child_solves_per_s"] and r["child_solves_per_s"] > 1e3
-    assert r["ms_max"] < 2000.0          # nowhere near the 60 s gate limit; a starved entry wait (0.5 s) would show up in `timeouts`
-    assert r["timeouts"] == 0
+    assert r["ms_max"] < 2000.0          # nowhere near the 60 s gate limit
+    # The waits are wall-clock bounded (0.5 s for a list entry): while the OTHER process holds the GPU a waiting workgroup's clock keeps
+    # running, so a time-out is legitimate exactly when a call was stretched that long by the time slicing (measured: calls of 0.7 s, no
+    # time-out so far); in a run without such a stretch there must be none
+    assert r["timeouts"] == 0 or r["ms_max"] >= 500.0, r

@@ -8,7 +8,6 @@ mkdir -p $O
 export MPCGPU_ORDER=as_given
 python bench.py --steps 5 --warmup 1 > $O/bench_line.json 2> $O/bench.err
 (echo "# tools/phase_prof.py on a -DMPC_PROFILE build of the final source of this round (throughput kernel; shader-clock cycles per phase; 16 resident wavefronts per CU at N = 20, 12 at N = 40)"; MPCGPU_LIB=$PWD/build_ab/libmpcgpu_prof.so python tools/phase_prof.py 8192 20; MPCGPU_LIB=$PWD/build_ab/libmpcgpu_prof.so python tools/phase_prof.py 4096 40) > $O/phase_table.txt 2>&1
-(echo "# tools/team_sweep.py bench (kernel ms, best of 3)"; python tools/team_sweep.py bench; python tools/team_sweep.py passing) > $O/team_sweep.txt 2>&1
 (echo "# config 2: N_hor = 20, 4 dynamic obstacles, B = 1024 (tools/prof_solve.py 1024 3 4 20)"; python tools/prof_solve.py 1024 3 4 20; echo "# config 3: N_hor = 40, 8 dynamic obstacles, B = 4096 / 16384 (tools/prof_solve.py B 3 8 40)"; python tools/prof_solve.py 4096 3 8 40; python tools/prof_solve.py 16384 2 8 40) > $O/config2_config3.txt 2>&1
 (echo "# tools/prof_solve.py B 2 8 20: benchmark scene family, N_hor = 20, 8 dynamic obstacles, cold start, solve kernel ms"; for B in 8192 16384 32768 65536 131072; do python tools/prof_solve.py $B 2 8 20; done) > $O/batch_scaling.txt 2>&1
 (echo "# Gram form vs two-loop recursion of the L-BFGS operator, same source otherwise (tools/ab.sh; kernel ms, 2 runs each)"; for B in 32768 8192; do echo "## N_hor = 20, B = $B"; ABB=$B bash tools/ab.sh trajtrack_mpcndqn_rlboost_amd/libmpcgpu.so trajtrack_mpcndqn_rlboost_amd/variants/libmpcgpu_twoloop.so; done) > $O/lbfgs_gram_ab.txt 2>&1
@@ -32,4 +31,7 @@ bash tools/pmc_stalls.sh 8192 gpurun_out/pmc_stalls_$R > $O/pmc_stalls_B8192.txt
 python tools/stall_rule_report.py 2>&1 | grep -v amdgpu.ids > $O/stall_rule.txt
 python tools/foreign_work_soak.py --calls 200 2>&1 | grep -v amdgpu.ids > $O/foreign_work.txt
 python tools/bench_env.py 2>&1 | grep -v amdgpu.ids > $O/env_bench.txt
+python tools/team_sweep.py bench either > $O/team_sweep.txt 2>&1; for a in "passing either" "avoidance either" "bench both" "passing both" "avoidance both" "bench either 40" "passing either 40"; do python tools/team_sweep.py $a 2>&1 | grep -v amdgpu.ids >> $O/team_sweep.txt; done
+(echo "# tests/tools/fuzz_parity.py: for s in 0..5: python tests/tools/fuzz_parity.py 150 \$s 12 (per-trial lines dropped)"; for s in 0 1 2 3 4 5; do echo "== seed $s"; python tests/tools/fuzz_parity.py 150 $s 12 2>&1 | grep -v "^trial \|^full  *[0-9]\|amdgpu.ids"; done) > $O/fuzz_parity.txt 2>&1
+python __graft_entry__.py smoke > $O/smoke.txt 2>&1
 tail -2 $O/bench.err; cat $O/bench_line.json | cut -c1-400
