@@ -36,8 +36,8 @@
 #ifndef MPC_CACHE_B
 #define MPC_CACHE_B 1
 #endif
-// ... the same for the balanced walk of N_hor = 40: the first four trips of a lane's OWN rows (the foreign items and later trips are
-// re-derived).  An experiment knob: 0 unless measured faster (the 168-register kernel has no register to spare).
+// ... the same for the balanced walk of N_hor = 40: the first MPC_CACHE_B40 (1..4) trips of a lane's OWN rows (the foreign items and later
+// trips are re-derived).  An experiment knob: 0 unless measured faster (the 168-register kernel has no register to spare).
 #ifndef MPC_CACHE_B40
 #define MPC_CACHE_B40 0
 #endif
@@ -1299,9 +1299,9 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
             int t_own = 0, i_own = c_isub;
             if (CB40) {
                 if (t_own < cx.balT2) { own_trip(t_own, i_own, cbx0, cby0); ++t_own; i_own += LPS; }
-                if (t_own < cx.balT2) { own_trip(t_own, i_own, cbx1, cby1); ++t_own; i_own += LPS; }
-                if (t_own < cx.balT2) { own_trip(t_own, i_own, cbx2, cby2); ++t_own; i_own += LPS; }
-                if (t_own < cx.balT2) { own_trip(t_own, i_own, cbx3, cby3); ++t_own; i_own += LPS; }
+                if (MPC_CACHE_B40 >= 2 && t_own < cx.balT2) { own_trip(t_own, i_own, cbx1, cby1); ++t_own; i_own += LPS; }
+                if (MPC_CACHE_B40 >= 3 && t_own < cx.balT2) { own_trip(t_own, i_own, cbx2, cby2); ++t_own; i_own += LPS; }
+                if (MPC_CACHE_B40 >= 4 && t_own < cx.balT2) { own_trip(t_own, i_own, cbx3, cby3); ++t_own; i_own += LPS; }
             }
             MPC_ITEM_LOOP
             for (; t_own < cx.balT2; ++t_own, i_own += LPS) own_trip(t_own, i_own, ux, uy);
@@ -1454,7 +1454,10 @@ __device__ __forceinline__ void eval_point(const KParams& kp, const Ctx& cx, dou
                             ++t_own; i_own += LPS;
                         }
                     };
-                    cached(cbx0, cby0); cached(cbx1, cby1); cached(cbx2, cby2); cached(cbx3, cby3);
+                    cached(cbx0, cby0);
+                    if (MPC_CACHE_B40 >= 2) cached(cbx1, cby1);
+                    if (MPC_CACHE_B40 >= 3) cached(cbx2, cby2);
+                    if (MPC_CACHE_B40 >= 4) cached(cbx3, cby3);
                 }
                 MPC_ITEM_LOOP
                 for (; t_own < cx.balT2; ++t_own, i_own += LPS) {

@@ -281,13 +281,16 @@ __global__ __launch_bounds__(WAVE * TW) MPC_TEAM_ATTR void solve_kernel_team(KPa
     // write its flag of pass k + 1 while a slow one still reads the four flags of pass k.
     int pub_slot = 0;
     auto publish = [&](double flag, double* all) {
+        PROF_MARK(13);
         if (lane == 0) XF[wid * TEAM_XCH + pub_slot] = flag;
         __syncthreads();
         for (int j = 0; j < TW; ++j) all[j] = uniform(XF[j * TEAM_XCH + pub_slot]);
         pub_slot ^= 1;
+        PROF_MARK(10);
     };
     // the winning wavefront hands over (point, gradient, half step; cost, ||grad||^2, ||gradient step - half step||^2)
     auto adopt = [&](int winner, double tcost, double tgg, double td2h, double thv, double thw) {
+        PROF_MARK(13);
         if (wid == winner) {
             if (vl) {
                 double* r = XV + lane * 6;
@@ -303,6 +306,7 @@ __global__ __launch_bounds__(WAVE * TW) MPC_TEAM_ATTR void solve_kernel_team(KPa
             uv = 0.0; uw = 0.0; gv = 0.0; gw = 0.0; hv = 0.0; hw = 0.0;
         }
         cost = uniform(XV[N * 6]); gg = uniform(XV[N * 6 + 1]); d2h = uniform(XV[N * 6 + 2]);
+        PROF_MARK(11);
     };
     // The wall clock differs between wavefronts by a few ticks: wavefront 0 decides for all (two alternating slots, so that a
     // wavefront that is one barrier behind still reads the verdict it was meant to read).
@@ -322,6 +326,8 @@ __global__ __launch_bounds__(WAVE * TW) MPC_TEAM_ATTR void solve_kernel_team(KPa
             resume_pending = false;
             step_begin = true;
         } else {
+        PROF_MARK(13);    // (profile builds: slots 10 verdict barrier, 11 adoption, 12 L-BFGS pair + direction, 13 other logic between two passes,
+        PROF_COUNT(16);   //  14 step residual; counts: 16 passes, 17 PANOC steps; wavefront 0 of every team reports)
         eval_point<NT, SC, P>(kp, cx, ev, ew, c, icm, ya, yb, want_grad, state == TS_OUTER, o PROF_PASS);
 
         if (state == TS_INIT0) {
@@ -503,7 +509,11 @@ __global__ __launch_bounds__(WAVE * TW) MPC_TEAM_ATTR void solve_kernel_team(KPa
                 }
             }
             if (!inner_done) {
-                if (panoc_step_residual<P>(cx, kp, vl, uv, uw, hv, hw, gv, gw, gamma, iter, akkt_tol, rv_, rw_, nfpr, ip)) {
+                PROF_MARK(13);
+                PROF_COUNT(17);
+                const bool solved = panoc_step_residual<P>(cx, kp, vl, uv, uw, hv, hw, gv, gw, gamma, iter, akkt_tol, rv_, rw_, nfpr, ip);
+                PROF_MARK(14);
+                if (solved) {
                     inner_done = true;
                 } else {
                     lip_it = 0;
@@ -514,9 +524,11 @@ __global__ __launch_bounds__(WAVE * TW) MPC_TEAM_ATTR void solve_kernel_team(KPa
                         sigma = uniform(KC(K_SIGMA) * ig);
                         head_spec = lb.head;
                         double lb_pr = 0.0;
+                        PROF_MARK(13);
                         lb.template update<P, NT, MEMT>(cx, kp, vl, lane, uv, uw, rv_, rw_, nfpr, lm, lb_pr);
                         wave_sync();
                         lb.template direction<P, NT, MEMT, true>(cx, kp, vl, lane, rv_, rw_, lm, lb_pr, dv, dw);
+                        PROF_MARK(12);
                         rhs = panoc_fbe_rhs(cost, gamma, ig, gg, d2h, sigma, nfpr);
                         if (wid == 0) { ev = hv; ew = hw; want_grad = false; }
                         else { trial_point(pow2_neg(wid - 1)); want_grad = true; }
@@ -531,6 +543,9 @@ __global__ __launch_bounds__(WAVE * TW) MPC_TEAM_ATTR void solve_kernel_team(KPa
         }
     }
 
+#ifdef MPC_PROFILE
+    if (wid == 0) { prof.mark(13); prof.flush(); }
+#endif
     if (__ballot(vl && !(isfinite(uv) && isfinite(uw))) != 0ull || !isfinite(f_final)) status = 3;
     if (wid == 0) {
         if (vl) {
