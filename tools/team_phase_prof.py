@@ -22,7 +22,7 @@ assert bs.last_shape()["latency_kernel"]
 bs._L.mpcgpu_debug_read_prof(out)
 t = np.array(out[:])
 passes, steps = t[16], t[17]
-tot = t[:16].sum()
+tot = t[:16].sum() + t[18] + t[19]
 names = ["headings", "positions+publish", "segments", "fleet+static", "dynamic", "pads+constraint sums", "phase B", "combine", "vector terms+psi", "adjoint"]
 print(f"latency kernel, N_hor {NH}, {B} problems of the benchmark family (one team of four wavefronts each): solve {bs.last_timing()['solve_ms']:.1f} ms; per problem "
       f"{steps / B:.0f} PANOC steps, {passes / B:.0f} passes ({passes / steps:.2f} per step), {tot / steps:.0f} cycles per step (wavefront 0)")
@@ -31,5 +31,7 @@ print(f"  evaluation passes                {ev / steps:8.0f} cycles per step = {
 for i, n in enumerate(names):
     print(f"      {n:26s} {t[i] / passes:8.0f} per pass")
 for i, n in ((10, "verdict barrier (publish + wait for the slowest wavefront)"), (11, "adoption of the winning trial (LDS hand-over + barrier)"),
-             (12, "L-BFGS pair update + direction (Gram form)"), (14, "step residual (two reductions, exit tests)"), (13, "other logic between passes")):
-    print(f"  {n:62s} {t[i] / steps:8.0f} cycles per step   {100 * t[i] / tot:5.1f} %")
+             (12, "L-BFGS pair update + direction (Gram form)"), (14, "step residual (two reductions, exit tests)"),
+             (15, "end of a pass -> its verdict (Lipschitz / acceptance test, envelope sums)"), (18, "bookkeeping of a completed step up to the residual"),
+             (19, "direction -> next pass (rhs, trial points, the loop's back edge + state dispatch)"), (13, "the rest (rare states)")):
+    print(f"  {n:84s} {t[i] / steps:8.0f} cycles per step   {100 * t[i] / tot:5.1f} %")

@@ -281,7 +281,7 @@ __global__ __launch_bounds__(WAVE * TW) MPC_TEAM_ATTR void solve_kernel_team(KPa
     // write its flag of pass k + 1 while a slow one still reads the four flags of pass k.
     int pub_slot = 0;
     auto publish = [&](double flag, double* all) {
-        PROF_MARK(13);
+        PROF_MARK(15);
         if (lane == 0) XF[wid * TEAM_XCH + pub_slot] = flag;
         __syncthreads();
         for (int j = 0; j < TW; ++j) all[j] = uniform(XF[j * TEAM_XCH + pub_slot]);
@@ -326,8 +326,9 @@ __global__ __launch_bounds__(WAVE * TW) MPC_TEAM_ATTR void solve_kernel_team(KPa
             resume_pending = false;
             step_begin = true;
         } else {
-        PROF_MARK(13);    // (profile builds: slots 10 verdict barrier, 11 adoption, 12 L-BFGS pair + direction, 13 other logic between two passes,
-        PROF_COUNT(16);   //  14 step residual; counts: 16 passes, 17 PANOC steps; wavefront 0 of every team reports)
+        PROF_MARK(19);    // (profile builds: slots 10 verdict barrier, 11 adoption, 12 L-BFGS pair + direction, 14 step residual, 15 end of a pass -> its
+        PROF_COUNT(16);   //  verdict, 18 bookkeeping of a completed step, 19 direction -> next pass incl. the loop's back edge, 13 the rest; counts: 16 passes,
+                          //  17 PANOC steps; wavefront 0 of every team reports)
         eval_point<NT, SC, P>(kp, cx, ev, ew, c, icm, ya, yb, want_grad, state == TS_OUTER, o PROF_PASS);
 
         if (state == TS_INIT0) {
@@ -509,7 +510,7 @@ __global__ __launch_bounds__(WAVE * TW) MPC_TEAM_ATTR void solve_kernel_team(KPa
                 }
             }
             if (!inner_done) {
-                PROF_MARK(13);
+                PROF_MARK(18);
                 PROF_COUNT(17);
                 const bool solved = panoc_step_residual<P>(cx, kp, vl, uv, uw, hv, hw, gv, gw, gamma, iter, akkt_tol, rv_, rw_, nfpr, ip);
                 PROF_MARK(14);
