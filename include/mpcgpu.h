@@ -161,7 +161,7 @@ int32_t mpcgpu_reserve_shape(void* handle, int32_t max_static, int32_t max_fleet
 
 /* Size the library-owned device buffers (workspace records, counters) for batches of up to B problems now, so that later
  * mpcgpu_solve_batch_dev calls allocate nothing (required before a call is captured into a hipGraph; growth is otherwise
- * automatic and drains the device first).  For a batch of the latency range (up to four problems per compute unit) without a
+ * automatic and drains the device first).  For a batch of the latency range (MPCGPU_OPT_TEAM_BATCH: by default up to two problems per compute unit) without a
  * reservation it also opts the one-launch latency kernel into its LDS size: inside a capture that whole range takes the
  * one-launch form (tables for the configured maxima, nothing read back). */
 int32_t mpcgpu_reserve_batch(void* handle, int32_t B);
@@ -264,7 +264,8 @@ int32_t mpcgpu_set_option(void* handle, int32_t option, double value);
 int32_t mpcgpu_last_waves_per_simd(void* handle);
 
 /* Wavefronts per problem of the latency kernel when the last solve call ran it (MPCGPU_OPT_TEAM_BATCH): 4, or 2 for batches
- * between two and four problems per compute unit; 0 = the throughput kernel ran. */
+ * between two and four problems per compute unit (when MPCGPU_OPT_TEAM_BATCH admits them: the default range ends at two); 0 = the throughput
+ * kernel ran. */
 int32_t mpcgpu_last_latency_kernel(void* handle);
 
 /* Dynamic-obstacle tables of the last solve / cost_grad launch, in the coding of mpcgpu_reserve_shape's var_shape: 1 general
