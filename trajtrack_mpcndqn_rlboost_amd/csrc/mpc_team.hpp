@@ -53,6 +53,14 @@ enum { TS_INIT0 = 0, TS_INIT1, TS_FIRST, TS_SPEC, TS_LIPSEQ, TS_BATCH, TS_FALLBA
 #else
 #define MPC_TEAM_ATTR __attribute__((amdgpu_waves_per_eu(MPC_TEAM_WPE, MPC_TEAM_WPE)))
 #endif
+// Round 6: the PANOC steps of the common path -- residual, speculative L-BFGS step, the pass with the Lipschitz test and the first
+// trials, further trial passes -- in a loop of their OWN with their own call sites of the evaluation (what the throughput kernel got in
+// round 3, MPC_STEP_LOOP); the rare states (first step of an inner problem, Lipschitz updates, the tau = 0 fallback, outer steps) stay
+// in the state machine around it.  Same step functions on the same values in the same order: same bits.  0 = one loop around one call
+// site (rounds 3-5).
+#ifndef MPC_TEAM_STEP_LOOP
+#define MPC_TEAM_STEP_LOOP 1
+#endif
 // CONCURRENT (round 5): with kp.yield_persist the kernel runs on a second stream WHILE the throughput launch drains (behind
 // tail_gate_kernel, which holds it back until the launch starts to promote).  Workgroup g waits for list entry g -- entries appear
 // in index order and workgroups are dispatched in index order, so the resident ones wait for the entries that come next -- or until
@@ -320,6 +328,85 @@ __global__ __launch_bounds__(WAVE * TW) MPC_TEAM_ATTR void solve_kernel_team(KPa
     };
     auto trial_point = [&](double t) { ev = panoc_trial(uv, rv_, dv, t); ew = panoc_trial(uw, rw_, dw, t); };
 
+    // The verdict of a pass, shared by the state machine and the step loop (MPC_TEAM_STEP_LOOP).  After the pass that carries the Lipschitz
+    // test and the first trials: 0 = the test failed (state = TS_LIPSEQ, the half step is the next point), 1 = a trial was adopted (the next
+    // step begins), 2 = none accepted (state = TS_BATCH, the next trials are set).
+    auto spec_verdict = [&]() -> int {
+            // wavefront 0: psi at the half step (Lipschitz test); wavefronts 1..3: trials tau = 1, 1/2, 1/4
+            double thv = 0.0, thw = 0.0, tgg = 0.0, td2h = 0.0, flag;
+            if (wid == 0) {
+                flag = (panoc_lip_test_fails(cx, o.psi, cost, ip, ig, nfpr) && lip_it < MAX_LIP_IT && Lip < KC(K_MAX_LIP)) ? 1.0 : 0.0;
+            } else {
+                panoc_envelope_sums<P>(kp, vl, ev, ew, gamma, o.gv, o.gw, thv, thw, tgg, td2h);
+                flag = panoc_fbe(uniform(o.psi), gamma, ig, tgg, td2h) > rhs ? 0.0 : 1.0;  // 1 = accepted
+            }
+            double all[TW];
+            publish(flag, all);
+            ++n_eval;
+            if (all[0] != 0.0) {
+                // Lipschitz test failed: the speculative pair and direction are void (the buffer is flushed).  The ring position
+                // goes back as well: the Gram form sums the rows in slot order, so the bits depend on where the ring stands, and
+                // the one-wavefront kernel never stored this pair.
+                lb.flush();
+                lb.head = head_spec;
+                panoc_lip_update<P>(kp, vl, uv, uw, gv, gw, Lip, gamma, ig, hv, hw, rv_, rw_, d2h, nfpr, ip);
+                ++lip_it;
+                ev = hv; ew = hw; want_grad = false; state = TS_LIPSEQ;
+                return 0;
+            }
+            int winner = 0;
+            for (int j = TW - 1; j >= 1; --j) if (all[j] != 0.0) winner = j;
+            if (winner) {
+                nls = winner - 1;
+                n_eval += nls + 1; n_eval_grad += nls + 1;
+                TEAM_TRACE_PSI();
+                adopt(winner, uniform(o.psi), tgg, td2h, thv, thw);
+                TEAM_TRACE(nls, pow2_neg(nls));
+                ++iter;
+                return 1;
+            }
+            n_eval += TW - 1; n_eval_grad += TW - 1;
+            TEAM_TRACE_PSI();
+            t0 = TW - 1;
+            trial_point(pow2_neg(t0 + wid));
+            want_grad = true; state = TS_BATCH;
+            return 2;
+    };
+    // ... after a pass of trials only: 1 = adopted, 2 = the next trials are set, 3 = ten halvings without acceptance under the tau = 0 reading
+    // (state = TS_FALLBACK, the point u - gamma fpr is set).
+    auto batch_verdict = [&]() -> int {
+            // trials t0 + wid, tau = 2^-t; t = MAX_LS_IT is taken unconditionally (ls_fallback = 0) or leads to the tau = 0 point
+            double thv, thw, tgg, td2h;
+            panoc_envelope_sums<P>(kp, vl, ev, ew, gamma, o.gv, o.gw, thv, thw, tgg, td2h);
+            const int t = t0 + wid;
+            const bool accepted = !(panoc_fbe(uniform(o.psi), gamma, ig, tgg, td2h) > rhs);
+            const double flag = t > MAX_LS_IT ? 0.0 : (accepted ? 1.0 : (t == MAX_LS_IT ? 2.0 : 0.0));  // 2 = last trial, rejected
+            double all[TW];
+            publish(flag, all);
+            int winner = -1;
+            for (int j = TW - 1; j >= 0; --j) if (all[j] != 0.0) winner = j;
+            if (winner >= 0) {
+                nls = t0 + winner;
+                n_eval += winner + 1; n_eval_grad += winner + 1;
+                if (all[winner] == 2.0 && kp.ls_fallback == 1) {
+                    TEAM_TRACE_PSI();
+                    // 10 halvings without acceptance, tau = 0 reading: u - gamma*fpr is evaluated and taken
+                    ev = uv - rv_; ew = uw - rw_;
+                    want_grad = true; state = TS_FALLBACK;
+                    return 3;
+                }
+                TEAM_TRACE_PSI();
+                adopt(winner, uniform(o.psi), tgg, td2h, thv, thw);
+                TEAM_TRACE(nls, pow2_neg(nls));
+                ++iter;
+                return 1;
+            }
+            n_eval += TW; n_eval_grad += TW;
+            t0 += TW;
+            trial_point(pow2_neg(t0 + wid));
+            return 2;
+    };
+
     for (;;) {
         bool step_begin = false;
         if (MPC_YIELD_STEP && resume_pending) {
@@ -378,78 +465,9 @@ __global__ __launch_bounds__(WAVE * TW) MPC_TEAM_ATTR void solve_kernel_team(KPa
                 continue;
             }
         } else if (state == TS_SPEC) {
-            // wavefront 0: psi at the half step (Lipschitz test); wavefronts 1..3: trials tau = 1, 1/2, 1/4
-            double thv = 0.0, thw = 0.0, tgg = 0.0, td2h = 0.0, flag;
-            if (wid == 0) {
-                flag = (panoc_lip_test_fails(cx, o.psi, cost, ip, ig, nfpr) && lip_it < MAX_LIP_IT && Lip < KC(K_MAX_LIP)) ? 1.0 : 0.0;
-            } else {
-                panoc_envelope_sums<P>(kp, vl, ev, ew, gamma, o.gv, o.gw, thv, thw, tgg, td2h);
-                flag = panoc_fbe(uniform(o.psi), gamma, ig, tgg, td2h) > rhs ? 0.0 : 1.0;  // 1 = accepted
-            }
-            double all[TW];
-            publish(flag, all);
-            ++n_eval;
-            if (all[0] != 0.0) {
-                // Lipschitz test failed: the speculative pair and direction are void (the buffer is flushed).  The ring position
-                // goes back as well: the Gram form sums the rows in slot order, so the bits depend on where the ring stands, and
-                // the one-wavefront kernel never stored this pair.
-                lb.flush();
-                lb.head = head_spec;
-                panoc_lip_update<P>(kp, vl, uv, uw, gv, gw, Lip, gamma, ig, hv, hw, rv_, rw_, d2h, nfpr, ip);
-                ++lip_it;
-                ev = hv; ew = hw; want_grad = false; state = TS_LIPSEQ;
-                continue;
-            }
-            int winner = 0;
-            for (int j = TW - 1; j >= 1; --j) if (all[j] != 0.0) winner = j;
-            if (winner) {
-                nls = winner - 1;
-                n_eval += nls + 1; n_eval_grad += nls + 1;
-                TEAM_TRACE_PSI();
-                adopt(winner, uniform(o.psi), tgg, td2h, thv, thw);
-                TEAM_TRACE(nls, pow2_neg(nls));
-                ++iter;
-                step_begin = true;
-            } else {
-                n_eval += TW - 1; n_eval_grad += TW - 1;
-                TEAM_TRACE_PSI();
-                t0 = TW - 1;
-                trial_point(pow2_neg(t0 + wid));
-                want_grad = true; state = TS_BATCH;
-                continue;
-            }
+            if (spec_verdict() == 1) step_begin = true; else continue;
         } else if (state == TS_BATCH) {
-            // trials t0 + wid, tau = 2^-t; t = MAX_LS_IT is taken unconditionally (ls_fallback = 0) or leads to the tau = 0 point
-            double thv, thw, tgg, td2h;
-            panoc_envelope_sums<P>(kp, vl, ev, ew, gamma, o.gv, o.gw, thv, thw, tgg, td2h);
-            const int t = t0 + wid;
-            const bool accepted = !(panoc_fbe(uniform(o.psi), gamma, ig, tgg, td2h) > rhs);
-            const double flag = t > MAX_LS_IT ? 0.0 : (accepted ? 1.0 : (t == MAX_LS_IT ? 2.0 : 0.0));  // 2 = last trial, rejected
-            double all[TW];
-            publish(flag, all);
-            int winner = -1;
-            for (int j = TW - 1; j >= 0; --j) if (all[j] != 0.0) winner = j;
-            if (winner >= 0) {
-                nls = t0 + winner;
-                n_eval += winner + 1; n_eval_grad += winner + 1;
-                if (all[winner] == 2.0 && kp.ls_fallback == 1) {
-                    TEAM_TRACE_PSI();
-                    // 10 halvings without acceptance, tau = 0 reading: u - gamma*fpr is evaluated and taken
-                    ev = uv - rv_; ew = uw - rw_;
-                    want_grad = true; state = TS_FALLBACK;
-                    continue;
-                }
-                TEAM_TRACE_PSI();
-                adopt(winner, uniform(o.psi), tgg, td2h, thv, thw);
-                TEAM_TRACE(nls, pow2_neg(nls));
-                ++iter;
-                step_begin = true;
-            } else {
-                n_eval += TW; n_eval_grad += TW;
-                t0 += TW;
-                trial_point(pow2_neg(t0 + wid));
-                continue;
-            }
+            if (batch_verdict() == 1) step_begin = true; else continue;
         } else if (state == TS_FALLBACK) {
             ++n_eval; ++n_eval_grad;
             uv = ev; uw = ew;
@@ -497,47 +515,66 @@ __global__ __launch_bounds__(WAVE * TW) MPC_TEAM_ATTR void solve_kernel_team(KPa
         }   // (evaluation + its state; skipped once when the kernel resumes at a step boundary)
 
         if (step_begin) {
-            bool inner_done = false;
-            if (state != TS_INIT1) {
-                if (cont_iters && cont_time) {
-                    ++num_iter;
-                    cont_iters = num_iter < kp.max_inner;
-                    // the wall clock is looked at every 16th step (a barrier per look: wavefront 0 decides for all); the throughput
-                    // kernel looks every step -- a time-out is not reproducible to the step in either
-                    if (kp.max_ticks > 0 && (num_iter & 15) == 0) cont_time = time_left();
-                } else {
-                    inner_done = true;
+            bool to_machine = false;   // leave for the state machine and its call site of the evaluation
+            for (;;) {                 // MPC_TEAM_STEP_LOOP: one trip per PANOC step while the common path holds (else: a single trip)
+                bool inner_done = false;
+                if (state != TS_INIT1) {
+                    if (cont_iters && cont_time) {
+                        ++num_iter;
+                        cont_iters = num_iter < kp.max_inner;
+                        // the wall clock is looked at every 16th step (a barrier per look: wavefront 0 decides for all); the throughput
+                        // kernel looks every step -- a time-out is not reproducible to the step in either
+                        if (kp.max_ticks > 0 && (num_iter & 15) == 0) cont_time = time_left();
+                    } else {
+                        inner_done = true;
+                    }
                 }
-            }
-            if (!inner_done) {
+                if (inner_done) break;
                 PROF_MARK(18);
                 PROF_COUNT(17);
                 const bool solved = panoc_step_residual<P>(cx, kp, vl, uv, uw, hv, hw, gv, gw, gamma, iter, akkt_tol, rv_, rw_, nfpr, ip);
                 PROF_MARK(14);
-                if (solved) {
-                    inner_done = true;
-                } else {
-                    lip_it = 0;
-                    if (iter == 0) {
-                        ev = hv; ew = hw; want_grad = true; state = TS_FIRST;
-                    } else {
-                        // speculation: pair update and direction before the Lipschitz test is known
-                        sigma = uniform(KC(K_SIGMA) * ig);
-                        head_spec = lb.head;
-                        double lb_pr = 0.0;
-                        PROF_MARK(13);
-                        lb.template update<P, NT, MEMT>(cx, kp, vl, lane, uv, uw, rv_, rw_, nfpr, lm, lb_pr);
-                        wave_sync();
-                        lb.template direction<P, NT, MEMT, true>(cx, kp, vl, lane, rv_, rw_, lm, lb_pr, dv, dw);
-                        PROF_MARK(12);
-                        rhs = panoc_fbe_rhs(cost, gamma, ig, gg, d2h, sigma, nfpr);
-                        if (wid == 0) { ev = hv; ew = hw; want_grad = false; }
-                        else { trial_point(pow2_neg(wid - 1)); want_grad = true; }
-                        state = TS_SPEC;
-                    }
-                    continue;
+                if (solved) break;
+                lip_it = 0;
+                if (iter == 0) {
+                    ev = hv; ew = hw; want_grad = true; state = TS_FIRST;
+                    to_machine = true;
+                    break;
                 }
+                // speculation: pair update and direction before the Lipschitz test is known
+                sigma = uniform(KC(K_SIGMA) * ig);
+                head_spec = lb.head;
+                double lb_pr = 0.0;
+                PROF_MARK(13);
+                lb.template update<P, NT, MEMT>(cx, kp, vl, lane, uv, uw, rv_, rw_, nfpr, lm, lb_pr);
+                wave_sync();
+                lb.template direction<P, NT, MEMT, true>(cx, kp, vl, lane, rv_, rw_, lm, lb_pr, dv, dw);
+                PROF_MARK(12);
+                rhs = panoc_fbe_rhs(cost, gamma, ig, gg, d2h, sigma, nfpr);
+                if (wid == 0) { ev = hv; ew = hw; want_grad = false; }
+                else { trial_point(pow2_neg(wid - 1)); want_grad = true; }
+                state = TS_SPEC;
+#if MPC_TEAM_STEP_LOOP
+                // the pass with the Lipschitz test and the first trials, then passes of trials only: call sites of their own
+                PROF_MARK(19);
+                PROF_COUNT(16);
+                eval_point<NT, SC, P>(kp, cx, ev, ew, c, icm, ya, yb, want_grad, false, o PROF_PASS);
+                int act = spec_verdict();
+                if (act == 2) {
+                    for (;;) {
+                        PROF_MARK(19);
+                        PROF_COUNT(16);
+                        eval_point<NT, SC, P>(kp, cx, ev, ew, c, icm, ya, yb, want_grad, false, o PROF_PASS);
+                        act = batch_verdict();
+                        if (act != 2) break;
+                    }
+                }
+                if (act == 1) continue;   // a trial was adopted: the next step begins
+#endif
+                to_machine = true;        // (step loop: a Lipschitz update or the tau = 0 fallback -- rare; else: every pass is the state machine's)
+                break;
             }
+            if (to_machine) continue;
             status = !cont_iters ? 1 : (!cont_time ? 2 : 0);
             uv = hv; uw = hw;
             ev = uv; ew = uw; want_grad = false; state = TS_OUTER;
