@@ -41,6 +41,11 @@
 #ifndef MPC_CACHE_B40
 #define MPC_CACHE_B40 0
 #endif
+// L-BFGS pair update: the sums of an accepted pair next to those of the acceptance test (see PanocLbfgsGram::update).  Round-6 experiment, measured:
+// the latency kernel LOSES 3 % (27.3 -> 28.2 ms for a cap-length solve), the throughput kernel is indifferent: not used.
+#ifndef MPC_LB_HOIST_SUMS
+#define MPC_LB_HOIST_SUMS 0
+#endif
 
 namespace mpcgpu {
 
@@ -2007,6 +2012,14 @@ struct PanocLbfgsGram {
         }
         double ys, ss;
         P::sum2(__builtin_fma(s0, y0_, s1 * y1_), __builtin_fma(s0, s0, s1 * s1), ys, ss);
+#if MPC_LB_HOIST_SUMS
+        // the three sums of an ACCEPTED pair (y'y, s'r, y'r), formed here -- next to the two of the acceptance test and ahead of pass 1 -- instead of
+        // behind the test: three independent reduction chains the scheduler can interleave (a lone wavefront of the latency kernel waits out
+        // every DPP step of a single chain); a rejected pair (rare) has computed them for nothing.  The same sums: same bits.
+        double yy_h, sr_h;
+        P::sum2(__builtin_fma(y0_, y0_, y1_ * y1_), __builtin_fma(s0, rv, s1 * rw), yy_h, sr_h);
+        const double yr_h = dot2r<P, P::RV>(y0_, y1_, rv, rw);
+#endif
         wave_sync();
         double ar = 0.0, ay = 0.0;
         auto mac = [&](const double2 mv, int k) {
@@ -2037,9 +2050,13 @@ struct PanocLbfgsGram {
         }
         pr = ar;
         if (!(ss <= KC(K_DBLMIN) || ys <= KC(K_MIN_L)) && (ys > (KC(K_CBFGS) * nfpr) * ss)) {  // s'y / ||s||^2 > eps ||gamma fpr||, ||s||^2 > 0
+#if MPC_LB_HOIST_SUMS
+            const double yy = yy_h, sr = sr_h, yr = yr_h;
+#else
             double yy, sr;
             P::sum2(__builtin_fma(y0_, y0_, y1_ * y1_), __builtin_fma(s0, rv, s1 * rw), yy, sr);
             const double yr = dot2r<P, P::RV>(y0_, y1_, rv, rw);
+#endif
             head = head == 0 ? mem - 1 : head - 1;
             const int h = head;
             if (vl) {
